@@ -1,0 +1,176 @@
+"""Generate tests/golden/*.npz by executing the REAL reference (read-only at /root/reference).
+
+TEST INFRASTRUCTURE ONLY -- runs in the build container (the reference does not exist on the GPU
+box).  Shims, none of which touches /root/reference:
+  1. torchvision is not installed -> stub ``torchvision.ops.nms`` with the greedy restatement;
+  2. ``load_pretrained_weights`` -> no-op (no network; weights come from make_state_dict);
+  3. ``Tensor.cuda`` -> identity (models/losses.py hard-codes .cuda()) and an out-of-place rewrite
+     of models/bifpn.py:178,180 (the in-place ``w /=`` breaks autograd on torch >= 1.5).
+
+Usage:  python oracle/make_golden.py            (writes tests/golden/)
+"""
+import hashlib
+import inspect
+import os
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import effdet_oracle as O  # noqa: E402
+
+REF = '/root/reference'
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    tv, ops = types.ModuleType('torchvision'), types.ModuleType('torchvision.ops')
+    ops.nms = lambda boxes, scores, iou_threshold: O.nms_greedy(boxes, scores, iou_threshold)
+    tv.ops = ops
+    sys.modules['torchvision'], sys.modules['torchvision.ops'] = tv, ops          # shim 1
+    import models.utils as mu
+    import models.efficientnet as me
+    mu.load_pretrained_weights = me.load_pretrained_weights = lambda *a, **k: None  # shim 2
+    from models.efficientdet import EfficientDet
+    import models.bifpn as mb
+    torch.Tensor.cuda = lambda self, *a, **k: self                                 # shim 3a
+    src = inspect.getsource(mb.BiFPNModule.forward) \
+        .replace("w1 /= torch.sum(w1, dim=0) + self.eps", "w1 = w1 / (torch.sum(w1, dim=0) + self.eps)") \
+        .replace("w2 /= torch.sum(w2, dim=0) + self.eps", "w2 = w2 / (torch.sum(w2, dim=0) + self.eps)")
+    ns = {}
+    exec(textwrap.dedent(src), mb.__dict__, ns)
+    mb.BiFPNModule.forward = ns['forward']                                         # shim 3b
+    return EfficientDet
+
+
+def build_ref(EfficientDet, network, num_classes, sd, **kw):
+    c = O.EFFICIENTDET[network]
+    m = EfficientDet(num_classes=num_classes, network=network, W_bifpn=c['W_bifpn'],
+                     D_bifpn=c['D_bifpn'], D_class=c['D_class'], **kw)
+    ref_keys = list(m.state_dict().keys())
+    assert ref_keys == list(sd.keys()), 'state_dict key layout differs from the reference'
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), (k, v.shape, sd[k].shape)
+    m.load_state_dict(sd)
+    # parity runs: no drop_connect
+    m.backbone._global_params = m.backbone._global_params._replace(drop_connect_rate=0.0)
+    return m
+
+
+def sample(t, n=256):
+    """Deterministic strided sample of a tensor (fixture stays small)."""
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
+    return f[idx].numpy().astype(np.float32)
+
+
+def summary(t):
+    f = t.detach().double().reshape(-1)
+    return np.array([f.sum().item(), f.abs().sum().item(), (f * f).sum().sqrt().item()], dtype=np.float64)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def taps_from_reference(m, img):
+    """Stage-boundary activations of the real reference via forward hooks."""
+    taps = {}
+    hooks = [m.backbone._bn0.register_forward_hook(lambda mod, i, o: None)]
+    for i, blk in enumerate(m.backbone._blocks):
+        hooks.append(blk.register_forward_hook(lambda mod, i_, o, k=f'block{i}': taps.__setitem__(k, o.detach().clone())))
+    for l, lc in enumerate(m.neck.lateral_convs):
+        hooks.append(lc.register_forward_hook(lambda mod, i_, o, k=f'lateral{l}': taps.__setitem__(k, o.detach().clone())))
+    for s, bm in enumerate(m.neck.stack_bifpn_convs):
+        def h(mod, i_, o, s=s):
+            for l, t in enumerate(o):
+                taps[f'bifpn{s}_p{l}'] = t.detach().clone()
+        hooks.append(bm.register_forward_hook(h))
+    return taps, hooks
+
+
+def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=True, seed=0):
+    sd = O.make_state_dict(network, num_classes, seed=seed)
+    m = build_ref(EfficientDet, network, num_classes, sd, is_training=False, threshold=threshold)
+    m.eval()
+    img, _ = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
+    taps, hooks = taps_from_reference(m, img)
+    with torch.no_grad():
+        x = m.extract_feat(img)
+        outs = m.bbox_head(x)
+        cls = torch.cat(list(outs[0]), 1); reg = torch.cat(list(outs[1]), 1)
+        anc = m.anchors(img)
+    for h_ in hooks:
+        h_.remove()
+    with torch.no_grad():
+        dets = [m(img[b:b + 1]) for b in range(B)]       # the reference only post-processes image 0 (Q8)
+    d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed, threshold=threshold,
+             anchors_sha256=sha(anc.numpy()), anchors_first=anc[0, :4].numpy(), anchors_last=anc[0, -4:].numpy(),
+             cls_summary=summary(cls), reg_summary=summary(reg), cls_sample=sample(cls, 4096), reg_sample=sample(reg, 4096))
+    if full:
+        d['cls'] = cls.numpy(); d['reg'] = reg.numpy(); d['anchors'] = anc.numpy()
+    for k, v in taps.items():
+        d['tap_' + k + '_sample'] = sample(v, 512)
+        d['tap_' + k + '_summary'] = summary(v)
+    for b, (s_, c_, bx) in enumerate(dets):
+        d[f'det{b}_scores'] = s_.numpy(); d[f'det{b}_labels'] = c_.numpy(); d[f'det{b}_boxes'] = bx.numpy()
+    # NMS candidates of image 0 exactly as the reference builds them (models/efficientdet.py:69-83)
+    with torch.no_grad():
+        boxes = m.clipBoxes(m.regressBoxes(anc, reg[:1]), img[:1])
+        scores = cls[:1].max(dim=2, keepdim=True)[0]
+        mask = (scores > threshold)[0, :, 0]
+        cb, cs = boxes[0, mask], scores[0, mask, 0]
+        keep = O.nms_greedy(cb, cs, 0.5)
+    d['nms_boxes'] = cb.numpy(); d['nms_scores'] = cs.numpy(); d['nms_keep'] = keep.numpy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'cls', tuple(cls.shape), 'cands', int(mask.sum()), 'kept', [len(x[0]) for x in dets])
+
+
+def case_train(EfficientDet, name, network, num_classes, B, S, seed=0):
+    sd = O.make_state_dict(network, num_classes, seed=seed)
+    m = build_ref(EfficientDet, network, num_classes, sd, is_training=True)
+    m.train(); m.is_training = True; m.freeze_bn()
+    img, ann = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
+    ann[-1, :, :] = -1.0            # last image has no annotations -> zero-loss branch (losses.py:54-58)
+    cl, rl = m([img, ann])
+    (cl.mean() + rl.mean()).backward()
+    d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed,
+             cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), annots=ann.numpy())
+    dead = []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            dead.append(k); continue
+        d['grad_' + k + '_sample'] = sample(p.grad, 64)
+        d['grad_' + k + '_summary'] = summary(p.grad)
+    d['dead_params'] = np.array(dead)
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'losses', cl.item(), rl.item(), 'dead', dead)
+
+
+def case_anchors(EfficientDet):
+    from models.module import Anchors
+    a = Anchors()
+    d = {}
+    for (H, W) in [(128, 128), (512, 512), (1024, 1024), (256, 384), (640, 512)]:
+        anc = a(torch.zeros(1, 3, H, W)).numpy()
+        d[f'sha_{H}x{W}'] = sha(anc); d[f'n_{H}x{W}'] = anc.shape[1]
+        d[f'head_{H}x{W}'] = anc[0, :18]; d[f'tail_{H}x{W}'] = anc[0, -18:]
+    np.savez_compressed(os.path.join(OUT, 'anchors.npz'), **d)
+    print('anchors', {k: v for k, v in d.items() if k.startswith('n_')})
+
+
+if __name__ == '__main__':
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    E = import_reference()
+    case_anchors(E)
+    case_eval(E, 'd0_128_eval', 'efficientdet-d0', 20, 2, 128, threshold=0.5)
+    case_train(E, 'd0_128_train', 'efficientdet-d0', 20, 3, 128)
+    case_eval(E, 'd0_512_eval', 'efficientdet-d0', 80, 1, 512, threshold=0.6, full=False)
+    case_eval(E, 'd4_256_eval', 'efficientdet-d4', 4, 1, 256, threshold=0.5, full=False)
+    case_train(E, 'd1_128_train', 'efficientdet-d1', 6, 2, 128)
