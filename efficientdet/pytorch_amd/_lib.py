@@ -1,0 +1,93 @@
+"""ctypes binding of libeffdet_hip.so (include/effdet_hip.h).
+
+The library is the product: there is NO CPU / eager fallback.  ``lib()`` raises if the shared
+library is missing and every op raises if a call returns a non-zero status.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must be imported first: the .so binds to torch's already-loaded libamdhip64)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libeffdet_hip.so')
+MAX_SEG = 5
+F32, BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
+RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
+
+_ERR = {-1: 'EFFDET_EINVAL', -2: 'EFFDET_ELAUNCH', -3: 'EFFDET_EUNSUPPORTED'}
+
+
+class Seg(C.Structure):
+    _fields_ = [('H', C.c_int), ('W', C.c_int), ('Ho', C.c_int), ('Wo', C.c_int),
+                ('in_off', C.c_longlong), ('in_bstride', C.c_longlong),
+                ('out_off', C.c_longlong), ('out_bstride', C.c_longlong)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('res', C.c_void_p),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('rowscale', C.c_void_p),
+                ('dtype', C.c_int), ('out_f32', C.c_int),
+                ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
+                ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
+                ('ldx', C.c_int), ('ldy', C.c_int), ('act', C.c_int), ('res_mode', C.c_int),
+                ('nseg', C.c_int), ('seg', Seg * MAX_SEG)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('dz', C.c_void_p), ('dw', C.c_void_p), ('dbias', C.c_void_p),
+                ('dtype', C.c_int),
+                ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
+                ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
+                ('ldx', C.c_int), ('lddz', C.c_int), ('nseg', C.c_int), ('seg', Seg * MAX_SEG)]
+
+
+_lib = None
+
+# every symbol include/effdet_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    'effdet_conv2d', 'effdet_conv2d_wgrad', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad',
+    'effdet_stem_fwd', 'effdet_stem_wgrad', 'effdet_dwconv_fwd', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad',
+    'effdet_se_gate_fwd', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_gate_bwd', 'effdet_se_bwd_apply',
+    'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_bwd',
+    'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
+    'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd',
+    'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_version',
+]
+
+
+def lib():
+    """Load (once) and return the HIP library; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libeffdet_hip.so is missing (%s). Build it with `python -m efficientdet.pytorch_amd.build` '
+                '(or __graft_entry__.build()). There is no CPU fallback for this path.' % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.effdet_version.restype = C.c_char_p
+        for name in ('effdet_num_anchors', 'effdet_nms_workspace_bytes', 'effdet_loss_workspace_bytes'):
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_longlong
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError('%s failed: %s (%d)' % (what, _ERR.get(status, 'unknown'), status))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def dtype_code(t):
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError('unsupported storage dtype %s' % t)

@@ -1,0 +1,298 @@
+// Dense convolution as an implicit GEMM on the CDNA4 matrix cores (gfx950).
+//
+//   y[m][n] = epilogue( sum_{tap,c} x[pix(m)+tap][c] * w[n][tap][c] )      m = (b,ho,wo), NHWC
+//
+// Design (MI355X-first):
+//   * block tile 128 (m) x BN (n), 4 waves of 64 lanes; K is walked in steps of 128 BYTES per row
+//     (64 bf16 or 32 fp32 channels) = two MFMA "slices" of 4 x 16-byte chunks.
+//   * both operands are staged through LDS as [row][8 chunks of 16 B] with the chunk index XORed
+//     by (row>>1)&7: ds_write_b128 of one 128-B row by 8 consecutive lanes and the fragment
+//     ds_read_b128 (lane l reads row l&15, chunk l>>4) are both bank-conflict free for the
+//     16-lane service groups of gfx950's 64-bank LDS.
+//   * the weight tile is the MFMA A operand and the activation tile the B operand, so every lane
+//     ends up with 4 CONSECUTIVE OUTPUT CHANNELS of one pixel -> 8/16-byte NHWC stores and float4
+//     scale/shift loads in the fused epilogue (bias / frozen-BN affine / ReLU / Swish / sigmoid /
+//     residual / activation-gradient masks).
+//   * bf16: v_mfma_f32_16x16x32_bf16 (8 k per lane); fp32: 4 x v_mfma_f32_16x16x4_f32 fed from the
+//     same 16-byte chunk (exact fp32, = fmaf chain) -- identical byte geometry for both dtypes.
+//   * software pipeline: global loads of K-step t+1 are issued before the MFMAs of step t and
+//     written to the other LDS buffer afterwards; one barrier per K-step.
+//   * im2col-free: per-thread (tap, channel-chunk) cursors advance incrementally, halo / tail
+//     lanes load zeros.  Several pyramid levels that share weights run as ONE grouped launch
+//     (segments), which keeps the tiny 8x8 / 4x4 levels from being launch-bound.
+//   * 1-D grid with a bijective XCD remap: the 8 blocks that land on one XCD walk neighbouring
+//     tiles (n fastest), so the activation tile is fetched into one private L2 only.
+#include "common.h"
+
+namespace {
+
+struct SegD {
+  int H, W, Ho, Wo, M, tile_start;
+  long long in_off, in_bs, out_off, out_bs;
+};
+
+struct ConvK {
+  const void* x; const void* w; void* y; void* z; const void* res;
+  const float* scale; const float* shift; const float* rowscale;
+  int Cin, Cout, KW, stride, pad_t, pad_l;
+  int ldx, ldy;
+  int Kc;    // K in 16-byte chunks (= KH*KW*Cin/CE)
+  int cpt;   // chunks per tap (= Cin/CE)
+  int act, res_mode, out_f32, vec_ok;
+  int nseg, mtiles, ntiles;
+  SegD seg[EFFDET_MAX_SEG];
+};
+
+constexpr int BM = 128;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+  }
+};
+
+// BN: block tile width in n; WAVES_N: waves along n (WAVES_M = 4 / WAVES_N)
+template <typename T, int BN, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+  constexpr int CE = Elem<T>::CE;
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int XLD = BM * 8;               // uint4 per X buffer
+  constexpr int WLD = BN * 8;
+  constexpr int WROWS = (BN + 31) / 32;     // weight rows per thread per K-step
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  uint4* xs = smem;                // [2][BM*8]
+  uint4* ws = smem + 2 * XLD;      // [2][BN*8]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm0 = (wave / WAVES_N) * WTM, wn0 = (wave % WAVES_N) * WTN;
+
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+  int si = 0;
+#pragma unroll
+  for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+    if (s < p.nseg && mt >= p.seg[s].tile_start) si = s;
+  const SegD sg = p.seg[si];
+  const int m_base = (mt - sg.tile_start) * BM;
+  const int n_base = nt * BN;
+  const int HoWo = sg.Ho * sg.Wo;
+
+  // ---- per-thread load bookkeeping: chunk column kc, rows tid/8 + 32*j ----
+  const int kc = tid & 7, r0 = tid >> 3;
+  const T* xrow[4]; int hi0[4], wi0[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m_base + r0 + 32 * j;
+    if (m < sg.M) {
+      const int b = m / HoWo, rem = m - b * HoWo;
+      const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+      hi0[j] = ho * p.stride - p.pad_t; wi0[j] = wo * p.stride - p.pad_l;
+      xrow[j] = (const T*)p.x + sg.in_off + (long long)b * sg.in_bs;
+    } else { hi0[j] = -100000; wi0[j] = 0; xrow[j] = (const T*)p.x; }
+  }
+  const T* wrow[WROWS]; bool wok[WROWS];
+#pragma unroll
+  for (int j = 0; j < WROWS; ++j) {
+    const int r = r0 + 32 * j, n = n_base + r;
+    wok[j] = (r < BN) && (n < p.Cout);
+    wrow[j] = (const T*)p.w + (long long)(wok[j] ? n : 0) * p.Kc * CE;
+  }
+  // K cursor of this thread's chunk column: chunk index kq = tap*cpt + cc
+  int kq = kc, tap = 0, cc = kc;
+  while (cc >= p.cpt) { cc -= p.cpt; ++tap; }
+  int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+  uint4 xr[4], wr[WROWS];
+  auto gload = [&]() {
+    const bool kok = kq < p.Kc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+      const bool ok = kok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
+      xr[j] = make_uint4(0, 0, 0, 0);
+      if (ok) xr[j] = *(const uint4*)(xrow[j] + ((long long)(hi * sg.W + wi) * p.ldx + cc * CE));
+    }
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+      wr[j] = make_uint4(0, 0, 0, 0);
+      if (kok && wok[j]) wr[j] = *(const uint4*)(wrow[j] + (long long)kq * CE);
+    }
+    // advance the cursor by one K-step (8 chunks)
+    kq += 8; cc += 8;
+    while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = r0 + 32 * j;
+      xs[buf * XLD + r * 8 + (kc ^ ((r >> 1) & 7))] = xr[j];
+    }
+#pragma unroll
+    for (int j = 0; j < WROWS; ++j) {
+      const int r = r0 + 32 * j;
+      if (r < BN) ws[buf * WLD + r * 8 + (kc ^ ((r >> 1) & 7))] = wr[j];
+    }
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.Kc + 7) >> 3;
+  gload(); sstore(0);
+  __syncthreads();
+  const int l15 = lane & 15, lq = lane >> 4, lsw = l15 >> 1;  // swizzle term (row>>1)&7 for row%16 = l15
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) gload();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      uint4 wf[NT], xf[MT];
+      const int ch = ((s * 4 + lq) ^ lsw);
+#pragma unroll
+      for (int a = 0; a < NT; ++a) wf[a] = ws[cur * WLD + (wn0 + a * 16 + l15) * 8 + ch];
+#pragma unroll
+      for (int b = 0; b < MT; ++b) xf[b] = xs[cur * XLD + (wm0 + b * 16 + l15) * 8 + ch];
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
+    }
+    if (kt + 1 < nk) sstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds channels n0..n0+3 (rows of D) of pixel m (column of D) ----
+#pragma unroll
+  for (int b = 0; b < MT; ++b) {
+    const int m = m_base + wm0 + b * 16 + l15;
+    if (m >= sg.M) continue;
+    const int bi = m / HoWo, pix = m - bi * HoWo;
+    const long long orow = sg.out_off + (long long)bi * sg.out_bs + (long long)pix * p.ldy;
+    const float rs = p.rowscale ? p.rowscale[bi] : 1.0f;
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+      const int n0 = n_base + wn0 + a * 16 + lq * 4;
+      if (n0 >= p.Cout) continue;
+      f32x4 v = acc[a][b];
+      const bool full = p.vec_ok && (n0 + 3 < p.Cout);
+      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n0 + r < p.Cout) {
+          if (p.scale) sc[r] = p.scale[n0 + r];
+          if (p.shift) sh[r] = p.shift[n0 + r];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
+      const long long o = orow + n0;
+      if (p.z) {
+        if (full) store4((T*)p.z + o, v);
+        else
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.z + o + r, v[r]);
+      }
+      if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+      else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+      else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+      for (int r = 0; r < 4; ++r) v[r] *= rs;
+      if (p.res_mode != EFFDET_RES_NONE) {
+        f32x4 q;
+        if (full) q = load4((const T*)p.res + o);
+        else
+          for (int r = 0; r < 4; ++r) q[r] = (n0 + r < p.Cout) ? Elem<T>::ld((const T*)p.res + o + r) : 0.f;
+        if (p.res_mode == EFFDET_RES_ADD) { for (int r = 0; r < 4; ++r) v[r] += q[r]; }
+        else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
+        else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
+      }
+      if (p.out_f32) {
+        if (full) store4((float*)p.y + o, v);
+        else
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) ((float*)p.y)[o + r] = v[r];
+      } else {
+        if (full) store4((T*)p.y + o, v);
+        else
+          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.y + o + r, v[r]);
+      }
+    }
+  }
+}
+
+template <typename T, int BN, int WAVES_N>
+int launch(const ConvK& k, hipStream_t st) {
+  const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);
+  const int grid = k.mtiles * k.ntiles;
+  static bool attr_set = false;  // idempotent; benign race
+  if (!attr_set && lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N>), dim3(grid), dim3(256), lds, st, k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+template <typename T>
+int dispatch(ConvK& k, hipStream_t st) {
+  int bn;
+  if (k.Cout > 64) bn = 128; else if (k.Cout > 32) bn = 64; else if (k.Cout > 16) bn = 32; else bn = 16;
+  k.ntiles = (k.Cout + bn - 1) / bn;
+  switch (bn) {
+    case 128: return launch<T, 128, 2>(k, st);
+    case 64: return launch<T, 64, 1>(k, st);
+    case 32: return launch<T, 32, 1>(k, st);
+    default: return launch<T, 16, 1>(k, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
+  if (!p || !p->x || !p->w || !p->y) return EFFDET_EINVAL;
+  if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
+  if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  const int ce = p->dtype == EFFDET_F32 ? 4 : 8;
+  if (p->Cin % ce || p->ldx % ce || p->KH < 1 || p->KW < 1 || p->stride < 1) return EFFDET_EUNSUPPORTED;
+  if (p->res_mode != EFFDET_RES_NONE && !p->res) return EFFDET_EINVAL;
+  if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
+  ConvK k;
+  k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res;
+  k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
+  k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
+  k.ldx = p->ldx; k.ldy = p->ldy;
+  k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt;
+  k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32;
+  k.nseg = p->nseg;
+  int tiles = 0;
+  bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
+  for (int s = 0; s < p->nseg; ++s) {
+    const effdet_seg_t& g = p->seg[s];
+    SegD& d = k.seg[s];
+    d.H = g.H; d.W = g.W; d.Ho = g.Ho; d.Wo = g.Wo;
+    d.M = p->B * g.Ho * g.Wo;
+    d.tile_start = tiles;
+    d.in_off = g.in_off; d.in_bs = g.in_bstride; d.out_off = g.out_off; d.out_bs = g.out_bstride;
+    if (d.M <= 0) return EFFDET_EINVAL;
+    if (g.in_off % ce || g.in_bstride % ce) return EFFDET_EUNSUPPORTED;
+    if (g.out_off % 4 || g.out_bstride % 4) vec = false;
+    tiles += (d.M + BM - 1) / BM;
+  }
+  for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
+  k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
+  hipStream_t st = (hipStream_t)stream;
+  return p->dtype == EFFDET_F32 ? dispatch<float>(k, st) : dispatch<bf16_t>(k, st);
+}

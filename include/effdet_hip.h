@@ -1,0 +1,230 @@
+/* effdet_hip.h -- C ABI of libeffdet_hip.so: the MI355X (gfx950) EfficientDet hot path.
+ *
+ * The reference (toandaominh1997/EfficientDet.Pytorch) is pure Python: it has no FFI; its
+ * "operator API" is the nn.Module surface of models/efficientdet.py::EfficientDet, and every
+ * kernel it runs is a stock torch / torchvision op.  Each entry point below replaces the stock
+ * op(s) named in its comment (reference file:line), so that a maintainer can bind them with
+ * ctypes from a module that keeps the reference's constructor, forward and
+ * state_dict layout.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated;
+ *   - returns 0 on success, a negative EFFDET_E* code otherwise; never throws, never allocates,
+ *     never synchronises; work is enqueued on `stream` (a hipStream_t passed as void*);
+ *   - thread-safe and re-entrant (no global mutable state);
+ *   - activations are NHWC ("channels last"), dtype EFFDET_F32 or EFFDET_BF16 (fp32 accumulate);
+ *   - tensors that feed losses / NMS (probabilities, box deltas, anchors, boxes) are always fp32.
+ */
+#ifndef EFFDET_HIP_H
+#define EFFDET_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* effdet_stream_t; /* hipStream_t */
+
+enum { EFFDET_OK = 0, EFFDET_EINVAL = -1, EFFDET_ELAUNCH = -2, EFFDET_EUNSUPPORTED = -3 };
+enum { EFFDET_F32 = 0, EFFDET_BF16 = 1 };
+enum { EFFDET_ACT_NONE = 0, EFFDET_ACT_RELU = 1, EFFDET_ACT_SWISH = 2, EFFDET_ACT_SIGMOID = 3 };
+/* what the `res` tensor of a conv does in the epilogue */
+enum { EFFDET_RES_NONE = 0, EFFDET_RES_ADD = 1, EFFDET_RES_RELU_MASK = 2, EFFDET_RES_SWISH_GRAD = 3 };
+
+#define EFFDET_MAX_SEG 5
+
+/* One pyramid level ("segment") of a grouped launch.  A single-tensor conv has nseg = 1.
+ * Element (b, h, w, c) of the input lives at  x + in_off  + b*in_bstride  + (h*W  + w )*ldx + c,
+ * element (b,ho,wo, n) of the output lives at y + out_off + b*out_bstride + (ho*Wo + wo)*ldy + n
+ * (same addressing for z and res).  Offsets/strides are in ELEMENTS. */
+typedef struct {
+  int H, W, Ho, Wo;
+  long long in_off, in_bstride, out_off, out_bstride;
+} effdet_seg_t;
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense convolution as an MFMA implicit GEMM (1x1 and 3x3, stride 1 or 2, asymmetric zero pad).
+ * Replaces F.conv2d(groups=1) [+ ZeroPad2d] [+ frozen BatchNorm2d] [+ bias] [+ ReLU / Swish /
+ * sigmoid] [+ residual add] of:
+ *   models/utils.py:151-155 (Conv2dStaticSamePadding.forward), models/efficientnet.py:88-89,98,104
+ *   (expand / project conv + BN + swish + skip), models/module.py:495-501 (ConvModule.forward:
+ *   BiFPN lateral + 3x3 convs, RetinaHead towers), models/retinahead.py:116-123 (retina_cls +
+ *   sigmoid, retina_reg).  Also used for the data gradient of stride-1 convs (flipped weights).
+ *   y = act( (conv(x,w)) * scale[n] + shift[n] ) [* rowscale[b]] [res op]
+ *   z (optional) receives the pre-activation value  conv*scale+shift  (saved for backward).
+ * w is packed [Cout][KH*KW][Cin] in `dtype` (effdet_pack_conv_weight).
+ * Requirements: Cin % (16/sizeof(dtype)) == 0, ldx % (16/sizeof(dtype)) == 0, x 16-byte aligned.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x; const void* w; void* y; void* z; const void* res;
+  const float* scale; const float* shift; /* per output channel, may be NULL (=> 1 / 0) */
+  const float* rowscale;                  /* per image [B], may be NULL (drop_connect keep mask / keep_prob) */
+  int dtype, out_f32;                     /* out_f32: y is written as fp32 regardless of dtype */
+  int B, Cin, Cout, KH, KW, stride, pad_t, pad_l;
+  int ldx, ldy;                           /* channel strides (elements) of x rows and y/z/res rows */
+  int act, res_mode;
+  int nseg;
+  effdet_seg_t seg[EFFDET_MAX_SEG];
+} effdet_conv_t;
+int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
+
+/* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]
+ * (fp32, packed [Cout][KH*KW][Cin], accumulated with atomics so levels / K-splits can add up),
+ * and optionally dbias[n] += sum_m dz[m][n].  Replaces autograd of F.conv2d w.r.t. weight/bias.
+ * Segment geometry: in_* addresses x, out_* addresses dz (Ho,Wo rows). */
+typedef struct {
+  const void* x; const void* dz; float* dw; float* dbias;
+  int dtype;
+  int B, Cin, Cout, KH, KW, stride, pad_t, pad_l;
+  int ldx, lddz;
+  int nseg;
+  effdet_seg_t seg[EFFDET_MAX_SEG];
+} effdet_wgrad_t;
+int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stream);
+
+/* OIHW fp32 master weight -> packed [Cout][KH*KW][Cin] (mode 0, forward) or the data-gradient
+ * operand [Cin][KH*KW flipped][Cout] (mode 1), optionally multiplied by scale[cout] (frozen-BN
+ * fold).  dtype selects the packed element type. */
+int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, int dtype, int mode,
+                            int Cout, int Cin, int KH, int KW, effdet_stream_t stream);
+/* packed fp32 gradient [Cout][KH*KW][Cin] -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
+ * If wsum != NULL also wsum[cout] = sum_{tap,c} w_oihw * g  (needed for the frozen-BN gamma grad). */
+int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
+                             float* wsum, int accumulate, int Cout, int Cin, int KH, int KW,
+                             effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stem: 3x3 stride-2 conv on the NCHW fp32 image (Cin = 3) + frozen BN + Swish -> NHWC.
+ * Replaces models/efficientnet.py:193 (_conv_stem/_bn0/_swish).  z (optional) = pre-activation.
+ * w: OIHW fp32 [Cout][3][3][3].  And its weight gradient (no data gradient: input is the image).
+ * ------------------------------------------------------------------------------------------- */
+int effdet_stem_fwd(const float* img_nchw, const float* w_oihw, const float* scale, const float* shift,
+                    void* y, void* z, int dtype, int B, int H, int W, int Cout, int pad_t, int pad_l,
+                    int Ho, int Wo, effdet_stream_t stream);
+int effdet_stem_wgrad(const float* img_nchw, const void* dz, float* dw_oihw, float* dsum, int dtype,
+                      int B, int H, int W, int Cout, int pad_t, int pad_l, int Ho, int Wo,
+                      effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise kxk conv (k = 3 or 5, stride 1 or 2, asymmetric zero pad) + frozen BN + Swish, with
+ * the per-(image, channel) sum of the output (the squeeze of squeeze-excite) as a side output.
+ * Replaces models/efficientnet.py:91 (_depthwise_conv/_bn1/_swish) and the adaptive_avg_pool2d
+ * of :95.  w: [k*k][C] fp32.  pool: [B][C] fp32, must be zeroed by the caller (+= atomics).
+ * ------------------------------------------------------------------------------------------- */
+int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, const float* shift,
+                      void* y, void* z, float* pool, int dtype, int B, int H, int W, int C, int k,
+                      int stride, int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
+/* data gradient: dx[b,h,w,c] = sum_taps dz[b,ho,wo,c] * w[tap][c] * scale[c];  optionally
+ * multiplied by swish'(zprev) (the expand conv's saved pre-activation) in the epilogue. */
+int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,
+                        void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
+/* weight gradient g[tap][c] += sum dz*x (unscaled), dsum[c] += sum dz. fp32 atomics. */
+int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, int dtype, int B,
+                        int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                        effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Squeeze-excite gate:  gate[b][c] = sigmoid(W2 * swish(W1 * (pool[b]/HW) + b1) + b2)
+ * Replaces models/efficientnet.py:95-97.  w1: [Cse][C], w2: [C][Cse] (the 1x1 conv weights as
+ * stored), fp32.  One workgroup per image, wave-level reductions.  mid (optional) saves the
+ * pre-swish squeeze activations [B][Cse] for backward.
+ * ------------------------------------------------------------------------------------------- */
+int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2,
+                       const float* b2, float* gate, float* mid, int B, int C, int Cse, float inv_hw,
+                       effdet_stream_t stream);
+/* y = x * gate[b][c]  (models/efficientnet.py:98) */
+int effdet_channel_scale(const void* x, const float* gate, void* y, int dtype, int B, long long HW,
+                         int C, effdet_stream_t stream);
+/* backward of (gate, scale):  given dy (grad of x*gate) and x:
+ *   dgate_raw[b][c] = sum_hw dy*x   (fp32 atomics into dgate, caller zeroes)   */
+int effdet_se_dgate(const void* dy, const void* x, float* dgate, int dtype, int B, long long HW, int C,
+                    effdet_stream_t stream);
+/* tiny FC backward: from dgate[b][c] (grad wrt gate), gate, mid, pool -> dpool[b][c] (grad wrt the
+ * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (+=, fp32). */
+int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool,
+                       const float* w1, const float* b1, const float* w2, float* dpool, float* dw1, float* db1,
+                       float* dw2, float* db2, int B, int C, int Cse, float inv_hw, effdet_stream_t stream);
+/* dx = (dy*gate[b][c] + dpool[b][c]) * swish'(z)   -- gradient wrt the depthwise pre-activation z */
+int effdet_se_bwd_apply(const void* dy, const float* gate, const float* dpool, const void* z, void* dzout,
+                        int dtype, int B, long long HW, int C, effdet_stream_t stream);
+
+/* elementwise: dz = dy * act'(aux)  (act = RELU: aux = y;  SWISH: aux = z) [* rowscale[b]] */
+int effdet_act_bwd(const void* dy, const void* aux, const float* rowscale, void* dz, int dtype, int act,
+                   int B, long long HWC, effdet_stream_t stream);
+/* y (+)= x   (gradient accumulation across branches) */
+int effdet_add_inplace(void* y, const void* x, int dtype, long long n, effdet_stream_t stream);
+/* per-channel column sum: out[c] += sum_rows x[row][c] */
+int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, int ldx,
+                  effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * BiFPN fast-normalised fusion nodes (models/bifpn.py:177-202).  Weights arrive raw (w1 [2][L],
+ * w2 [3][L-2]); the double normalisation relu -> /(sum+eps) -> /(wa+wb+eps) is done on device.
+ *   mode 0 (top-down):   out = (a*wa + up2(b)*wb)/(wa+wb+eps)          b is at half resolution
+ *   mode 1 (bottom-up3): out = (a*wa + maxpool2(b)*wb + c*wc)/(sum+eps) b is at double resolution
+ *   mode 2 (bottom-up2): out = (a*wa + maxpool2(b)*wb)/(sum+eps)
+ * wraw: pointer to the full raw weight matrix (fp32), wrows rows x wcols columns; col selects the node.
+ * ------------------------------------------------------------------------------------------- */
+int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out, const float* wraw,
+                          int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
+                          effdet_stream_t stream);
+/* backward: given dout -> da, db (+= into db when db_accum), dc, and dwraw[wrows][wcols] (+=, fp32) */
+int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, void* da, void* db,
+                          void* dc, int da_accum, int db_accum, int dc_accum, const float* wraw, float* dwraw,
+                          int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
+                          effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Anchors (models/module.py:145-214,252-273): float64 arithmetic on device, cast to fp32;
+ * bit-exact with the reference's NumPy float64 -> float32 path.  out: [A][4].
+ * ------------------------------------------------------------------------------------------- */
+int effdet_anchors(float* out, int H, int W, effdet_stream_t stream);
+long long effdet_num_anchors(int H, int W);
+
+/* Box decode + clip (models/module.py:24-49, 57-67) fused with the per-anchor class max and the
+ * threshold test of models/efficientdet.py:72-73.  boxes [B][A][4], score [B][A], label [B][A]. */
+int effdet_decode_score(const float* anchors, const float* reg, const float* cls, float* boxes,
+                        float* score, int* label, int B, long long A, int num_classes, float img_w,
+                        float img_h, effdet_stream_t stream);
+
+/* Per-image threshold + stable sort by descending score + greedy class-agnostic NMS
+ * (models/efficientdet.py:73-86 and torchvision.ops.nms semantics: suppress IoU > thr).
+ * Everything stays on the device; no host round trip.
+ * Outputs (per image, capacity A each): out_idx [B][A] (indices into the anchor list, in kept
+ * order), out_count [B].  workspace: effdet_nms_workspace_bytes(B, A) bytes. */
+long long effdet_nms_workspace_bytes(int B, long long A);
+int effdet_nms(const float* boxes, const float* score, float threshold, float iou_threshold, int* out_idx,
+               int* out_count, void* workspace, long long workspace_bytes, int B, long long A,
+               effdet_stream_t stream);
+/* gather kept rows: scores [B][A], labels [B][A] (int64), boxes [B][A][4] for the first count[b] rows */
+int effdet_gather_dets(const float* boxes, const float* score, const int* label, const int* idx,
+                       const int* count, float* out_scores, long long* out_labels, float* out_boxes, int B,
+                       long long A, effdet_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Focal + smooth-L1 loss, forward and backward in one pass (models/losses.py:32-152): per-image
+ * IoU assignment, focal BCE (alpha .25, gamma 2), smooth-L1 (beta 1/9); no per-image host loop,
+ * no syncs.  cls = probabilities [B][A][nc] fp32, reg [B][A][4] fp32, anchors [A][4],
+ * annots [B][N][5] (pad rows label = -1).  Outputs: losses[2] (batch-mean cls, reg), and the
+ * gradients wrt the LOGITS of cls (dcls_logit, written in `dtype`) and wrt reg (dreg, `dtype`),
+ * already scaled by gscale[0] (cls) / gscale[1] (reg) = the upstream grads of the two losses.
+ * workspace: effdet_loss_workspace_bytes(B, A).
+ * ------------------------------------------------------------------------------------------- */
+long long effdet_loss_workspace_bytes(int B, long long A);
+int effdet_focal_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* annots,
+                          float* losses, void* workspace, long long workspace_bytes, int B, long long A,
+                          int num_classes, int N, effdet_stream_t stream);
+int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots,
+                          const float* gscale, const void* workspace, void* dcls_logit, void* dreg, int dtype,
+                          int B, long long A, int num_classes, int N, effdet_stream_t stream);
+
+/* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
+int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
+int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
+
+/* library identification: returns "effdet-hip gfx950 <version>" */
+const char* effdet_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EFFDET_HIP_H */

@@ -1,0 +1,16 @@
+"""Helpers shared by the -m gpu parity tests."""
+import torch
+
+
+def assert_close(got, ref, tol, what=''):
+    """|a-b| <= tol * max(|b|, tiny) with tiny = 1e-2 * |b|_max (SURVEY §8d parity gate)."""
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    floor = 1e-2 * float(ref.abs().max()) + 1e-30
+    bound = tol * torch.maximum(ref.abs(), torch.tensor(floor))
+    bad = (got - ref).abs() > bound
+    if bool(bad.any()) or not bool(torch.isfinite(got).all()):
+        i = int(torch.nonzero(bad.reshape(-1))[0]) if bool(bad.any()) else 0
+        raise AssertionError('%s: %d/%d elements exceed tol %g (first at %d: got %g ref %g; max abs err %g, ref max %g)' % (
+            what, int(bad.sum()), bad.numel(), tol, i, float(got.reshape(-1)[i]), float(ref.reshape(-1)[i]),
+            float((got - ref).abs().max()), float(ref.abs().max())))

@@ -1,0 +1,184 @@
+"""GPU parity: MFMA implicit-GEMM conv (C ABI effdet_conv2d) vs torch-CPU fp32 F.conv2d."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
+
+
+def _run(dtype, B, H, W, Cin, Cout, k, stride=1, pad=(1, 1, 1, 1), act=0, bn=False, res=False, save_z=False,
+         rowscale=False, out_f32=False, seed=0):
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = (0.5 + torch.rand(Cout, generator=g)) if bn else None
+    shift = torch.randn(Cout, generator=g) * 0.3
+    pl, pr, pt, pb = pad
+    if dtype == torch.bfloat16:     # compare against the same rounded operands
+        xq = x.bfloat16().float(); wq = w.bfloat16().float()
+    else:
+        xq, wq = x, w
+    ref = F.conv2d(F.pad(xq, [pl, pr, pt, pb]), wq, None, stride)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    if bn:
+        ref = ref * scale.view(1, -1, 1, 1)
+    ref = ref + shift.view(1, -1, 1, 1)
+    zref = ref.clone()
+    if act == 1: ref = F.relu(ref)
+    elif act == 2: ref = ref * torch.sigmoid(ref)
+    elif act == 3: ref = torch.sigmoid(ref)
+    rs = None
+    if rowscale:
+        rs = torch.rand(B, generator=g) + 0.5
+        ref = ref * rs.view(-1, 1, 1, 1)
+    r = None
+    if res:
+        r = torch.randn(B, Cout, Ho, Wo, generator=g)
+        rq = r.bfloat16().float() if dtype == torch.bfloat16 else r
+        ref = ref + rq
+    dev = 'cuda'
+    xm = Map.of(x.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+    wp = ops.pack_weight(w.to(dev), dtype)
+    ym = Map.new(B, Ho, Wo, Cout, torch.float32 if out_f32 else dtype, dev)
+    zm = Map.new(B, Ho, Wo, Cout, dtype, dev) if save_z else None
+    rm = Map.of(r.permute(0, 2, 3, 1).contiguous().to(dev, dtype)) if res else None
+    ops.conv2d(xm, wp, ym, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=stride, pad_t=pt, pad_l=pl,
+               scale=scale.to(dev) if bn else None, shift=shift.to(dev), act=act,
+               res=rm, res_mode=ops.RES_ADD if res else ops.RES_NONE,
+               rowscale=rs.to(dev) if rowscale else None, zs=zm, out_f32=out_f32)
+    torch.cuda.synchronize()
+    got = ym.tensor().float().cpu().permute(0, 3, 1, 2)
+    assert_close(got, ref, TOL[dtype], 'conv y %s' % ((dtype, B, H, W, Cin, Cout, k, stride),))
+    if save_z:
+        assert_close(zm.tensor().float().cpu().permute(0, 3, 1, 2), zref, TOL[dtype], 'conv z')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv3x3_head_shapes(dtype):
+    _run(dtype, 2, 16, 16, 64, 256, 3, act=1)                       # tower layer 0 (K=576)
+    _run(dtype, 1, 8, 8, 256, 256, 3, act=1)                        # tower (K=2304)
+    _run(dtype, 1, 8, 8, 256, 720, 3, act=3, out_f32=True)          # retina_cls + sigmoid, fp32 out
+    _run(dtype, 1, 8, 8, 256, 36, 3, out_f32=True)                  # retina_reg
+    _run(dtype, 2, 4, 4, 64, 64, 3)                                 # BiFPN conv on a tiny level
+    _run(dtype, 1, 1, 1, 64, 64, 3)                                 # 1x1 map (D0@128: top level)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv1x1_backbone_shapes(dtype):
+    for (cin, cout) in [(16, 96), (96, 24), (144, 24), (24, 144), (240, 40), (40, 240), (480, 80), (672, 112),
+                        (1152, 192), (1152, 320), (320, 64), (112, 64), (32, 16)]:
+        _run(dtype, 2, 8, 8, cin, cout, 1, pad=(0, 0, 0, 0), act=2, bn=True, save_z=True)
+    _run(dtype, 2, 8, 8, 96, 24, 1, pad=(0, 0, 0, 0), bn=True, res=True, rowscale=True)   # project + skip + drop_connect
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_odd_geometry(dtype):
+    _run(dtype, 3, 13, 9, 40, 54, 3, act=0)                                   # ragged tiles, Cout % 4 != 0
+    _run(dtype, 1, 17, 17, 24, 32, 3, stride=2, pad=(0, 1, 0, 1), act=2, bn=True)   # TF-same stride 2
+    _run(dtype, 2, 12, 12, 16, 16, 5, pad=(2, 2, 2, 2))                       # 5x5, several taps per K-step
+    _run(dtype, 1, 40, 40, 64, 64, 3, act=1)                                  # multiple m-tiles
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_conv_grouped_pyramid(dtype):
+    """One launch over 5 levels with shared weights, outputs written into the [B, A, C] head layout."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(3)
+    B, Cin, nc = 2, 64, 20
+    Cout = 9 * nc
+    sizes = [16, 8, 4, 2, 1]
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    bias = torch.randn(Cout, generator=g) * 0.1
+    xs = [torch.randn(B, Cin, s, s, generator=g) for s in sizes]
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    refs = [torch.sigmoid(F.conv2d(q(x), q(w), bias, 1, 1)).permute(0, 2, 3, 1).reshape(B, -1, nc) for x in xs]
+    ref = torch.cat(refs, 1)
+    A = ref.shape[1]
+    dev = 'cuda'
+    tot = sum(B * s * s * Cin for s in sizes)
+    flat = torch.empty(tot, dtype=dtype, device=dev)
+    xm, off = [], 0
+    for x, s in zip(xs, sizes):
+        n = B * s * s * Cin
+        flat[off:off + n] = x.permute(0, 2, 3, 1).reshape(-1).to(dev, dtype)
+        xm.append(Map(flat, B, s, s, Cin, off=off)); off += n
+    out = torch.zeros(B, A, nc, dtype=torch.float32, device=dev)
+    ym, aoff = [], 0
+    for s in sizes:
+        ym.append(Map(out, B, s, s, Cout, ld=Cout, bstride=A * nc, off=aoff * nc)); aoff += s * s * 9
+    ops.conv2d(xm, ops.pack_weight(w.to(dev), dtype), ym, Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1,
+               shift=bias.to(dev), act=ops.ACT_SIGMOID, out_f32=True)
+    torch.cuda.synchronize()
+    assert_close(out.cpu(), ref, TOL[dtype], 'grouped head output')
+
+
+def _run_wgrad(dtype, B, H, W, Cin, Cout, k, stride=1, pad=(1, 1, 1, 1), seed=0, bias=True):
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    pl, pr, pt, pb = pad
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    w = torch.zeros(Cout, Cin, k, k, requires_grad=True)
+    xp = F.pad(q(x), [pl, pr, pt, pb])
+    y = F.conv2d(xp, w, None, stride)
+    dz = torch.randn(y.shape, generator=g)
+    y.backward(q(dz))
+    ref = w.grad                                     # [Cout][Cin][k][k]
+    dev = 'cuda'
+    xm = Map.of(x.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+    dzm = Map.of(dz.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+    gp = torch.zeros(Cout, k * k, Cin, dtype=torch.float32, device=dev)
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev) if bias else None
+    ops.conv2d_wgrad(xm, dzm, gp, db, Cin=Cin, Cout=Cout, KH=k, KW=k, stride=stride, pad_t=pt, pad_l=pl)
+    dw = torch.empty(Cout, Cin, k, k, dtype=torch.float32, device=dev)
+    ops.unpack_wgrad(gp, dw)
+    torch.cuda.synchronize()
+    tol = 3e-4 if dtype == torch.float32 else 1e-2
+    assert_close(dw.cpu(), ref, tol, 'wgrad %s' % ((dtype, B, H, W, Cin, Cout, k, stride),))
+    if bias:
+        assert_close(db.cpu(), q(dz).sum(dim=(0, 2, 3)), tol, 'dbias')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_shapes(dtype):
+    _run_wgrad(dtype, 2, 16, 16, 64, 256, 3)
+    _run_wgrad(dtype, 1, 8, 8, 256, 256, 3)
+    _run_wgrad(dtype, 2, 8, 8, 256, 180, 3)
+    _run_wgrad(dtype, 2, 4, 4, 256, 36, 3)
+    _run_wgrad(dtype, 3, 13, 9, 40, 54, 3)
+    _run_wgrad(dtype, 2, 12, 12, 96, 24, 1, pad=(0, 0, 0, 0))
+    _run_wgrad(dtype, 2, 12, 12, 16, 96, 1, pad=(0, 0, 0, 0))
+    _run_wgrad(dtype, 1, 17, 17, 24, 32, 3, stride=2, pad=(0, 1, 0, 1))
+    _run_wgrad(dtype, 4, 40, 40, 64, 64, 3)          # several K-splits
+    _run_wgrad(dtype, 2, 1, 1, 64, 64, 3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_dgrad_via_flipped_weights(dtype):
+    """Data gradient of a stride-1 conv = forward kernel on the mode-1 packed (flipped, transposed) weights."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 2, 10, 12, 64, 96
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0
+    scale = 0.5 + torch.rand(Cout, generator=g)
+    y = F.conv2d(x, q(w * scale.view(-1, 1, 1, 1)), None, 1, 1)
+    dz = torch.randn(y.shape, generator=g)
+    y.backward(q(dz))
+    dev = 'cuda'
+    wd = ops.pack_weight(w.to(dev), dtype, mode=1, scale=scale.to(dev))
+    dzm = Map.of(dz.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+    dxm = Map.new(B, H, W, Cin, dtype, dev)
+    ops.conv2d(dzm, wd, dxm, Cin=Cout, Cout=Cin, KH=3, KW=3, pad_t=1, pad_l=1)
+    torch.cuda.synchronize()
+    assert_close(dxm.tensor().float().cpu().permute(0, 3, 1, 2), x.grad, 2e-4 if dtype == torch.float32 else 2e-2, 'dgrad')
