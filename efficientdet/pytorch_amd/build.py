@@ -15,6 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libeffdet_hip.so')
+PER_FILE = {'postprocess.hip': ['-ffp-contract=off']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall',
          '-Wno-unused-function']
 
@@ -48,7 +49,7 @@ def build(force=False, verbose=True):
 
     def one(src):
         obj = os.path.join(CSRC, 'build', os.path.basename(src)[:-4] + '.o')
-        cmd = [hipcc] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [hipcc] + FLAGS + PER_FILE.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed for %s:\n%s' % (src, r.stderr))

@@ -7,18 +7,18 @@ namespace {
 // mode 1: out[ci][tap flipped][co]    = w[co][ci][KH-1-kh][KW-1-kw] * scale[co]   (data-gradient operand)
 template <typename T>
 __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
-                              int mode, int Cout, int Cin, int KH, int KW) {
-  const long long total = (long long)Cout * Cin * KH * KW;
+                              int mode, int Cout, int Cin, int KH, int KW, int Cin_pad) {
   const int taps = KH * KW;
+  const long long total = mode == 0 ? (long long)Cout * Cin_pad * taps : (long long)Cout * Cin * taps;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     // i indexes the OUTPUT (coalesced writes)
     int c, tap, n;
-    if (mode == 0) { c = (int)(i % Cin); tap = (int)((i / Cin) % taps); n = (int)(i / ((long long)Cin * taps)); }
+    if (mode == 0) { c = (int)(i % Cin_pad); tap = (int)((i / Cin_pad) % taps); n = (int)(i / ((long long)Cin_pad * taps)); }
     else { c = (int)(i % Cout); tap = (int)((i / Cout) % taps); n = (int)(i / ((long long)Cout * taps)); }
     const int kh = tap / KW, kw = tap % KW;
     float v;
     if (mode == 0) {
-      v = w[(((long long)n * Cin + c) * KH + kh) * KW + kw];
+      v = c < Cin ? w[(((long long)n * Cin + c) * KH + kh) * KW + kw] : 0.f;   // zero-filled channel padding
       if (scale) v *= scale[n];
     } else {
       v = w[(((long long)c * Cin + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
@@ -31,14 +31,14 @@ __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restri
 // one block per output channel
 __global__ void unpack_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ scale,
                                     const float* __restrict__ w, float* __restrict__ dw, float* __restrict__ wsum,
-                                    int accumulate, int Cin, int KH, int KW) {
+                                    int accumulate, int Cin, int KH, int KW, int Cin_pad) {
   const int co = blockIdx.x, taps = KH * KW, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
   float part = 0.f;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     // i indexes OIHW within this co: i = ci*taps + tap
     const int ci = i / taps, tap = i - ci * taps;
-    const float gv = g[((long long)co * taps + tap) * Cin + ci];
+    const float gv = g[((long long)co * taps + tap) * Cin_pad + ci];
     const long long o = (long long)co * n + i;
     if (wsum) part += w[o] * gv;
     dw[o] = accumulate ? dw[o] + s * gv : s * gv;
@@ -62,11 +62,11 @@ __global__ void nhwc_to_nchw_kernel(const T* __restrict__ x, float* __restrict__
   }
 }
 template <typename T>
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int HW, int C) {
-  const long long total = (long long)B * HW * C;
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int HW, int C, int Cpad) {
+  const long long total = (long long)B * HW * Cpad;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C); const int p = (int)((i / C) % HW); const int b = (int)(i / ((long long)HW * C));
-    Elem<T>::st(y + i, x[((long long)b * C + c) * HW + p]);
+    const int c = (int)(i % Cpad); const int p = (int)((i / Cpad) % HW); const int b = (int)(i / ((long long)HW * Cpad));
+    Elem<T>::st(y + i, c < C ? x[((long long)b * C + c) * HW + p] : 0.f);
   }
 }
 
@@ -78,23 +78,23 @@ inline int grid_for(long long n, int block = 256) {
 }  // namespace
 
 extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void* out, int dtype, int mode,
-                                       int Cout, int Cin, int KH, int KW, effdet_stream_t stream) {
-  if (!w || !out || (mode != 0 && mode != 1)) return EFFDET_EINVAL;
-  const long long n = (long long)Cout * Cin * KH * KW;
+                                       int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream) {
+  if (!w || !out || (mode != 0 && mode != 1) || Cin_pad < Cin || (mode == 1 && Cin_pad != Cin)) return EFFDET_EINVAL;
+  const long long n = (long long)Cout * Cin_pad * KH * KW;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EFFDET_F32)
-    hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW);
+    hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
   else if (dtype == EFFDET_BF16)
-    hipLaunchKernelGGL(pack_w_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (bf16_t*)out, mode, Cout, Cin, KH, KW);
+    hipLaunchKernelGGL(pack_w_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (bf16_t*)out, mode, Cout, Cin, KH, KW, Cin_pad);
   else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
 extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w, float* dw, float* wsum,
-                                        int accumulate, int Cout, int Cin, int KH, int KW, effdet_stream_t stream) {
-  if (!g || !dw || (wsum && !w)) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW);
+                                        int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream) {
+  if (!g || !dw || (wsum && !w) || Cin_pad < Cin) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW, Cin_pad);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -107,11 +107,12 @@ extern "C" int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
-extern "C" int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream) {
-  const long long n = (long long)B * H * W * C;
+extern "C" int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, int Cpad, effdet_stream_t stream) {
+  if (Cpad < C) return EFFDET_EINVAL;
+  const long long n = (long long)B * H * W * Cpad;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, x, (float*)y, B, H * W, C);
-  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, x, (bf16_t*)y, B, H * W, C);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, x, (float*)y, B, H * W, C, Cpad);
+  else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, x, (bf16_t*)y, B, H * W, C, Cpad);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

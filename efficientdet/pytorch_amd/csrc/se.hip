@@ -1,0 +1,350 @@
+// Squeeze-excite micro-kernels and the small elementwise / reduction helpers of the MBConv
+// backward pass.  All HBM-bound or latency-bound; wave-level (64-lane) reductions, 16-byte I/O.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long long n, int block = 256) {
+  long long g = (n + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+// ---- gate = sigmoid(W2 * swish(W1 * mean + b1) + b2); one workgroup per image ----
+__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ gate,
+                                                          float* __restrict__ mid, int C, int Cse, float inv_hw) {
+  extern __shared__ float sm[];          // mean[C] | sw[Cse]
+  float* mean = sm; float* sw = sm + C;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) mean[c] = pool[(long long)b * C + c] * inv_hw;
+  __syncthreads();
+  for (int j = wave; j < Cse; j += 4) {          // one wave per squeezed channel
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w1[(long long)j * C + c], mean[c], s);
+    s = wave_sum(s);
+    if (lane == 0) { const float m = s + b1[j]; if (mid) mid[(long long)b * Cse + j] = m; sw[j] = swishf_(m); }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s = b2[c];
+    for (int j = 0; j < Cse; ++j) s = fmaf(w2[(long long)c * Cse + j], sw[j], s);
+    gate[(long long)b * C + c] = sigmoidf_(s);
+  }
+}
+
+// ---- backward of the gate MLP; one workgroup per image, parameter grads via fp32 atomics ----
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                          const float* __restrict__ mid, const float* __restrict__ pool,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          float* __restrict__ dpool, float* __restrict__ dw1,
+                                                          float* __restrict__ db1, float* __restrict__ dw2,
+                                                          float* __restrict__ db2, int C, int Cse, float inv_hw) {
+  extern __shared__ float sm[];          // du[C] | mean[C] | sw[Cse] | dmid[Cse]
+  float* du = sm; float* mean = sm + C; float* sw = mean + C; float* dmid = sw + Cse;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    const float g = gate[(long long)b * C + c];
+    const float d = dgate[(long long)b * C + c] * g * (1.f - g);      // through the sigmoid
+    du[c] = d; mean[c] = pool[(long long)b * C + c] * inv_hw;
+    atomicAdd(db2 + c, d);
+  }
+  for (int j = tid; j < Cse; j += 256) sw[j] = swishf_(mid[(long long)b * Cse + j]);
+  __syncthreads();
+  // dw2[c][j] += du[c]*sw[j]
+  for (int i = tid; i < C * Cse; i += 256) { const int c = i / Cse, j = i - c * Cse; atomicAdd(dw2 + i, du[c] * sw[j]); }
+  // dsw[j] = sum_c w2[c][j]*du[c];  dmid = dsw * swish'(mid)
+  for (int j = wave; j < Cse; j += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w2[(long long)c * Cse + j], du[c], s);
+    s = wave_sum(s);
+    if (lane == 0) { const float d = s * swish_gradf_(mid[(long long)b * Cse + j]); dmid[j] = d; atomicAdd(db1 + j, d); }
+  }
+  __syncthreads();
+  // dw1[j][c] += dmid[j]*mean[c];  dmean[c] = sum_j w1[j][c]*dmid[j];  dpool (wrt the SUM) = dmean*inv_hw
+  for (int i = tid; i < C * Cse; i += 256) { const int j = i / C, c = i - j * C; atomicAdd(dw1 + i, dmid[j] * mean[c]); }
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int j = 0; j < Cse; ++j) s = fmaf(w1[(long long)j * C + c], dmid[j], s);
+    dpool[(long long)b * C + c] = s * inv_hw;
+  }
+}
+
+// ---- y = x * gate[b][c] ----
+template <typename T>
+__global__ void channel_scale_kernel(const T* __restrict__ x, const float* __restrict__ gate, T* __restrict__ y,
+                                     long long HW, int C, long long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  const int cpr = C / CE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr); const long long row = i / cpr; const long long b = row / HW;
+    float v[CE];
+    Chunk<T>::unpack(((const uint4*)x)[i], v);
+    const float* g = gate + b * C + cc * CE;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) v[e] *= g[e];
+    ((uint4*)y)[i] = Chunk<T>::pack(v);
+  }
+}
+
+// ---- dgate[b][c] += sum_hw dy*x ; block = (image, pixel slab); LDS accumulate, one global atomic per channel ----
+template <typename T>
+__global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                       float* __restrict__ dgate, long long HW, int C, int slabs) {
+  constexpr int CE = Elem<T>::CE;
+  extern __shared__ float accs[];                 // [C]
+  const int cpr = C / CE;
+  const int b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
+  const long long p0 = HW * slab / slabs, p1 = HW * (slab + 1) / slabs;
+  for (int c = threadIdx.x; c < C; c += 256) accs[c] = 0.f;
+  __syncthreads();
+  const int tcols = cpr < 256 ? cpr : 256;
+  const int rpp = 256 / tcols;                       // rows per pass
+  const int cc0 = threadIdx.x % tcols, r0 = threadIdx.x / tcols;
+  if (r0 < rpp) {
+    for (int cc = cc0; cc < cpr; cc += tcols) {
+      float s[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) s[e] = 0.f;
+      for (long long p = p0 + r0; p < p1; p += rpp) {
+        const long long i = ((long long)b * HW + p) * cpr + cc;
+        float a[CE], q[CE];
+        Chunk<T>::unpack(((const uint4*)dy)[i], a);
+        Chunk<T>::unpack(((const uint4*)x)[i], q);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s[e] = fmaf(a[e], q[e], s[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < CE; ++e) atomicAdd(&accs[cc * CE + e], s[e]);
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dgate + (long long)b * C + c, accs[c]);
+}
+
+// ---- dz = (dy*gate + dpool) * swish'(z) ----
+template <typename T>
+__global__ void se_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
+                                    const T* __restrict__ z, T* __restrict__ out, long long HW, int C, long long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  const int cpr = C / CE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
+    const int cc = (int)(i % cpr); const long long row = i / cpr; const long long b = row / HW;
+    float d[CE], zz[CE];
+    Chunk<T>::unpack(((const uint4*)dy)[i], d);
+    Chunk<T>::unpack(((const uint4*)z)[i], zz);
+    const float* g = gate + b * C + cc * CE; const float* dp = dpool + b * C + cc * CE;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) d[e] = (d[e] * g[e] + dp[e]) * swish_gradf_(zz[e]);
+    ((uint4*)out)[i] = Chunk<T>::pack(d);
+  }
+}
+
+// ---- dz = dy * act'(aux) [* rowscale[b]] ----
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ aux, const float* __restrict__ rowscale,
+                               T* __restrict__ dz, int act, long long per_image_chunks, long long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
+    float d[CE], a[CE];
+    Chunk<T>::unpack(((const uint4*)dy)[i], d);
+    if (act != EFFDET_ACT_NONE) {
+      Chunk<T>::unpack(((const uint4*)aux)[i], a);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) d[e] = (act == EFFDET_ACT_RELU) ? (a[e] > 0.f ? d[e] : 0.f) : d[e] * swish_gradf_(a[e]);
+    }
+    if (rowscale) { const float r = rowscale[i / per_image_chunks];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) d[e] *= r; }
+    ((uint4*)dz)[i] = Chunk<T>::pack(d);
+  }
+}
+
+template <typename T>
+__global__ void add_inplace_kernel(T* __restrict__ y, const T* __restrict__ x, long long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
+    float a[CE], b[CE];
+    Chunk<T>::unpack(((const uint4*)y)[i], a); Chunk<T>::unpack(((const uint4*)x)[i], b);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) a[e] += b[e];
+    ((uint4*)y)[i] = Chunk<T>::pack(a);
+  }
+}
+
+// ---- out[c] += sum_rows x[row][c] ----
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long rows, int C,
+                                                     int ldx) {
+  // block handles a slab of rows; thread -> channel (strided), rows strided
+  const int tcols = C < 256 ? C : 256;
+  const int rpp = 256 / tcols;
+  const int c0 = threadIdx.x % tcols, r0 = threadIdx.x / tcols;
+  if (r0 >= rpp) return;
+  const long long p0 = rows * blockIdx.x / gridDim.x, p1 = rows * (blockIdx.x + 1) / gridDim.x;
+  for (int c = c0; c < C; c += tcols) {
+    float s = 0.f;
+    for (long long p = p0 + r0; p < p1; p += rpp) s += Elem<T>::ld(x + p * ldx + c);
+    atomicAdd(out + c, s);
+  }
+}
+
+// ---- frozen BatchNorm folding and parameter gradients (per-channel vectors) ----
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float eps,
+                               float* scale, float* shift, float* invstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float is = 1.0f / sqrtf(var[c] + eps);
+  const float s = g[c] * is;
+  scale[c] = s; shift[c] = b[c] - mean[c] * s;
+  if (invstd) invstd[c] = is;
+}
+// dgamma = invstd*(wsum - mean*dsum), dbeta = dsum   (wsum = sum_k W*G, see DESIGN.md §frozen-BN backward)
+__global__ void bn_param_grad_kernel(const float* wsum, const float* dsum, const float* mean, const float* invstd,
+                                     float* dgamma, float* dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] = invstd[c] * (wsum[c] - mean[c] * dsum[c]);
+  dbeta[c] = dsum[c];
+}
+
+// depthwise weight layout helpers: [C][1][k][k] <-> [k*k][C]
+__global__ void dw_pack_kernel(const float* w, float* out, int C, int kk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= C * kk) return;
+  const int t = i / C, c = i - t * C;
+  out[i] = w[c * kk + t];
+}
+__global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const float* w, float* dw, float* wsum, int C, int kk) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = scale ? scale[c] : 1.f;
+  float acc = 0.f;
+  for (int t = 0; t < kk; ++t) { const float gv = g[t * C + c]; dw[c * kk + t] = s * gv; acc = fmaf(w[c * kk + t], gv, acc); }
+  if (wsum) wsum[c] = acc;
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
+                                  float* gate, float* mid, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
+  if (!pool || !w1 || !b1 || !w2 || !b2 || !gate) return EFFDET_EINVAL;
+  const size_t lds = (size_t)(C + Cse) * sizeof(float);
+  if (lds > 60000) return EFFDET_EUNSUPPORTED;
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool, const float* w1,
+                                  const float* b1, const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
+                                  int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
+  (void)b1;
+  if (!dgate || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2) return EFFDET_EINVAL;
+  const size_t lds = (size_t)(2 * C + 2 * Cse) * sizeof(float);
+  if (lds > 60000) return EFFDET_EUNSUPPORTED;
+  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, ST, dgate, gate, mid, pool, w1, w2, dpool, dw1, db1, dw2, db2, C, Cse, inv_hw);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+#define DISPATCH_T(dtype, KERNEL, grid, ...)                                                    \
+  do {                                                                                          \
+    if ((dtype) == EFFDET_F32) hipLaunchKernelGGL(KERNEL<float>, grid, dim3(256), 0, ST, __VA_ARGS__); \
+    else if ((dtype) == EFFDET_BF16) hipLaunchKernelGGL(KERNEL<bf16_t>, grid, dim3(256), 0, ST, __VA_ARGS__); \
+    else return EFFDET_EINVAL;                                                                  \
+    EFFDET_CHECK_LAUNCH();                                                                      \
+  } while (0)
+
+extern "C" int effdet_channel_scale(const void* x, const float* gate, void* y, int dtype, int B, long long HW, int C,
+                                    effdet_stream_t stream) {
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (!x || !gate || !y || C % ce) return EFFDET_EINVAL;
+  const long long n = (long long)B * HW * (C / ce);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST, (const float*)x, gate, (float*)y, HW, C, n);
+  else hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)x, gate, (bf16_t*)y, HW, C, n);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate, int dtype, int B, long long HW, int C,
+                               effdet_stream_t stream) {
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (!dy || !x || !dgate || C % ce) return EFFDET_EINVAL;
+  int slabs = (int)((HW + 255) / 256); if (slabs > 64) slabs = 64; if (slabs < 1) slabs = 1;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const float*)dy, (const float*)x, dgate, HW, C, slabs);
+  else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate, HW, C, slabs);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_se_bwd_apply(const void* dy, const float* gate, const float* dpool, const void* z, void* out, int dtype,
+                                   int B, long long HW, int C, effdet_stream_t stream) {
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (!dy || !gate || !dpool || !z || !out || C % ce) return EFFDET_EINVAL;
+  const long long n = (long long)B * HW * (C / ce);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_bwd_apply_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST, (const float*)dy, gate, dpool, (const float*)z, (float*)out, HW, C, n);
+  else hipLaunchKernelGGL(se_bwd_apply_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)dy, gate, dpool, (const bf16_t*)z, (bf16_t*)out, HW, C, n);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_act_bwd(const void* dy, const void* aux, const float* rowscale, void* dz, int dtype, int act, int B,
+                              long long HWC, effdet_stream_t stream) {
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (!dy || !dz || HWC % ce || (act != EFFDET_ACT_NONE && !aux)) return EFFDET_EINVAL;
+  const long long per = HWC / ce, n = per * B;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST, (const float*)dy, (const float*)aux, rowscale, (float*)dz, act, per, n);
+  else hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)dy, (const bf16_t*)aux, rowscale, (bf16_t*)dz, act, per, n);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_add_inplace(void* y, const void* x, int dtype, long long n, effdet_stream_t stream) {
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (!y || !x || n % ce) return EFFDET_EINVAL;
+  const long long nc = n / ce;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(grid_for(nc)), dim3(256), 0, ST, (float*)y, (const float*)x, nc);
+  else hipLaunchKernelGGL(add_inplace_kernel<bf16_t>, dim3(grid_for(nc)), dim3(256), 0, ST, (bf16_t*)y, (const bf16_t*)x, nc);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, int ldx, effdet_stream_t stream) {
+  if (!x || !out) return EFFDET_EINVAL;
+  int g = (int)((rows + 63) / 64); if (g > 1024) g = 1024; if (g < 1) g = 1;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, ST, (const float*)x, out, rows, C, ldx);
+  else hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, ST, (const bf16_t*)x, out, rows, C, ldx);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                              float* scale, float* shift, float* invstd, int C, effdet_stream_t stream) {
+  if (!gamma || !beta || !mean || !var || !scale || !shift) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, gamma, beta, mean, var, eps, scale, shift, invstd, C);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+extern "C" int effdet_bn_param_grad(const float* wsum, const float* dsum, const float* mean, const float* invstd,
+                                    float* dgamma, float* dbeta, int C, effdet_stream_t stream) {
+  if (!wsum || !dsum || !mean || !invstd || !dgamma || !dbeta) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, wsum, dsum, mean, invstd, dgamma, dbeta, C);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+extern "C" int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream) {
+  if (!w_c1kk || !out_kkc) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(dw_pack_kernel, dim3((C * k * k + 255) / 256), dim3(256), 0, ST, w_c1kk, out_kkc, C, k * k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+extern "C" int effdet_dw_unpack_wgrad(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk, float* wsum,
+                                      int C, int k, effdet_stream_t stream) {
+  if (!g_kkc || !w_c1kk || !dw_c1kk) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, wsum, C, k * k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}

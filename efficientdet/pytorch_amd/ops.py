@@ -57,15 +57,16 @@ def _segs(desc, xs, ys, base_x, base_y, isz_x, isz_y):
         s.out_off, s.out_bstride = dy // isz_y, y.bstride
 
 
-def pack_weight(w_oihw, dtype, mode=0, scale=None):
-    """OIHW fp32 -> packed [Cout][taps][Cin] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1)."""
+def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
+    """OIHW fp32 -> packed [Cout][taps][Cin_pad] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1)."""
     Cout, Cin, KH, KW = w_oihw.shape
     w = w_oihw.detach()
     assert w.dtype == torch.float32 and w.is_contiguous()
-    shape = (Cout, KH * KW, Cin) if mode == 0 else (Cin, KH * KW, Cout)
+    cin_pad = Cin if cin_pad is None else cin_pad
+    shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, Cout)
     out = torch.empty(shape, dtype=dtype, device=w.device)
     L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), L.dtype_code(dtype), mode,
-                                            Cout, Cin, KH, KW, L.stream_ptr()), 'effdet_pack_conv_weight')
+                                            Cout, Cin, KH, KW, cin_pad, L.stream_ptr()), 'effdet_pack_conv_weight')
     return out
 
 
@@ -123,11 +124,11 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.stream_ptr()), 'effdet_conv2d_wgrad')
 
 
-def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False):
+def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None):
     Cout, Cin, KH, KW = dw_oihw.shape
     L.check(L.lib().effdet_unpack_conv_wgrad(L.ptr(g), L.ptr(scale), L.ptr(w_oihw), L.ptr(dw_oihw), L.ptr(wsum),
-                                             int(accumulate), Cout, Cin, KH, KW, L.stream_ptr()),
-            'effdet_unpack_conv_wgrad')
+                                             int(accumulate), Cout, Cin, KH, KW, Cin if cin_pad is None else cin_pad,
+                                             L.stream_ptr()), 'effdet_unpack_conv_wgrad')
 
 
 def nhwc_to_nchw(m):
@@ -137,10 +138,224 @@ def nhwc_to_nchw(m):
     return out
 
 
-def nchw_to_nhwc(x, dtype):
+def nchw_to_nhwc(x, dtype, cpad=None):
     B, Cc, H, W = x.shape
-    x = x.contiguous().float()
-    m = Map.new(B, H, W, Cc, dtype, x.device)
-    L.check(L.lib().effdet_nchw_f32_to_nhwc(L.ptr(x), L.ptr(m.t), L.dtype_code(dtype), B, H, W, Cc, L.stream_ptr()),
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    cpad = Cc if cpad is None else cpad
+    m = Map.new(B, H, W, cpad, dtype, x.device)
+    L.check(L.lib().effdet_nchw_f32_to_nhwc(L.ptr(x), L.ptr(m.t), L.dtype_code(dtype), B, H, W, Cc, cpad, L.stream_ptr()),
             'effdet_nchw_f32_to_nhwc')
     return m
+
+
+# ----------------------------------------------------------------------------- frozen BN
+def bn_fold(gamma, beta, mean, var, eps=1e-3):
+    C_ = gamma.numel()
+    out = torch.empty((3, C_), dtype=torch.float32, device=gamma.device)     # scale | shift | invstd
+    L.check(L.lib().effdet_bn_fold(L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(var), C.c_float(eps),
+                                   L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), C_, L.stream_ptr()), 'effdet_bn_fold')
+    return out[0], out[1], out[2]
+
+
+def bn_param_grad(wsum, dsum, mean, invstd):
+    C_ = wsum.numel()
+    dg = torch.empty(C_, dtype=torch.float32, device=wsum.device); db = torch.empty_like(dg)
+    L.check(L.lib().effdet_bn_param_grad(L.ptr(wsum), L.ptr(dsum), L.ptr(mean), L.ptr(invstd), L.ptr(dg), L.ptr(db), C_,
+                                         L.stream_ptr()), 'effdet_bn_param_grad')
+    return dg, db
+
+
+# ----------------------------------------------------------------------------- depthwise
+def dw_pack_weight(w_c1kk):
+    Cc, _, k, _ = w_c1kk.shape
+    out = torch.empty((k * k, Cc), dtype=torch.float32, device=w_c1kk.device)
+    L.check(L.lib().effdet_dw_pack_weight(L.ptr(w_c1kk.detach()), L.ptr(out), Cc, k, L.stream_ptr()), 'effdet_dw_pack_weight')
+    return out
+
+
+def dw_unpack_wgrad(g_kkc, scale, w_c1kk, wsum=None):
+    Cc, _, k, _ = w_c1kk.shape
+    dw = torch.empty_like(w_c1kk)
+    L.check(L.lib().effdet_dw_unpack_wgrad(L.ptr(g_kkc), L.ptr(scale), L.ptr(w_c1kk.detach()), L.ptr(dw), L.ptr(wsum), Cc, k,
+                                           L.stream_ptr()), 'effdet_dw_unpack_wgrad')
+    return dw
+
+
+def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None):
+    y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device)
+    z = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_z else None
+    L.check(L.lib().effdet_dwconv_fwd(L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t),
+                                      L.ptr(z.t if z else None), L.ptr(pool), L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k,
+                                      stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd')
+    return y, z
+
+
+def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
+    dx = Map.new(dz.B, H, W, dz.C, dz.dtype, dz.t.device)
+    L.check(L.lib().effdet_dwconv_dgrad(L.ptr(dz.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(zprev.tensor() if zprev else None),
+                                        L.ptr(dx.t), L.dtype_code(dz.dtype), dz.B, H, W, dz.C, k, stride, pad_t, pad_l,
+                                        dz.H, dz.W, L.stream_ptr()), 'effdet_dwconv_dgrad')
+    return dx
+
+
+def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
+    g = torch.zeros((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum
+    L.check(L.lib().effdet_dwconv_wgrad(L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.dtype_code(x.dtype),
+                                        x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W, L.stream_ptr()),
+            'effdet_dwconv_wgrad')
+    return g[:k * k], g[k * k]
+
+
+# ----------------------------------------------------------------------------- squeeze-excite
+def se_gate_fwd(pool, w1, b1, w2, b2, inv_hw, save_mid=False):
+    B, Cc = pool.shape
+    Cse = w1.shape[0]
+    gate = torch.empty((B, Cc), dtype=torch.float32, device=pool.device)
+    mid = torch.empty((B, Cse), dtype=torch.float32, device=pool.device) if save_mid else None
+    L.check(L.lib().effdet_se_gate_fwd(L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()), L.ptr(w2.detach()), L.ptr(b2.detach()),
+                                       L.ptr(gate), L.ptr(mid), B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_fwd')
+    return gate, mid
+
+
+def channel_scale(x, gate):
+    y = Map.new(x.B, x.H, x.W, x.C, x.dtype, x.t.device)
+    L.check(L.lib().effdet_channel_scale(L.ptr(x.tensor()), L.ptr(gate), L.ptr(y.t), L.dtype_code(x.dtype), x.B,
+                                         C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_channel_scale')
+    return y
+
+
+def se_dgate(dy, x):
+    dg = torch.zeros((x.B, x.C), dtype=torch.float32, device=x.t.device)
+    L.check(L.lib().effdet_se_dgate(L.ptr(dy.tensor()), L.ptr(x.tensor()), L.ptr(dg), L.dtype_code(x.dtype), x.B,
+                                    C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_se_dgate')
+    return dg
+
+
+def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, dw1, db1, dw2, db2):
+    B, Cc = pool.shape
+    dpool = torch.empty_like(pool)
+    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
+                                       L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), B, Cc,
+                                       w1.shape[0], C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
+    return dpool
+
+
+def se_bwd_apply(dy, gate, dpool, z):
+    out = Map.new(z.B, z.H, z.W, z.C, z.dtype, z.t.device)
+    L.check(L.lib().effdet_se_bwd_apply(L.ptr(dy.tensor()), L.ptr(gate), L.ptr(dpool), L.ptr(z.tensor()), L.ptr(out.t),
+                                        L.dtype_code(z.dtype), z.B, C.c_longlong(z.H * z.W), z.C, L.stream_ptr()), 'effdet_se_bwd_apply')
+    return out
+
+
+def act_bwd(dy, aux, act, rowscale=None, out=None):
+    out = out or Map.new(dy.B, dy.H, dy.W, dy.C, dy.dtype, dy.t.device)
+    L.check(L.lib().effdet_act_bwd(L.ptr(dy.tensor()), L.ptr(aux.tensor() if aux is not None else None), L.ptr(rowscale),
+                                   L.ptr(out.t), L.dtype_code(dy.dtype), act, dy.B, C.c_longlong(dy.H * dy.W * dy.C),
+                                   L.stream_ptr()), 'effdet_act_bwd')
+    return out
+
+
+def add_inplace(y, x):
+    """y += x for two same-shaped contiguous tensors / Maps."""
+    ty = y.tensor() if isinstance(y, Map) else y
+    tx = x.tensor() if isinstance(x, Map) else x
+    assert ty.numel() == tx.numel() and ty.dtype == tx.dtype
+    L.check(L.lib().effdet_add_inplace(L.ptr(ty), L.ptr(tx), L.dtype_code(ty.dtype), C.c_longlong(ty.numel()), L.stream_ptr()),
+            'effdet_add_inplace')
+
+
+def colsum(t2d, out):
+    rows, Cc = t2d.shape
+    L.check(L.lib().effdet_colsum(L.ptr(t2d), L.ptr(out), L.dtype_code(t2d.dtype), C.c_longlong(rows), Cc, Cc, L.stream_ptr()),
+            'effdet_colsum')
+
+
+# ----------------------------------------------------------------------------- BiFPN fusion
+def bifpn_fuse_fwd(a, b, c, wraw, col, mode):
+    out = Map.new(a.B, a.H, a.W, a.C, a.dtype, a.t.device)
+    wr, wc = wraw.shape
+    L.check(L.lib().effdet_bifpn_fuse_fwd(L.ptr(a.tensor()), L.ptr(b.tensor()), L.ptr(c.tensor() if c is not None else None),
+                                          L.ptr(out.t), L.ptr(wraw.detach()), wr, wc, col, mode, L.dtype_code(a.dtype),
+                                          a.B, a.H, a.W, a.C, L.stream_ptr()), 'effdet_bifpn_fuse_fwd')
+    return out
+
+
+def bifpn_fuse_bwd(dout, a, b, c, da, db, dc, da_acc, db_acc, dc_acc, wraw, dn, col, mode):
+    wr, wc = wraw.shape
+    L.check(L.lib().effdet_bifpn_fuse_bwd(L.ptr(dout.tensor()), L.ptr(a.tensor()), L.ptr(b.tensor()),
+                                          L.ptr(c.tensor() if c is not None else None), L.ptr(da.tensor()), L.ptr(db.tensor()),
+                                          L.ptr(dc.tensor() if dc is not None else None), int(da_acc), int(db_acc), int(dc_acc),
+                                          L.ptr(wraw.detach()), L.ptr(dn), wr, wc, col, mode, L.dtype_code(a.dtype),
+                                          a.B, a.H, a.W, a.C, L.stream_ptr()), 'effdet_bifpn_fuse_bwd')
+
+
+def bifpn_weight_bwd(wraw, dn, dwraw):
+    wr, wc = wraw.shape
+    L.check(L.lib().effdet_bifpn_weight_bwd(L.ptr(wraw.detach()), L.ptr(dn), L.ptr(dwraw), wr, wc, L.stream_ptr()),
+            'effdet_bifpn_weight_bwd')
+
+
+# ----------------------------------------------------------------------------- anchors / decode / NMS
+def num_anchors(H, W):
+    return int(L.lib().effdet_num_anchors(H, W))
+
+
+def anchors(H, W, device):
+    A = num_anchors(H, W)
+    out = torch.empty((1, A, 4), dtype=torch.float32, device=device)
+    L.check(L.lib().effdet_anchors(L.ptr(out), H, W, L.stream_ptr()), 'effdet_anchors')
+    return out
+
+
+def decode_score(anc, reg, cls, img_h, img_w):
+    B, A, nc = cls.shape
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=cls.device)
+    score = torch.empty((B, A), dtype=torch.float32, device=cls.device)
+    label = torch.empty((B, A), dtype=torch.int32, device=cls.device)
+    L.check(L.lib().effdet_decode_score(L.ptr(anc), L.ptr(reg), L.ptr(cls), L.ptr(boxes), L.ptr(score), L.ptr(label), B,
+                                        C.c_longlong(A), nc, C.c_float(img_w), C.c_float(img_h), L.stream_ptr()), 'effdet_decode_score')
+    return boxes, score, label
+
+
+def nms(boxes, score, threshold, iou_threshold):
+    """-> (idx [B][A] int32 kept anchor indices in order, count [B] int32); all on device, no sync."""
+    B, A = score.shape
+    nbytes = int(L.lib().effdet_nms_workspace_bytes(B, C.c_longlong(A)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=score.device)
+    idx = torch.empty((B, A), dtype=torch.int32, device=score.device)
+    count = torch.empty((B,), dtype=torch.int32, device=score.device)
+    L.check(L.lib().effdet_nms(L.ptr(boxes), L.ptr(score), C.c_float(threshold), C.c_float(iou_threshold), L.ptr(idx), L.ptr(count),
+                               L.ptr(ws), C.c_longlong(nbytes), B, C.c_longlong(A), L.stream_ptr()), 'effdet_nms')
+    return idx, count
+
+
+def gather_dets(boxes, score, label, idx, count):
+    B, A = score.shape
+    os_ = torch.empty((B, A), dtype=torch.float32, device=score.device)
+    ol = torch.empty((B, A), dtype=torch.int64, device=score.device)
+    ob = torch.empty((B, A, 4), dtype=torch.float32, device=score.device)
+    L.check(L.lib().effdet_gather_dets(L.ptr(boxes), L.ptr(score), L.ptr(label), L.ptr(idx), L.ptr(count), L.ptr(os_), L.ptr(ol),
+                                       L.ptr(ob), B, C.c_longlong(A), L.stream_ptr()), 'effdet_gather_dets')
+    return os_, ol, ob
+
+
+# ----------------------------------------------------------------------------- loss
+def focal_loss_fwd(cls, reg, anc, annots):
+    B, A, nc = cls.shape
+    N = annots.shape[1]
+    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cls.device)
+    losses = torch.empty(2, dtype=torch.float32, device=cls.device)
+    L.check(L.lib().effdet_focal_loss_fwd(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(losses), L.ptr(ws),
+                                          C.c_longlong(nbytes), B, C.c_longlong(A), nc, N, L.stream_ptr()), 'effdet_focal_loss_fwd')
+    return losses, ws
+
+
+def focal_loss_bwd(cls, reg, anc, annots, gscale, ws, dtype):
+    B, A, nc = cls.shape
+    dcls = torch.empty((B, A, nc), dtype=dtype, device=cls.device)
+    dreg = torch.empty((B, A, 4), dtype=dtype, device=cls.device)
+    L.check(L.lib().effdet_focal_loss_bwd(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(gscale), L.ptr(ws), L.ptr(dcls),
+                                          L.ptr(dreg), L.dtype_code(dtype), B, C.c_longlong(A), nc, annots.shape[1], L.stream_ptr()),
+            'effdet_focal_loss_bwd')
+    return dcls, dreg

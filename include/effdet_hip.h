@@ -80,28 +80,30 @@ typedef struct {
 } effdet_wgrad_t;
 int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stream);
 
-/* OIHW fp32 master weight -> packed [Cout][KH*KW][Cin] (mode 0, forward) or the data-gradient
- * operand [Cin][KH*KW flipped][Cout] (mode 1), optionally multiplied by scale[cout] (frozen-BN
- * fold).  dtype selects the packed element type. */
+/* OIHW fp32 master weight -> packed [Cout][KH*KW][Cin_pad] (mode 0, forward; channels >= Cin are
+ * zero: the stem pads its 3 image channels to one 16-byte chunk) or the data-gradient operand
+ * [Cin][KH*KW flipped][Cout] (mode 1, Cin_pad == Cin), optionally multiplied by scale[cout]
+ * (frozen-BN fold).  dtype selects the packed element type. */
 int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, int dtype, int mode,
-                            int Cout, int Cin, int KH, int KW, effdet_stream_t stream);
-/* packed fp32 gradient [Cout][KH*KW][Cin] -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
+                            int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream);
+/* packed fp32 gradient [Cout][KH*KW][Cin_pad] -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
  * If wsum != NULL also wsum[cout] = sum_{tap,c} w_oihw * g  (needed for the frozen-BN gamma grad). */
 int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
-                             float* wsum, int accumulate, int Cout, int Cin, int KH, int KW,
+                             float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad,
                              effdet_stream_t stream);
 
-/* ---------------------------------------------------------------------------------------------
- * Stem: 3x3 stride-2 conv on the NCHW fp32 image (Cin = 3) + frozen BN + Swish -> NHWC.
- * Replaces models/efficientnet.py:193 (_conv_stem/_bn0/_swish).  z (optional) = pre-activation.
- * w: OIHW fp32 [Cout][3][3][3].  And its weight gradient (no data gradient: input is the image).
- * ------------------------------------------------------------------------------------------- */
-int effdet_stem_fwd(const float* img_nchw, const float* w_oihw, const float* scale, const float* shift,
-                    void* y, void* z, int dtype, int B, int H, int W, int Cout, int pad_t, int pad_l,
-                    int Ho, int Wo, effdet_stream_t stream);
-int effdet_stem_wgrad(const float* img_nchw, const void* dz, float* dw_oihw, float* dsum, int dtype,
-                      int B, int H, int W, int Cout, int pad_t, int pad_l, int Ho, int Wo,
-                      effdet_stream_t stream);
+/* Frozen (eval-mode) BatchNorm2d as a per-channel affine (models/efficientdet.py:88-92, eps 1e-3):
+ *   scale = gamma/sqrt(var+eps), shift = beta - mean*scale, invstd = 1/sqrt(var+eps). */
+int effdet_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                   float* scale, float* shift, float* invstd, int C, effdet_stream_t stream);
+/* Its parameter gradients from the conv weight-gradient by-products (frozen-BN backward):
+ *   dgamma = invstd*(wsum - mean*dsum), dbeta = dsum,  wsum[c] = sum_k W[c][k]*G[c][k], dsum = colsum(dz). */
+int effdet_bn_param_grad(const float* wsum, const float* dsum, const float* mean, const float* invstd,
+                         float* dgamma, float* dbeta, int C, effdet_stream_t stream);
+
+/* The stem (models/efficientnet.py:193, 3x3 stride-2 conv on the image + BN + Swish) runs through
+ * effdet_conv2d on an NHWC copy of the image whose 3 channels are zero-padded to one 16-byte chunk
+ * (effdet_nchw_f32_to_nhwc with Cpad = 8 / 4); its weight gradient through effdet_conv2d_wgrad. */
 
 /* ---------------------------------------------------------------------------------------------
  * Depthwise kxk conv (k = 3 or 5, stride 1 or 2, asymmetric zero pad) + frozen BN + Swish, with
@@ -121,6 +123,11 @@ int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, 
 int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, int dtype, int B,
                         int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
                         effdet_stream_t stream);
+/* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
+ * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
+int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);
+int effdet_dw_unpack_wgrad(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk,
+                           float* wsum, int C, int k, effdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Squeeze-excite gate:  gate[b][c] = sigmoid(W2 * swish(W1 * (pool[b]/HW) + b1) + b2)
@@ -167,11 +174,15 @@ int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, i
 int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out, const float* wraw,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                           effdet_stream_t stream);
-/* backward: given dout -> da, db (+= into db when db_accum), dc, and dwraw[wrows][wcols] (+=, fp32) */
+/* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and
+ * dn[r][col] += d loss / d n_r  (grad wrt the ONCE-normalised weights, fp32 [wrows][wcols], zeroed by
+ * the caller).  effdet_bifpn_weight_bwd then maps dn -> dwraw (+=) through the first normalisation. */
 int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, void* da, void* db,
-                          void* dc, int da_accum, int db_accum, int dc_accum, const float* wraw, float* dwraw,
+                          void* dc, int da_accum, int db_accum, int dc_accum, const float* wraw, float* dn,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                           effdet_stream_t stream);
+int effdet_bifpn_weight_bwd(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols,
+                            effdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Anchors (models/module.py:145-214,252-273): float64 arithmetic on device, cast to fp32;
@@ -219,7 +230,8 @@ int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* ancho
 
 /* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
 int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
-int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
+/* Cpad >= C: channels C..Cpad-1 of the NHWC output are written as zeros */
+int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, int Cpad, effdet_stream_t stream);
 
 /* library identification: returns "effdet-hip gfx950 <version>" */
 const char* effdet_version(void);

@@ -1,0 +1,158 @@
+"""GPU parity: depthwise conv (fwd/dgrad/wgrad), squeeze-excite (fwd/bwd), BN fold, elementwise helpers."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import assert_close
+
+pytestmark = pytest.mark.gpu
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: 2e-4, torch.bfloat16: 2e-2}
+
+
+def q_(dtype):
+    return (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+
+
+def nhwc(t, dtype):
+    from efficientdet.pytorch_amd.ops import Map
+    return Map.of(t.permute(0, 2, 3, 1).contiguous().to('cuda', dtype))
+
+
+def nchw(m):
+    return m.tensor().float().cpu().permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cfg', [(2, 16, 16, 32, 3, 1, (1, 1)), (2, 17, 17, 96, 3, 2, (0, 1)), (1, 16, 16, 144, 5, 2, (1, 2)),
+                                 (2, 8, 8, 240, 5, 1, (2, 2)), (3, 4, 4, 1152, 3, 2, (0, 1)), (2, 9, 7, 672, 5, 1, (2, 2)),
+                                 (2, 2, 2, 1152, 3, 2, (0, 1))])
+def test_dwconv_fwd_bwd(dtype, cfg):
+    from efficientdet.pytorch_amd import ops
+    B, H, W, C, k, s, (plo, phi) = cfg
+    g = torch.Generator().manual_seed(1)
+    q = q_(dtype)
+    x = q(torch.randn(B, C, H, W, generator=g)).requires_grad_(True)
+    w = (torch.randn(C, 1, k, k, generator=g) * (2.0 / (k * k)) ** 0.5).requires_grad_(True)
+    scale = 0.5 + torch.rand(C, generator=g); shift = torch.randn(C, generator=g) * 0.2
+    c = F.conv2d(F.pad(x, [plo, phi, plo, phi]), w, None, s, 0, 1, C)
+    z = c * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    y = z * torch.sigmoid(z)
+    Ho, Wo = y.shape[2:]
+    dev = 'cuda'
+    wk = ops.dw_pack_weight(w.detach().to(dev))
+    assert_close(wk.cpu(), w.detach().reshape(C, k * k).t(), 1e-7, 'dw pack')
+    pool = torch.zeros(B, C, device=dev)
+    xm = nhwc(x.detach(), dtype)
+    ym, zm = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=pool)
+    torch.cuda.synchronize()
+    assert_close(nchw(zm), z, TOL[dtype], 'dw z'); assert_close(nchw(ym), y, TOL[dtype], 'dw y')
+    assert_close(pool.cpu(), q(y.detach()).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool')
+    # backward wrt the pre-activation z: dz given
+    dz = q(torch.randn(z.shape, generator=g))
+    z.backward(dz)
+    dzm = nhwc(dz, dtype)
+    dxm = ops.dwconv_dgrad(dzm, wk, scale.to(dev), None, H, W, k, s, plo, plo)
+    gk, dsum = ops.dwconv_wgrad(xm, dzm, k, s, plo, plo)
+    wsum = torch.empty(C, device=dev)
+    dw = ops.dw_unpack_wgrad(gk, scale.to(dev), w.detach().to(dev), wsum)
+    torch.cuda.synchronize()
+    assert_close(nchw(dxm), x.grad, TOL[dtype], 'dw dgrad')
+    assert_close(dw.cpu(), w.grad, 5 * TOL[dtype], 'dw wgrad')
+    assert_close(dsum.cpu(), dz.sum(dim=(0, 2, 3)), 5 * TOL[dtype], 'dw dsum')
+    assert_close(wsum.cpu(), (w.detach() * (w.grad / scale.view(-1, 1, 1, 1))).sum(dim=(1, 2, 3)), 1e-2, 'dw wsum')
+    # fused swish'(zprev) epilogue
+    zp = q(torch.randn(B, C, H, W, generator=g))
+    dxm2 = ops.dwconv_dgrad(dzm, wk, scale.to(dev), nhwc(zp, dtype), H, W, k, s, plo, plo)
+    sg = torch.sigmoid(zp)
+    assert_close(nchw(dxm2), x.grad * (sg * (1 + zp * (1 - sg))), TOL[dtype], 'dw dgrad*swish')
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8)])
+def test_squeeze_excite_fwd_bwd(dtype, cfg):
+    """pool -> gate MLP -> channel scale, and the whole backward chain, vs torch autograd."""
+    from efficientdet.pytorch_amd import ops
+    B, H, W, C, Cse = cfg
+    g = torch.Generator().manual_seed(2)
+    q = q_(dtype)
+    z = q(torch.randn(B, C, H, W, generator=g)).requires_grad_(True)     # depthwise pre-activation
+    w1 = (torch.randn(Cse, C, 1, 1, generator=g) / C ** 0.5).requires_grad_(True)
+    b1 = (torch.randn(Cse, generator=g) * 0.1).requires_grad_(True)
+    w2 = (torch.randn(C, Cse, 1, 1, generator=g) / Cse ** 0.5).requires_grad_(True)
+    b2 = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    x = z * torch.sigmoid(z)
+    xq = x.detach()
+    if dtype == torch.bfloat16:        # the kernels see the bf16-rounded activation; mirror with a straight-through round
+        x = x + (q(xq) - xq)
+    sq = F.adaptive_avg_pool2d(x, 1)
+    mid = F.conv2d(sq, w1, b1)
+    gate = torch.sigmoid(F.conv2d(mid * torch.sigmoid(mid), w2, b2))
+    y = gate * x
+    dy = q(torch.randn(y.shape, generator=g))
+    y.backward(dy)
+    dev = 'cuda'
+    xm = nhwc(x.detach(), dtype); zm = nhwc(z.detach(), dtype)
+    pool = x.detach().sum(dim=(2, 3)).to(dev)
+    inv = 1.0 / (H * W)
+    w1d, b1d, w2d, b2d = (t.detach().to(dev) for t in (w1, b1, w2, b2))
+    gd, midd = ops.se_gate_fwd(pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), b2d, inv, save_mid=True)
+    ymm = ops.channel_scale(xm, gd)
+    torch.cuda.synchronize()
+    assert_close(gd.cpu(), gate.detach().view(B, C), 1e-4, 'se gate')
+    assert_close(nchw(ymm), y.detach(), TOL[dtype], 'se scale')
+    dym = nhwc(dy, dtype)
+    dg = ops.se_dgate(dym, xm)
+    dw1 = torch.zeros(Cse, C, device=dev); db1 = torch.zeros(Cse, device=dev)
+    dw2 = torch.zeros(C, Cse, device=dev); db2 = torch.zeros(C, device=dev)
+    dpool = ops.se_gate_bwd(dg, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv, dw1, db1, dw2, db2)
+    dzm = ops.se_bwd_apply(dym, gd, dpool, zm)
+    torch.cuda.synchronize()
+    t = 5 * TOL[dtype]
+    assert_close(dw1.cpu(), w1.grad.view(Cse, C), t, 'se dw1'); assert_close(db1.cpu(), b1.grad, t, 'se db1')
+    assert_close(dw2.cpu(), w2.grad.view(C, Cse), t, 'se dw2'); assert_close(db2.cpu(), b2.grad, t, 'se db2')
+    assert_close(nchw(dzm), z.grad, t, 'se dz')
+
+
+def test_bn_fold_and_param_grad():
+    from efficientdet.pytorch_amd import ops
+    g = torch.Generator().manual_seed(3)
+    C = 100
+    gamma = (0.5 + torch.rand(C, generator=g)).requires_grad_(True); beta = torch.randn(C, generator=g).requires_grad_(True)
+    mean = torch.randn(C, generator=g); var = 0.5 + torch.rand(C, generator=g)
+    sc, sh, inv = ops.bn_fold(*(t.detach().cuda() for t in (gamma, beta, mean, var)))
+    invr = 1 / torch.sqrt(var + 1e-3)
+    assert_close(sc.cpu(), gamma.detach() * invr, 1e-6, 'scale'); assert_close(sh.cpu(), beta.detach() - mean * gamma.detach() * invr, 1e-5, 'shift')
+    # y = bn(c), c = conv out [M, C]; dgamma = sum dz*(c-mean)*invstd with sum_m dz*c given as wsum
+    c = torch.randn(50, C, generator=g); dz = torch.randn(50, C, generator=g)
+    y = (c - mean) * invr * gamma + beta
+    y.backward(dz)
+    wsum = (dz * c).sum(0).cuda(); dsum = dz.sum(0).cuda()
+    dg, db = ops.bn_param_grad(wsum, dsum, mean.cuda(), inv)
+    assert_close(dg.cpu(), gamma.grad, 1e-4, 'dgamma'); assert_close(db.cpu(), beta.grad, 1e-5, 'dbeta')
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_elementwise_helpers(dtype):
+    from efficientdet.pytorch_amd import ops
+    g = torch.Generator().manual_seed(4)
+    q = q_(dtype)
+    B, H, W, C = 3, 5, 6, 40
+    dy = q(torch.randn(B, C, H, W, generator=g)); aux = q(torch.randn(B, C, H, W, generator=g)); rs = torch.rand(B, generator=g) + 0.5
+    out = ops.act_bwd(nhwc(dy, dtype), nhwc(aux, dtype), ops.ACT_RELU)
+    assert_close(nchw(out), dy * (aux > 0), TOL[dtype], 'relu bwd')
+    sg = torch.sigmoid(aux)
+    out = ops.act_bwd(nhwc(dy, dtype), nhwc(aux, dtype), ops.ACT_SWISH, rowscale=rs.cuda())
+    assert_close(nchw(out), dy * sg * (1 + aux * (1 - sg)) * rs.view(-1, 1, 1, 1), TOL[dtype], 'swish bwd')
+    out = ops.act_bwd(nhwc(dy, dtype), None, ops.ACT_NONE, rowscale=rs.cuda())
+    assert_close(nchw(out), dy * rs.view(-1, 1, 1, 1), TOL[dtype], 'rowscale bwd')
+    a = nhwc(dy, dtype); ops.add_inplace(a, nhwc(aux, dtype))
+    assert_close(nchw(a), q(dy + aux), TOL[dtype], 'add')
+    cs = torch.zeros(C, device='cuda')
+    ops.colsum(nhwc(dy, dtype).tensor().view(-1, C), cs)
+    assert_close(cs.cpu(), dy.sum(dim=(0, 2, 3)), 5 * TOL[dtype], 'colsum')
+    x = torch.randn(2, 3, 9, 7, generator=g)
+    m = ops.nchw_to_nhwc(x.cuda(), dtype, cpad=8)
+    assert_close(m.tensor()[..., :3].float().cpu().permute(0, 3, 1, 2), q(x), 1e-6, 'nchw->nhwc')
+    assert float(m.tensor()[..., 3:].float().abs().max()) == 0.0
+    assert_close(ops.nhwc_to_nchw(nhwc(x, dtype)).cpu(), q(x), 1e-6, 'nhwc->nchw')
