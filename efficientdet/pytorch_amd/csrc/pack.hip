@@ -9,20 +9,21 @@ template <typename T>
 __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
                               int mode, int Cout, int Cin, int KH, int KW, int Cin_pad) {
   const int taps = KH * KW;
-  const long long total = mode == 0 ? (long long)Cout * Cin_pad * taps : (long long)Cout * Cin * taps;
+  // mode 0 pads the inner Cin dim to Cin_pad; mode 1 pads the inner Cout dim to Cin_pad (named Kpad in the ABI)
+  const long long total = mode == 0 ? (long long)Cout * Cin_pad * taps : (long long)Cin * Cin_pad * taps;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     // i indexes the OUTPUT (coalesced writes)
     int c, tap, n;
     if (mode == 0) { c = (int)(i % Cin_pad); tap = (int)((i / Cin_pad) % taps); n = (int)(i / ((long long)Cin_pad * taps)); }
-    else { c = (int)(i % Cout); tap = (int)((i / Cout) % taps); n = (int)(i / ((long long)Cout * taps)); }
+    else { c = (int)(i % Cin_pad); tap = (int)((i / Cin_pad) % taps); n = (int)(i / ((long long)Cin_pad * taps)); }
     const int kh = tap / KW, kw = tap % KW;
     float v;
     if (mode == 0) {
       v = c < Cin ? w[(((long long)n * Cin + c) * KH + kh) * KW + kw] : 0.f;   // zero-filled channel padding
       if (scale) v *= scale[n];
     } else {
-      v = w[(((long long)c * Cin + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
-      if (scale) v *= scale[c];
+      v = c < Cout ? w[(((long long)c * Cin + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)] : 0.f;
+      if (scale && c < Cout) v *= scale[c];
     }
     Elem<T>::st(out + i, v);
   }
@@ -70,6 +71,16 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
+// dst[b][pix][0..Cpad) = src[src_off + b*src_bs + pix*src_ld + c] (c < C), zeros beyond C
+template <typename T>
+__global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, long long src_off, long long src_bs, int src_ld,
+                                int HW, int C, int Cpad, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad); const long long r = i / Cpad; const long long b = r / HW; const int pix = (int)(r - b * HW);
+    dst[i] = c < C ? src[src_off + b * src_bs + (long long)pix * src_ld + c] : (T)0;
+  }
+}
+
 inline int grid_for(long long n, int block = 256) {
   long long g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -79,8 +90,9 @@ inline int grid_for(long long n, int block = 256) {
 
 extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void* out, int dtype, int mode,
                                        int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream) {
-  if (!w || !out || (mode != 0 && mode != 1) || Cin_pad < Cin || (mode == 1 && Cin_pad != Cin)) return EFFDET_EINVAL;
-  const long long n = (long long)Cout * Cin_pad * KH * KW;
+  if (!w || !out || (mode != 0 && mode != 1)) return EFFDET_EINVAL;
+  if ((mode == 0 && Cin_pad < Cin) || (mode == 1 && Cin_pad < Cout)) return EFFDET_EINVAL;
+  const long long n = mode == 0 ? (long long)Cout * Cin_pad * KH * KW : (long long)Cin * Cin_pad * KH * KW;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EFFDET_F32)
     hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
@@ -113,6 +125,18 @@ extern "C" int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, x, (float*)y, B, H * W, C, Cpad);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, x, (bf16_t*)y, B, H * W, C, Cpad);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, long long src_bstride, int src_ld,
+                               int B, int HW, int C, int Cpad, effdet_stream_t stream) {
+  if (!src || !dst || Cpad < C) return EFFDET_EINVAL;
+  const long long n = (long long)B * HW * Cpad;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)src, (float*)dst, src_off, src_bstride, src_ld, HW, C, Cpad, n);
+  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(pad_rows_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, src_off, src_bstride, src_ld, HW, C, Cpad, n);
+  else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -1,0 +1,373 @@
+"""Explicit forward / backward of the EfficientDet components over the HIP kernels.
+
+Each component has a ``*_fwd`` that returns (outputs, saved) and a ``*_bwd`` that maps output gradients
+to input + parameter gradients.  PyTorch only owns memory, streams and the outer autograd graph
+(efficientdet.py wraps these in autograd.Function nodes); every numeric op is a kernel of
+libeffdet_hip.so.  Reference lines cited are relative to the reference repository root.
+
+Frozen-BN backward without re-reading the conv output: for y = act(s*c + t), c = conv(x, W),
+s = gamma*invstd:   dz = dy*act'(z);  dx = dgrad(dz, W*s);  G = x^T dz;  dW = s*G;
+dgamma = invstd*(sum_k W*G - mean*sum dz);  dbeta = sum dz.
+"""
+import torch
+
+from . import ops
+from .config import BN_EPS, conv_out
+from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE, RES_RELU_MASK, Map
+
+
+def chunk_elems(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+class ZeroArena:
+    """One zero-filled fp32 allocation carved into gradient accumulators (one memset instead of dozens)."""
+
+    def __init__(self, nfloats, device):
+        self.buf = torch.zeros(max(int(nfloats), 1), dtype=torch.float32, device=device)
+        self.pos = 0
+
+    def take(self, *shape):
+        n = 1
+        for s in shape:
+            n *= s
+        v = self.buf[self.pos:self.pos + n].view(*shape)
+        self.pos += (n + 63) // 64 * 64
+        assert self.pos <= self.buf.numel() + 64
+        return v
+
+    @staticmethod
+    def need(*sizes):
+        return sum((n + 63) // 64 * 64 for n in sizes)
+
+
+def as_map(t):
+    return Map.of(t)
+
+
+# ------------------------------------------------------------------------------------------ stem
+def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train):
+    """models/efficientnet.py:193  swish(bn0(conv_stem(img)))  (3x3 s2, static same pad)."""
+    ce = chunk_elems(dtype)
+    B, _, H, W = img.shape
+    x = ops.nchw_to_nhwc(img.contiguous().float(), dtype, cpad=ce)
+    s, t, inv = ops.bn_fold(gamma, beta, mean, var, BN_EPS)
+    wp = ops.pack_weight(w, dtype, cin_pad=ce)
+    Cout = w.shape[0]
+    Ho, Wo = conv_out(H, 3, 2, pad), conv_out(W, 3, 2, pad)
+    y = Map.new(B, Ho, Wo, Cout, dtype, img.device)
+    z = Map.new(B, Ho, Wo, Cout, dtype, img.device) if train else None
+    ops.conv2d(x, wp, y, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0], scale=s, shift=t,
+               act=ACT_SWISH, zs=z)
+    return y, (x, z, s, inv, mean, w, pad)
+
+
+def stem_bwd(saved, dy):
+    x, z, s, inv, mean, w, pad = saved
+    Cout, ce = w.shape[0], x.C
+    dz = ops.act_bwd(dy, z, ACT_SWISH)
+    ar = ZeroArena(ZeroArena.need(Cout * 9 * ce, Cout), w.device)
+    G, dsum = ar.take(Cout, 9, ce), ar.take(Cout)
+    ops.conv2d_wgrad(x, dz, G, dsum, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
+    dw = torch.empty_like(w); wsum = torch.empty(Cout, dtype=torch.float32, device=w.device)
+    ops.unpack_wgrad(G, dw, scale=s, w_oihw=w, wsum=wsum, cin_pad=ce)
+    dg, db = ops.bn_param_grad(wsum, dsum, mean, inv)
+    return dw, dg, db
+
+
+# ------------------------------------------------------------------------------------------ MBConv
+def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
+    """models/efficientnet.py:75-105.  P: dict of parameter / buffer tensors of the block.
+    rowscale: optional [B] fp32 = drop_connect keep-mask / keep_prob (models/utils.py:79-90)."""
+    dev = x.t.device
+    B, H, W = x.B, x.H, x.W
+    sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale}
+    if blk.expand != 1:
+        s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
+        xe = Map.new(B, H, W, blk.cexp, dtype, dev)
+        ze = Map.new(B, H, W, blk.cexp, dtype, dev) if train else None
+        ops.conv2d(x, ops.pack_weight(P['expand.weight'], dtype), xe, Cin=blk.cin, Cout=blk.cexp, KH=1, KW=1,
+                   scale=s0, shift=t0, act=ACT_SWISH, zs=ze)
+        sv.update(s0=s0, i0=i0, ze=ze)
+    else:
+        xe = x
+    s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
+    wk = ops.dw_pack_weight(P['dw.weight'])
+    Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
+    pool = torch.zeros((B, blk.cexp), dtype=torch.float32, device=dev)
+    xd, zd = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=pool)
+    inv_hw = 1.0 / (Ho * Wo)
+    w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
+    gate, mid = ops.se_gate_fwd(pool, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
+    xs = ops.channel_scale(xd, gate)
+    s2, t2, i2 = ops.bn_fold(P['bn2.weight'], P['bn2.bias'], P['bn2.running_mean'], P['bn2.running_var'], BN_EPS)
+    y = Map.new(B, Ho, Wo, blk.cout, dtype, dev)
+    ops.conv2d(xs, ops.pack_weight(P['project.weight'], dtype), y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1,
+               scale=s2, shift=t2, act=ACT_NONE, rowscale=rowscale if blk.skip else None,
+               res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
+    if train:
+        sv.update(xe=xe, s1=s1, i1=i1, wk=wk, xd=xd, zd=zd, pool=pool, gate=gate, mid=mid, xs=xs, s2=s2, i2=i2,
+                  inv_hw=inv_hw)
+    return y, sv
+
+
+def mbconv_bwd(sv, dy):
+    """-> (dx Map, grads dict keyed like P)."""
+    blk, P, x = sv['blk'], sv['P'], sv['x']
+    dtype, dev = x.dtype, x.t.device
+    B, H, W = x.B, x.H, x.W
+    g = {}
+    Ce, Co, Ci, Cs, kk = blk.cexp, blk.cout, blk.cin, blk.cse, blk.k * blk.k
+    ar = ZeroArena(ZeroArena.need(Co * Ce, Co, Cs * Ce, Cs, Ce * Cs, Ce, Ce * Ci, Ce), dev)
+    # ---- project conv (+ drop_connect scale on the branch) ----
+    rs = sv['rowscale'] if blk.skip else None
+    dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
+    G2, dsum2 = ar.take(Co, 1, Ce), ar.take(Co)
+    ops.conv2d_wgrad(sv['xs'], dz2, G2, dsum2, Cin=Ce, Cout=Co, KH=1, KW=1)
+    wp = P['project.weight']
+    dwp = torch.empty_like(wp); wsum2 = torch.empty(Co, dtype=torch.float32, device=dev)
+    ops.unpack_wgrad(G2, dwp, scale=sv['s2'], w_oihw=wp, wsum=wsum2)
+    g['project.weight'] = dwp
+    g['bn2.weight'], g['bn2.bias'] = ops.bn_param_grad(wsum2, dsum2, P['bn2.running_mean'], sv['i2'])
+    dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
+    ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
+    # ---- squeeze-excite ----
+    dgate = ops.se_dgate(dxs, sv['xd'])
+    dw1, db1, dw2, db2 = ar.take(Cs, Ce), ar.take(Cs), ar.take(Ce, Cs), ar.take(Ce)
+    w1 = P['se_reduce.weight'].view(Cs, Ce); w2 = P['se_expand.weight'].view(Ce, Cs)
+    dpool = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2, sv['inv_hw'],
+                            dw1, db1, dw2, db2)
+    g['se_reduce.weight'], g['se_reduce.bias'] = dw1.view(Cs, Ce, 1, 1), db1
+    g['se_expand.weight'], g['se_expand.bias'] = dw2.view(Ce, Cs, 1, 1), db2
+    dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
+    # ---- depthwise ----
+    gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0])
+    wsum1 = torch.empty(Ce, dtype=torch.float32, device=dev)
+    g['dw.weight'] = ops.dw_unpack_wgrad(gk, sv['s1'], P['dw.weight'], wsum1)
+    g['bn1.weight'], g['bn1.bias'] = ops.bn_param_grad(wsum1, dsum1, P['bn1.running_mean'], sv['i1'])
+    dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else None, H, W, blk.k, blk.stride,
+                           blk.pad[0], blk.pad[0])
+    if blk.expand == 1:
+        return dze, g           # block 0: depthwise acts on the block input directly, no skip
+    # ---- expand conv; the identity-skip gradient is added in the data-gradient epilogue ----
+    G0, dsum0 = ar.take(Ce, 1, Ci), ar.take(Ce)
+    ops.conv2d_wgrad(x, dze, G0, dsum0, Cin=Ci, Cout=Ce, KH=1, KW=1)
+    we = P['expand.weight']
+    dwe = torch.empty_like(we); wsum0 = torch.empty(Ce, dtype=torch.float32, device=dev)
+    ops.unpack_wgrad(G0, dwe, scale=sv['s0'], w_oihw=we, wsum=wsum0)
+    g['expand.weight'] = dwe
+    g['bn0.weight'], g['bn0.bias'] = ops.bn_param_grad(wsum0, dsum0, P['bn0.running_mean'], sv['i0'])
+    dx = Map.new(B, H, W, Ci, dtype, dev)
+    ops.conv2d(dze, ops.pack_weight(we, dtype, mode=1, scale=sv['s0']), dx, Cin=Ce, Cout=Ci, KH=1, KW=1,
+               res=dy if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
+    return dx, g
+
+
+# ------------------------------------------------------------------------------------------ BiFPN
+def lateral_fwd(feats, weights, biases, W, dtype):
+    """models/bifpn.py:100-103: 1x1 conv + bias per level (different Cin / weights per level)."""
+    outs = []
+    for f, w, b in zip(feats, weights, biases):
+        y = Map.new(f.B, f.H, f.W, W, dtype, f.t.device)
+        ops.conv2d(f, ops.pack_weight(w, dtype), y, Cin=f.C, Cout=W, KH=1, KW=1, shift=b)
+        outs.append(y)
+    return outs
+
+
+def lateral_bwd(feats, weights, douts, dtype):
+    dfs, dws, dbs = [], [], []
+    for f, w, dy in zip(feats, weights, douts):
+        W, Cin = w.shape[0], w.shape[1]
+        ar = ZeroArena(ZeroArena.need(W * Cin, W), w.device)
+        G, db = ar.take(W, 1, Cin), ar.take(W)
+        ops.conv2d_wgrad(f, dy, G, db, Cin=Cin, Cout=W, KH=1, KW=1)
+        dw = torch.empty_like(w)
+        ops.unpack_wgrad(G, dw)
+        df = Map.new(f.B, f.H, f.W, Cin, dtype, w.device)
+        ops.conv2d(dy, ops.pack_weight(w, dtype, mode=1), df, Cin=W, Cout=Cin, KH=1, KW=1)
+        dfs.append(df); dws.append(dw); dbs.append(db)
+    return dfs, dws, dbs
+
+
+def _conv3_fwd(x, w, b, dtype):
+    y = Map.new(x.B, x.H, x.W, w.shape[0], dtype, x.t.device)
+    ops.conv2d(x, ops.pack_weight(w, dtype), y, Cin=w.shape[1], Cout=w.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, shift=b)
+    return y
+
+
+def bifpn_module_fwd(p, w1, w2, cw, cb, dtype, train):
+    """models/bifpn.py:172-203.  p: 5 Maps (fine -> coarse); cw/cb: the 8 conv weights / biases.
+    Node order and aliasing follow the reference exactly: top-down results overwrite p[3..0], the
+    bottom-up pass reads those plus the ORIGINAL inputs (its `inputs_clone`)."""
+    L_ = len(p)
+    t_in = list(p)
+    cur = list(p)
+    nodes = []            # (mode, col, wsel, a_name, b_name, c_name, out_name, fused Map)
+    names = {('in', l): t_in[l] for l in range(L_)}
+    c = 0
+    for i in range(L_ - 1, 0, -1):                                  # top-down, bifpn.py:188-192
+        a_n = ('in', i - 1); b_n = ('in', i) if i == L_ - 1 else ('td', i)
+        f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], None, w1, i - 1, 0)
+        out_n = ('td', i - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+        nodes.append((0, i - 1, 1, a_n, b_n, None, out_n, f, c)); c += 1
+    for i in range(0, L_ - 2):                                      # bottom-up, bifpn.py:194-198
+        a_n = ('td', i + 1); b_n = ('td', 0) if i == 0 else ('bu', i); c_n = ('in', i + 1)
+        f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], names[c_n], w2, i, 1)
+        out_n = ('bu', i + 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+        nodes.append((1, i, 2, a_n, b_n, c_n, out_n, f, c)); c += 1
+    a_n = ('in', L_ - 1); b_n = ('bu', L_ - 2)                      # top node, bifpn.py:200-202
+    f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], None, w1, L_ - 1, 2)
+    out_n = ('top', L_ - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+    nodes.append((2, L_ - 1, 1, a_n, b_n, None, out_n, f, c))
+    out_names = [('td', 0)] + [('bu', l) for l in range(1, L_ - 1)] + [out_n]
+    outs = [names[n] for n in out_names]
+    cur = outs
+    saved = (nodes, names, out_names, w1, w2, cw) if train else None
+    return cur, saved
+
+
+def bifpn_module_bwd(saved, douts, dtype):
+    """-> (d_inputs [5 Maps], dw1, dw2, dcw [8], dcb [8])."""
+    nodes, names, out_names, w1, w2, cw = saved
+    dev = w1.device
+    Wc = cw[0].shape[0]
+    grads = {}                                   # tensor name -> Map (private, safe to accumulate into)
+    for n, d in zip(out_names, douts):
+        grads[n] = Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
+    ar = ZeroArena(ZeroArena.need(*([Wc * 9 * Wc, Wc] * 8), 10, 9), dev)
+    dn1, dn2 = ar.take(2, w1.shape[1]), ar.take(3, w2.shape[1])
+    dcw, dcb = [None] * 8, [None] * 8
+
+    def target(name):
+        like = names[name]
+        if name in grads:
+            return grads[name], True
+        grads[name] = Map.new(like.B, like.H, like.W, like.C, dtype, dev)
+        return grads[name], False
+
+    for (mode, col, wsel, a_n, b_n, c_n, out_n, f, ci) in reversed(nodes):
+        dz = grads[out_n]                                            # conv has bias only: dz = dy
+        G, db = ar.take(Wc, 9, Wc), ar.take(Wc)
+        ops.conv2d_wgrad(f, dz, G, db, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+        dw = torch.empty_like(cw[ci]); ops.unpack_wgrad(G, dw)
+        dcw[ci], dcb[ci] = dw, db
+        df = Map.new(f.B, f.H, f.W, Wc, dtype, dev)
+        ops.conv2d(dz, ops.pack_weight(cw[ci], dtype, mode=1), df, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+        da, da_acc = target(a_n); dbm, db_acc = target(b_n)
+        dc, dc_acc = target(c_n) if c_n is not None else (None, False)
+        ops.bifpn_fuse_bwd(df, names[a_n], names[b_n], names[c_n] if c_n else None, da, dbm, dc, da_acc, db_acc, dc_acc,
+                           w1 if wsel == 1 else w2, dn1 if wsel == 1 else dn2, col, mode)
+    dw1 = torch.zeros_like(w1); dw2 = torch.zeros_like(w2)
+    ops.bifpn_weight_bwd(w1, dn1, dw1); ops.bifpn_weight_bwd(w2, dn2, dw2)
+    dins = [grads[('in', l)] for l in range(len(out_names))]
+    return dins, dw1, dw2, dcw, dcb
+
+
+# ------------------------------------------------------------------------------------------ RetinaHead
+def pyramid_alloc(B, sizes, C, dtype, device):
+    """All levels of one activation in ONE flat buffer (level-major) so that grouped launches can
+    address every pyramid tensor of the same channel count with identical relative offsets."""
+    tot = sum(B * h * w * C for (h, w) in sizes)
+    flat = torch.empty(tot, dtype=dtype, device=device)
+    maps, off = [], 0
+    for (h, w) in sizes:
+        maps.append(Map(flat, B, h, w, C, off=off)); off += B * h * w * C
+    return flat, maps
+
+
+def level_tensor(m):
+    n = m.B * m.H * m.W * m.C
+    return m.t[m.off:m.off + n].view(m.B, m.H, m.W, m.C)
+
+
+def head_out_maps(buf, B, sizes, per_anchor):
+    """Views of a [B, A, per_anchor] output buffer as per-level NHWC maps with 9*per_anchor channels
+    (models/retinahead.py:119-127: NHWC permute + view(B, -1, C) is free in this layout)."""
+    A = sum(h * w for (h, w) in sizes) * 9
+    maps, aoff = [], 0
+    for (h, w) in sizes:
+        maps.append(Map(buf, B, h, w, 9 * per_anchor, ld=9 * per_anchor, bstride=A * per_anchor, off=aoff * per_anchor))
+        aoff += h * w * 9
+    return maps
+
+
+def head_fwd(p, HP, num_classes, dtype, train):
+    """models/retinahead.py:109-132 for all 5 levels per launch (weights are shared across levels).
+    p: 5 Maps; HP: dict of head parameter tensors.  -> classification [B,A,nc] fp32 (probabilities),
+    regression [B,A,4] fp32."""
+    dev = p[0].t.device
+    B, Wc = p[0].B, p[0].C
+    sizes = [(m.H, m.W) for m in p]
+    A = sum(h * w for (h, w) in sizes) * 9
+    acts = {'cls': [], 'reg': []}
+    for tower in ('cls', 'reg'):
+        cur = p
+        for t in range(4):
+            w, b = HP[f'{tower}_convs.{t}.weight'], HP[f'{tower}_convs.{t}.bias']
+            _, nxt = pyramid_alloc(B, sizes, 256, dtype, dev)
+            ops.conv2d(cur, ops.pack_weight(w, dtype), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
+                       shift=b, act=ACT_RELU)
+            acts[tower].append(nxt); cur = nxt
+    cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
+    reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+    ops.conv2d(acts['cls'][3], ops.pack_weight(HP['retina_cls.weight'], dtype), head_out_maps(cls, B, sizes, num_classes),
+               Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
+               act=ACT_SIGMOID, out_f32=True)
+    ops.conv2d(acts['reg'][3], ops.pack_weight(HP['retina_reg.weight'], dtype), head_out_maps(reg, B, sizes, 4),
+               Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True)
+    saved = (p, acts, sizes, HP, num_classes) if train else None
+    return cls, reg, saved
+
+
+def head_bwd(saved, dcls_logit, dreg, dtype):
+    """dcls_logit [B,A,nc], dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.
+    -> (dp: 5 Maps, grads dict keyed like HP)."""
+    p, acts, sizes, HP, nc = saved
+    dev = p[0].t.device
+    B, Wc = p[0].B, p[0].C
+    g = {}
+    need = []
+    for name, w in HP.items():
+        if name.endswith('weight'):
+            need += [w.numel(), w.shape[0]]
+    ar = ZeroArena(ZeroArena.need(*need), dev)
+    dp_maps = None
+    for tower, dout, per in (('cls', dcls_logit, nc), ('reg', dreg, 4)):
+        fin = f'retina_{tower}'
+        wf = HP[fin + '.weight']
+        dzmaps = head_out_maps(dout, B, sizes, per)
+        Cf = wf.shape[0]
+        ce = chunk_elems(dtype)
+        Cfp = (Cf + ce - 1) // ce * ce
+        if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
+            dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
+        G, db = ar.take(Cf, 9, 256), ar.take(Cf)
+        ops.conv2d_wgrad(acts[tower][3], dzmaps, G, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
+        dw = torch.empty_like(wf); ops.unpack_wgrad(G, dw)
+        g[fin + '.weight'], g[fin + '.bias'] = dw, db
+        # data gradient with the ReLU mask of the producing tower layer fused into the epilogue
+        _, dz = pyramid_alloc(B, sizes, 256, dtype, dev)
+        ops.conv2d(dzmaps, ops.pack_weight(wf, dtype, mode=1, cin_pad=Cfp), dz, Cin=Cfp, Cout=256, KH=3, KW=3, pad_t=1,
+                   pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK)
+        for t in range(3, -1, -1):
+            w = HP[f'{tower}_convs.{t}.weight']
+            xin = acts[tower][t - 1] if t > 0 else p
+            Cin = w.shape[1]
+            G, db = ar.take(256, 9, Cin), ar.take(256)
+            ops.conv2d_wgrad(xin, dz, G, db, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
+            dw = torch.empty_like(w); ops.unpack_wgrad(G, dw)
+            g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
+            wd = ops.pack_weight(w, dtype, mode=1)
+            if t > 0:
+                _, nz = pyramid_alloc(B, sizes, 256, dtype, dev)
+                ops.conv2d(dz, wd, nz, Cin=256, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, res=acts[tower][t - 1],
+                           res_mode=RES_RELU_MASK)
+                dz = nz
+            else:
+                if dp_maps is None:
+                    _, dp_maps = pyramid_alloc(B, sizes, Wc, dtype, dev)
+                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+                else:                                   # second tower: accumulate onto the first one's gradient
+                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, res=dp_maps,
+                               res_mode=RES_ADD)
+    return dp_maps, g

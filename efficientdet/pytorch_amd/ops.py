@@ -62,8 +62,9 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
     Cout, Cin, KH, KW = w_oihw.shape
     w = w_oihw.detach()
     assert w.dtype == torch.float32 and w.is_contiguous()
-    cin_pad = Cin if cin_pad is None else cin_pad
-    shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, Cout)
+    if cin_pad is None:
+        cin_pad = Cin if mode == 0 else Cout
+    shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, cin_pad)
     out = torch.empty(shape, dtype=dtype, device=w.device)
     L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), L.dtype_code(dtype), mode,
                                             Cout, Cin, KH, KW, cin_pad, L.stream_ptr()), 'effdet_pack_conv_weight')
@@ -359,3 +360,12 @@ def focal_loss_bwd(cls, reg, anc, annots, gscale, ws, dtype):
                                           L.ptr(dreg), L.dtype_code(dtype), B, C.c_longlong(A), nc, annots.shape[1], L.stream_ptr()),
             'effdet_focal_loss_bwd')
     return dcls, dreg
+
+
+def pad_rows(src_map, cpad):
+    """Level map with unaligned channel count -> fresh contiguous [B,H,W,cpad] map, zero padded."""
+    m = src_map
+    dst = Map.new(m.B, m.H, m.W, cpad, m.dtype, m.t.device)
+    L.check(L.lib().effdet_pad_rows(L.ptr(m.t), L.ptr(dst.t), L.dtype_code(m.dtype), C.c_longlong(m.off), C.c_longlong(m.bstride),
+                                    m.ld, m.B, m.H * m.W, m.C, cpad, L.stream_ptr()), 'effdet_pad_rows')
+    return dst

@@ -80,10 +80,11 @@ typedef struct {
 } effdet_wgrad_t;
 int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stream);
 
-/* OIHW fp32 master weight -> packed [Cout][KH*KW][Cin_pad] (mode 0, forward; channels >= Cin are
+/* OIHW fp32 master weight -> packed [Cout][KH*KW][Kpad] (mode 0, forward; channels >= Cin are
  * zero: the stem pads its 3 image channels to one 16-byte chunk) or the data-gradient operand
- * [Cin][KH*KW flipped][Cout] (mode 1, Cin_pad == Cin), optionally multiplied by scale[cout]
- * (frozen-BN fold).  dtype selects the packed element type. */
+ * [Cin][KH*KW flipped][Kpad] (mode 1; Kpad >= Cout, entries >= Cout zero: the head's 9*num_classes /
+ * 36-channel gradient maps are padded to whole chunks), optionally multiplied by scale[cout]
+ * (frozen-BN fold).  `Cin_pad` is that inner-dimension padding Kpad.  dtype = packed element type. */
 int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, int dtype, int mode,
                             int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream);
 /* packed fp32 gradient [Cout][KH*KW][Cin_pad] -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
@@ -227,6 +228,11 @@ int effdet_focal_loss_fwd(const float* cls, const float* reg, const float* ancho
 int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots,
                           const float* gscale, const void* workspace, void* dcls_logit, void* dreg, int dtype,
                           int B, long long A, int num_classes, int N, effdet_stream_t stream);
+
+/* Row repack with zero channel padding: dst[b][pix][0..Cpad) = src[src_off + b*src_bstride + pix*src_ld + c]
+ * for c < C, 0 beyond (makes an unaligned-channel gradient map consumable by effdet_conv2d). */
+int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, long long src_bstride, int src_ld,
+                    int B, int HW, int C, int Cpad, effdet_stream_t stream);
 
 /* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
 int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);

@@ -14,3 +14,12 @@ def assert_close(got, ref, tol, what=''):
         raise AssertionError('%s: %d/%d elements exceed tol %g (first at %d: got %g ref %g; max abs err %g, ref max %g)' % (
             what, int(bad.sum()), bad.numel(), tol, i, float(got.reshape(-1)[i]), float(ref.reshape(-1)[i]),
             float((got - ref).abs().max()), float(ref.abs().max())))
+
+
+def assert_close_scale(got, ref, tol, what=''):
+    """Tensor-scale criterion for the bf16 throughput mode: |a-b| <= tol * max|b| for every element."""
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    assert bool(torch.isfinite(got).all()), what
+    err = float((got - ref).abs().max()); scale = float(ref.abs().max()) + 1e-30
+    assert err <= tol * scale, '%s: max abs err %g > %g * ref max %g' % (what, err, tol, scale)
