@@ -99,6 +99,33 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Bounds-checked 16-byte load through a buffer descriptor (SRD): an offset >= num_records returns zeros in
+// hardware, so padding / tail lanes need neither a branch nor a select.  Per-lane `if (ok) load` makes hipcc
+// wrap every load in its own exec-mask branch with an s_waitcnt behind it (serialised HBM round trips), and a
+// `ok ? load(p) : 0` select is legally re-sunk into that same branch; the SRD form cannot be.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define EFFDET_OOB 0xFFFFFFF0u
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 srd_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+// 4 consecutive elements (16 B fp32 / 8 B bf16) through an SRD -> 4 floats
+template <typename T> __device__ __forceinline__ f32x4 srd_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
+template <> __device__ __forceinline__ f32x4 srd_load4<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+}
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+template <> __device__ __forceinline__ f32x4 srd_load4<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+  return f32x4{__uint_as_float(u[0] << 16), __uint_as_float(u[0] & 0xffff0000u), __uint_as_float(u[1] << 16),
+               __uint_as_float(u[1] & 0xffff0000u)};
+}
+
 // Bijective XCD-aware remap of a 1-D block id: blocks b, b+8, b+16.. (same XCD, private L2) get
 // consecutive logical tiles.  Speed only -- never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

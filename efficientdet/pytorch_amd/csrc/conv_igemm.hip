@@ -29,6 +29,7 @@ namespace {
 struct SegD {
   int H, W, Ho, Wo, M, tile_start;
   long long in_off, in_bs, out_off, out_bs;
+  unsigned x_bytes;   // byte extent of this segment's input (its own SRD: 32-bit offsets span one tensor only)
 };
 
 struct ConvK {
@@ -40,6 +41,7 @@ struct ConvK {
   int cpt;   // chunks per tap (= Cin/CE)
   int act, res_mode, out_f32, vec_ok;
   int nseg, mtiles, ntiles;
+  unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   SegD seg[EFFDET_MAX_SEG];
 };
 
@@ -91,8 +93,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int HoWo = sg.Ho * sg.Wo;
 
   // ---- per-thread load bookkeeping: chunk column kc, rows tid/8 + 32*j ----
+  // All staging loads are bounds-checked SRD buffer loads with 32-bit BYTE offsets (common.h: srd_load16):
+  // halo / tail / K-padding lanes pass EFFDET_OOB and receive zeros from the hardware.
+  constexpr unsigned ES = sizeof(T);
+  const __amdgpu_buffer_rsrc_t rx = make_srd((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd(p.w, p.w_bytes);
   const int kc = tid & 7, r0 = tid >> 3;
-  const T* xrow[4]; int hi0[4], wi0[4];
+  unsigned xoff[4]; int hi0[4], wi0[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m_base + r0 + 32 * j;
@@ -100,15 +106,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
       const int b = m / HoWo, rem = m - b * HoWo;
       const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
       hi0[j] = ho * p.stride - p.pad_t; wi0[j] = wo * p.stride - p.pad_l;
-      xrow[j] = (const T*)p.x + sg.in_off + (long long)b * sg.in_bs;
-    } else { hi0[j] = -100000; wi0[j] = 0; xrow[j] = (const T*)p.x; }
+      xoff[j] = (unsigned)((long long)b * sg.in_bs * ES);
+    } else { hi0[j] = -100000; wi0[j] = 0; xoff[j] = 0; }
   }
-  const T* wrow[WROWS]; bool wok[WROWS];
+  unsigned woff[WROWS]; bool wok[WROWS];
 #pragma unroll
   for (int j = 0; j < WROWS; ++j) {
     const int r = r0 + 32 * j, n = n_base + r;
     wok[j] = (r < BN) && (n < p.Cout);
-    wrow[j] = (const T*)p.w + (long long)(wok[j] ? n : 0) * p.Kc * CE;
+    woff[j] = (unsigned)((long long)(wok[j] ? n : 0) * p.Kc * 16);
   }
   // K cursor of this thread's chunk column: chunk index kq = tap*cpt + cc
   int kq = kc, tap = 0, cc = kc;
@@ -122,14 +128,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     for (int j = 0; j < 4; ++j) {
       const int hi = hi0[j] + kh, wi = wi0[j] + kw;
       const bool ok = kok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
-      xr[j] = make_uint4(0, 0, 0, 0);
-      if (ok) xr[j] = *(const uint4*)(xrow[j] + ((long long)(hi * sg.W + wi) * p.ldx + cc * CE));
+      const unsigned off = xoff[j] + (unsigned)((hi * sg.W + wi) * p.ldx + cc * CE) * ES;
+      xr[j] = srd_load16(rx, ok ? off : EFFDET_OOB);
     }
 #pragma unroll
-    for (int j = 0; j < WROWS; ++j) {
-      wr[j] = make_uint4(0, 0, 0, 0);
-      if (kok && wok[j]) wr[j] = *(const uint4*)(wrow[j] + (long long)kq * CE);
-    }
+    for (int j = 0; j < WROWS; ++j)
+      wr[j] = srd_load16(rw, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     // advance the cursor by one K-step (8 chunks)
     kq += 8; cc += 8;
     while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
@@ -293,6 +297,17 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   }
   for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
   k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
+  // byte extents actually addressed through each segment's SRD (32-bit offsets): refuse tensors beyond 4 GiB - 64 KiB
+  const long long es = p->dtype == EFFDET_F32 ? 4 : 2;
+  for (int s = 0; s < p->nseg; ++s) {
+    const effdet_seg_t& g = p->seg[s];
+    const long long e = ((long long)(p->B - 1) * g.in_bstride + ((long long)(g.H - 1) * g.W + (g.W - 1)) * p->ldx + p->Cin) * es;
+    if (e >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
+    k.seg[s].x_bytes = (unsigned)e;
+  }
+  const long long wb = (long long)p->Cout * k.Kc * 16;
+  if (wb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
+  k.w_bytes = (unsigned)wb;
   hipStream_t st = (hipStream_t)stream;
   return p->dtype == EFFDET_F32 ? dispatch<float>(k, st) : dispatch<bf16_t>(k, st);
 }

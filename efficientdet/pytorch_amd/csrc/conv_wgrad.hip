@@ -14,9 +14,10 @@
 //     the TRANSPOSED LDS tile [n or j][pixels] with ds_write_b128.  The XOR swizzle
 //     f(row) = ((row>>1)&7) ^ ((row>>4)&7) keeps both those writes and the fragment reads
 //     bank-conflict free.
-//   * the pixel range is split across blockIdx.z (split-K); partial tiles are combined with
-//     fp32 global atomics (hardware float add, -munsafe-fp-atomics), which also lets the 5
-//     pyramid levels that share one weight accumulate into the same buffer in ONE launch.
+//   * the pixel range is split across blockIdx.z (split-K, which also lets the 5 pyramid levels that share
+//     one weight run as ONE launch); every split writes its fp32 partial tile to a slab with plain
+//     coalesced stores and a vectorised reduce kernel sums the slabs into dw (cross-XCD float atomics
+//     from all splits serialise at the memory side: measured 10x the MFMA time).
 //   * the bias gradient rides along as one extra MFMA per dz fragment against an all-ones
 //     operand (blocks of j-tile 0 only).
 #include "common.h"
@@ -26,15 +27,16 @@ namespace {
 struct WSeg {
   int H, W, Ho, Wo, M, split_start;
   long long in_off, in_bs, out_off, out_bs;
+  unsigned x_bytes, dz_bytes;   // per-segment SRD extents (32-bit offsets span one tensor only)
 };
 struct WgradK {
-  const void* x; const void* dz; float* dw; float* dbias;
+  const void* x; const void* dz; float* dw; float* dbias; float* slab;
   int Cin, Cout, KW, stride, pad_t, pad_l;
   int ldx, lddz;
   int Kc, cpt;      // j extent in 16-byte chunks, chunks per tap
   int K;            // taps*Cin
   int mchunk;       // pixels per split (multiple of the K-step)
-  int nseg, ntiles, jtiles;
+  int nseg, ntiles, jtiles, vec_a;
   WSeg seg[EFFDET_MAX_SEG];
 };
 
@@ -109,8 +111,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   // bf16: threads 0..127 stage dz, 128..255 stage x (one task each); fp32: every thread does both.
   constexpr bool SPLIT = (TASKS == 128);
   const int task = SPLIT ? (tid & 127) : tid;
-  const bool do_a = SPLIT ? (tid < 128) : true;
-  const bool do_b = SPLIT ? (tid >= 128) : true;
+  // the staging role is wave-uniform; readfirstlane makes that PROVABLE, so the role branch is a scalar branch and
+  // each SRD stays in SGPRs (a per-lane `do_a ? rz : rx` select costs a waterfall loop around every buffer load)
+  const bool do_a = SPLIT ? (__builtin_amdgcn_readfirstlane(tid) < 128) : true;
+  const bool do_b = SPLIT ? !do_a : true;
   const int g = task / NCH, c = task - g * NCH;      // pixel group (CE pixels), chunk column
 
   // dz side: channels n0..n0+CE-1
@@ -127,50 +131,84 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   int b0 = m0 / HoWo, rem = m0 - b0 * HoWo;
   int ho0 = rem / sg.Wo, wo0 = rem - ho0 * sg.Wo;
 
-  uint4 ra[CE], rb[CE];
+  // SPLIT (bf16): a thread stages EITHER a dz block or an x block -> ONE staging register set (rb unused),
+  // which halves the staging VGPRs and lets two workgroups share a CU.
+  uint4 ra[CE], rb[SPLIT ? 1 : CE];
+  (void)rb;
+  // Bounds-checked SRD buffer loads (common.h: srd_load16): out-of-range lanes pass EFFDET_OOB and get zeros.
+  // All address arithmetic is 32-bit BYTE offsets (the host refuses tensors >= 4 GiB).
+  // vec_a (kernel-uniform): every dz chunk [n0, n0+CE) lies inside its lddz-wide row and rows are 16-B aligned,
+  // so whole-chunk loads are safe; channels >= Cout then hold row padding and the epilogue drops those rows.
+  // rowfast (uniform per level): Wo % CE == 0, so the CE consecutive pixels of a task share one image row and
+  // their addresses are base + e*stride -- this keeps the hot loop MFMA-bound instead of VALU-bound.
+  constexpr unsigned ES = sizeof(T);
+  const __amdgpu_buffer_rsrc_t rx = make_srd((const T*)p.x + sg.in_off, sg.x_bytes), rz = make_srd((const T*)p.dz + sg.out_off, sg.dz_bytes);
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  const unsigned a_off0 = (unsigned)n0 * ES, a_bs = (unsigned)(sg.out_bs * ES), a_ld = (unsigned)p.lddz * ES;
+  const unsigned b_off0 = (unsigned)(cc * CE) * ES, b_bs = (unsigned)(sg.in_bs * ES), b_ld = (unsigned)p.ldx * ES;
+  const bool rowfast = (sg.Wo % CE) == 0;
+  const bool a_in = n0 + CE <= p.lddz;
+  auto load_a_slow = [&](int b, int ho, int wo, bool mok) -> uint4 {     // ragged channel tail / unaligned rows (rare)
+    uint4 r = zero4;
+    if (mok && n0 < p.Cout) {
+      const T* q = (const T*)p.dz + sg.out_off + (long long)b * sg.out_bs + (long long)(ho * sg.Wo + wo) * p.lddz + n0;
+      float f[CE];
+#pragma unroll
+      for (int i = 0; i < CE; ++i) f[i] = (n0 + i < p.Cout) ? Elem<T>::ld(q + i) : 0.f;
+      r = Chunk<T>::pack(f);
+    }
+    return r;
+  };
   auto gload = [&]() {
-    int b = b0, ho = ho0, wo = wo0;
+    if (rowfast && p.vec_a) {
+      const unsigned abase = a_off0 + (unsigned)b0 * a_bs + (unsigned)(ho0 * sg.Wo + wo0) * a_ld;
+      const int hi = ho0 * p.stride - p.pad_t + kh, wi0 = wo0 * p.stride - p.pad_l + kw;
+      const bool rowok = jok && hi >= 0 && hi < sg.H;
+      const unsigned bbase = b_off0 + (unsigned)b0 * b_bs + (unsigned)(hi * sg.W + wi0) * b_ld;
+      const unsigned bstep = (unsigned)p.stride * b_ld;
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-      const bool mok = (m0 + e) < m_end;
-      if (do_a) {
-        ra[e] = make_uint4(0, 0, 0, 0);
-        if (mok && n0 < p.Cout) {
-          const T* q = (const T*)p.dz + sg.out_off + (long long)b * sg.out_bs + (long long)(ho * sg.Wo + wo) * p.lddz + n0;
-          if (n0 + CE <= p.Cout && (p.lddz % CE) == 0) ra[e] = *(const uint4*)q;
-          else {  // ragged channel tail / unaligned rows: element loads
-            float f[CE];
-#pragma unroll
-            for (int i = 0; i < CE; ++i) f[i] = (n0 + i < p.Cout) ? Elem<T>::ld(q + i) : 0.f;
-            ra[e] = Chunk<T>::pack(f);
-          }
-        }
+      for (int e = 0; e < CE; ++e) {
+        const bool mok = (m0 + e) < m_end;
+        const int wi = wi0 + e * p.stride;
+        const unsigned oa = (mok && a_in) ? abase + (unsigned)e * a_ld : EFFDET_OOB;
+        const unsigned ob = (mok && rowok && wi >= 0 && wi < sg.W) ? bbase + (unsigned)e * bstep : EFFDET_OOB;
+        if constexpr (SPLIT) { if (do_a) ra[e] = srd_load16(rz, oa); else ra[e] = srd_load16(rx, ob); }
+        else { ra[e] = srd_load16(rz, oa); rb[e] = srd_load16(rx, ob); }
       }
-      if (do_b) {
-        rb[e] = make_uint4(0, 0, 0, 0);
+    } else {
+      int b = b0, ho = ho0, wo = wo0;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const bool mok = (m0 + e) < m_end;
         const int hi = ho * p.stride - p.pad_t + kh, wi = wo * p.stride - p.pad_l + kw;
-        if (mok && jok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W)
-          rb[e] = *(const uint4*)((const T*)p.x + sg.in_off + (long long)b * sg.in_bs + (long long)(hi * sg.W + wi) * p.ldx + cc * CE);
+        const unsigned oa = (mok && a_in) ? a_off0 + (unsigned)b * a_bs + (unsigned)(ho * sg.Wo + wo) * a_ld : EFFDET_OOB;
+        const unsigned ob = (mok && jok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W)
+                                ? b_off0 + (unsigned)b * b_bs + (unsigned)(hi * sg.W + wi) * b_ld : EFFDET_OOB;
+        if constexpr (SPLIT) {
+          if (do_a) ra[e] = p.vec_a ? srd_load16(rz, oa) : load_a_slow(b, ho, wo, mok);
+          else ra[e] = srd_load16(rx, ob);
+        } else {
+          ra[e] = p.vec_a ? srd_load16(rz, oa) : load_a_slow(b, ho, wo, mok);
+          rb[e] = srd_load16(rx, ob);
+        }
+        if (++wo == sg.Wo) { wo = 0; if (++ho == sg.Ho) { ho = 0; ++b; } }
       }
-      // next pixel
-      if (++wo == sg.Wo) { wo = 0; if (++ho == sg.Ho) { ho = 0; ++b; } }
     }
     // advance the cursor by one K-step
     m0 += BKM; wo0 += BKM;
     while (wo0 >= sg.Wo) { wo0 -= sg.Wo; if (++ho0 == sg.Ho) { ho0 = 0; ++b0; } }
   };
   auto sstore = [&](int buf) {
-    if (do_a) {
-      uint4 t[CE];
-      Transpose<T>::run(ra, t);
+    uint4 t[CE];
+    Transpose<T>::run(ra, t);
+    uint4* dst = (SPLIT && !do_a) ? bs : as;
 #pragma unroll
-      for (int e = 0; e < CE; ++e) { const int row = c * CE + e; as[buf * TLD + row * 8 + (g ^ swz(row))] = t[e]; }
-    }
-    if (do_b) {
-      uint4 t[CE];
-      Transpose<T>::run(rb, t);
+    for (int e = 0; e < CE; ++e) { const int row = c * CE + e; dst[buf * TLD + row * 8 + (g ^ swz(row))] = t[e]; }
+    if constexpr (!SPLIT) {
+      uint4 u[CE];
+      Transpose<T>::run(rb, u);
 #pragma unroll
-      for (int e = 0; e < CE; ++e) { const int row = c * CE + e; bs[buf * TLD + row * 8 + (g ^ swz(row))] = t[e]; }
+      for (int e = 0; e < CE; ++e) { const int row = c * CE + e; bs[buf * TLD + row * 8 + (g ^ swz(row))] = u[e]; }
     }
   };
 
@@ -210,7 +248,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
       if (kt + 1 < nsteps) sstore(cur ^ 1);
       __syncthreads();
     }
-    // ---- epilogue: D[row = n (4 per lane)][col = j (lane&15)] -> atomics into g[n][j] ----
+    // ---- epilogue: D[row = n (4 per lane)][col = j (lane&15)] -> this split's fp32 slab (plain coalesced stores;
+    //      cross-XCD float atomics from every split serialise at the memory side and were 10x the MFMA time) ----
+    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.K;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -220,40 +260,64 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int j = jt * 128 + wj0 + b * 16 + l15;
-          if (j < p.K) atomicAdd(p.dw + (long long)n * p.K + j, acc[a][b][r]);
+          if (j < p.K) slab[(long long)n * p.K + j] = acc[a][b][r];
         }
         if (want_bias && l15 == 0) atomicAdd(p.dbias + n, bsum[a][r]);
       }
     }
+  } else {
+    // empty split (cannot happen with the host's split table, but keep the slab defined)
+    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.K;
+    for (int i = tid; i < 128 * 128; i += 256) {
+      const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
+      if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
+    }
+  }
+}
+
+// dw[i] += sum_s slab[s][i]      (16-byte vectorised, fully coalesced)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int splits) {
+  const long long n4 = n >> 2;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 s = ((const f32x4*)dw)[i];
+    for (int k = 0; k < splits; ++k) s += ((const f32x4*)(slab + (long long)k * n))[i];
+    ((f32x4*)dw)[i] = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = (n4 << 2) + threadIdx.x;
+    float s = dw[i];
+    for (int k = 0; k < splits; ++k) s += slab[(long long)k * n + i];
+    dw[i] = s;
   }
 }
 
 }  // namespace
 
-extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stream) {
-  if (!p || !p->x || !p->dz || !p->dw) return EFFDET_EINVAL;
-  if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
+namespace {
+int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
+  if (!p || p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
   if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
   const int ce = p->dtype == EFFDET_F32 ? 4 : 8;
   if (p->Cin % ce || p->ldx % ce) return EFFDET_EUNSUPPORTED;
-  WgradK k;
-  k.x = p->x; k.dz = p->dz; k.dw = p->dw; k.dbias = p->dbias;
+  k.x = p->x; k.dz = p->dz; k.dw = p->dw; k.dbias = p->dbias; k.slab = nullptr;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
   k.ldx = p->ldx; k.lddz = p->lddz;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt; k.K = p->KH * p->KW * p->Cin;
   k.nseg = p->nseg;
   k.ntiles = (p->Cout + 127) / 128; k.jtiles = (k.K + 127) / 128;
+  k.vec_a = (p->lddz % ce == 0) && (((p->Cout + ce - 1) / ce * ce) <= p->lddz) ? 1 : 0;
   const int bkm = 8 * ce;
   long long Mtot = 0;
   for (int s = 0; s < p->nseg; ++s) Mtot += (long long)p->B * p->seg[s].Ho * p->seg[s].Wo;
-  // split the pixel range so that the launch has >= ~1024 blocks, but keep >= 8 K-steps per block
+  // split the pixel range so that the launch has ~512 blocks = ONE resident round (2 per CU x 256 CUs), but keep >= 8
+  // K-steps per block so the slab write + reduce stay a small fraction of the MFMA work
   const long long tiles = (long long)k.ntiles * k.jtiles;
-  long long want = (1024 + tiles - 1) / tiles;
+  long long want = (512 + tiles - 1) / tiles;
   long long mchunk = (Mtot + want - 1) / want;
   if (mchunk < 8LL * bkm) mchunk = 8LL * bkm;
   mchunk = (mchunk + bkm - 1) / bkm * bkm;
   k.mchunk = (int)mchunk;
-  int splits = 0;
+  splits = 0;
   for (int s = 0; s < p->nseg; ++s) {
     const effdet_seg_t& gsg = p->seg[s];
     WSeg& d = k.seg[s];
@@ -261,12 +325,40 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stre
     d.M = p->B * gsg.Ho * gsg.Wo;
     if (d.M <= 0) return EFFDET_EINVAL;
     if (gsg.in_off % ce || gsg.in_bstride % ce) return EFFDET_EUNSUPPORTED;
+    if (gsg.out_off % ce || gsg.out_bstride % ce) k.vec_a = 0;
     d.split_start = splits;
     d.in_off = gsg.in_off; d.in_bs = gsg.in_bstride; d.out_off = gsg.out_off; d.out_bs = gsg.out_bstride;
     splits += (int)((d.M + mchunk - 1) / mchunk);
   }
   for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].split_start = 0x7fffffff; }
   if (splits > 65535) return EFFDET_EUNSUPPORTED;
+  const long long es = p->dtype == EFFDET_F32 ? 4 : 2;
+  for (int s = 0; s < p->nseg; ++s) {
+    const effdet_seg_t& g = p->seg[s];
+    const long long ex = ((long long)(p->B - 1) * g.in_bstride + ((long long)(g.H - 1) * g.W + (g.W - 1)) * p->ldx + p->Cin) * es;
+    const long long ez = ((long long)(p->B - 1) * g.out_bstride + ((long long)(g.Ho - 1) * g.Wo + (g.Wo - 1)) * p->lddz + p->lddz) * es;
+    if (ex >= 0xFFFF0000LL || ez >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
+    k.seg[s].x_bytes = (unsigned)ex; k.seg[s].dz_bytes = (unsigned)ez;
+  }
+  return EFFDET_OK;
+}
+}  // namespace
+
+extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p) {
+  WgradK k; int splits = 0;
+  if (plan(p, k, splits) != EFFDET_OK) return -1;
+  return (long long)splits * p->Cout * k.K * (long long)sizeof(float);
+}
+
+extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
+                                   effdet_stream_t stream) {
+  if (!p || !p->x || !p->dz || !p->dw || !workspace) return EFFDET_EINVAL;
+  WgradK k; int splits = 0;
+  const int rc = plan(p, k, splits);
+  if (rc != EFFDET_OK) return rc;
+  const long long n = (long long)p->Cout * k.K;
+  if (workspace_bytes < (long long)splits * n * (long long)sizeof(float)) return EFFDET_EINVAL;
+  k.slab = (float*)workspace;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(k.ntiles, k.jtiles, splits);
@@ -277,6 +369,9 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stre
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, k);
   }
+  EFFDET_CHECK_LAUNCH();
+  long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -18,15 +18,19 @@ struct DwK {
   const void* x; const float* w; const float* scale; const float* shift;
   void* y; void* z; float* pool; const void* aux;
   int B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo;
+  unsigned x_bytes;  // byte extent of the tensor read through the SRD (x, or dz for the data gradient)
   int nch;        // channel chunks (C / CE, rounded up)
   int tx;         // chunk lanes per block (power of two <= 64)
   int ppt;        // pixels per thread
 };
 
 // ---------------------------------------------------------------- forward
-template <typename T>
+// K is a template parameter so the k*k taps are fully unrolled: all tap loads are bounds-checked SRD buffer loads
+// (halo taps pass EFFDET_OOB and read zeros), issued back to back with no per-tap branch / s_waitcnt.
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
   constexpr int CE = Elem<T>::CE;
+  constexpr unsigned ES = sizeof(T);
   const int tx = threadIdx.x & (p.tx - 1), ty = threadIdx.x / p.tx, TY = 256 / p.tx;
   const int chunk = blockIdx.y * p.tx + tx;
   const bool cok = chunk < p.nch;
@@ -35,6 +39,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
   const int pixb = TY * p.ppt;                       // pixels per block (within ONE image)
   const int tiles_per_img = (HoWo + pixb - 1) / pixb;
   const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
+  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
 
   float sc[CE], sh[CE], psum[CE];
 #pragma unroll
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
 #pragma unroll
     for (int e = 0; e < CE; ++e) if (c0 + e < p.C) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
   }
-  const T* xb = (const T*)p.x + (long long)b * p.H * p.W * p.C;
+  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES) + (unsigned)c0 * ES;
   for (int i = 0; i < p.ppt; ++i) {
     const int pix = tile * pixb + i * TY + ty;
     if (pix >= HoWo || !cok) continue;
@@ -52,15 +57,16 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
     float acc[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-    for (int kh = 0; kh < p.k; ++kh) {
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
       const int hi = hi0 + kh;
-      if (hi < 0 || hi >= p.H) continue;
-      for (int kw = 0; kw < p.k; ++kw) {
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
         const int wi = wi0 + kw;
-        if (wi < 0 || wi >= p.W) continue;
+        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
         float xv[CE], wv[CE];
-        Chunk<T>::unpack(*(const uint4*)(xb + ((long long)hi * p.W + wi) * p.C + c0), xv);
-        const float* wp = p.w + (long long)(kh * p.k + kw) * p.C + c0;
+        Chunk<T>::unpack(srd_load16(rx, ok ? img_off + (unsigned)((hi * p.W + wi) * p.C) * ES : EFFDET_OOB), xv);
+        const float* wp = p.w + (kh * K + kw) * p.C + c0;
 #pragma unroll
         for (int q = 0; q < CE; q += 4) { f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
 #pragma unroll
@@ -110,9 +116,10 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
 
 // ---------------------------------------------------------------- data gradient
 // dx[b,h,w,c] = sum_{kh,kw} dz[b,(h+pt-kh)/s,(w+pl-kw)/s,c] * w[kh,kw,c] * scale[c]   [* swish'(aux)]
-template <typename T>
+template <typename T, int K>
 __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwK p) {
   constexpr int CE = Elem<T>::CE;
+  constexpr unsigned ES = sizeof(T);
   const int tx = threadIdx.x & (p.tx - 1), ty = threadIdx.x / p.tx, TY = 256 / p.tx;
   const int chunk = blockIdx.y * p.tx + tx;
   if (chunk >= p.nch) return;
@@ -121,10 +128,11 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwK p) {
   const int pixb = TY * p.ppt;
   const int tiles_per_img = (HW + pixb - 1) / pixb;
   const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
+  const __amdgpu_buffer_rsrc_t rz = make_srd(p.x, p.x_bytes);       // p.x carries dz here
   float sc[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) sc[e] = p.scale ? p.scale[c0 + e] : 1.f;
-  const T* zb = (const T*)p.x + (long long)b * HoWo * p.C;     // p.x carries dz here
+  const unsigned img_off = (unsigned)((long long)b * HoWo * p.C * ES) + (unsigned)c0 * ES;
   for (int i = 0; i < p.ppt; ++i) {
     const int pix = tile * pixb + i * TY + ty;
     if (pix >= HW) continue;
@@ -132,19 +140,19 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwK p) {
     float acc[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-    for (int kh = 0; kh < p.k; ++kh) {
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
       const int hn = h + p.pad_t - kh;
-      if (hn < 0 || (hn % p.stride) != 0) continue;
-      const int ho = hn / p.stride;
-      if (ho >= p.Ho) continue;
-      for (int kw = 0; kw < p.k; ++kw) {
+      const int ho = p.stride == 2 ? (hn >> 1) : hn;
+      const bool hok = hn >= 0 && (p.stride == 1 || (hn & 1) == 0) && ho < p.Ho;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
         const int wn = w + p.pad_l - kw;
-        if (wn < 0 || (wn % p.stride) != 0) continue;
-        const int wo = wn / p.stride;
-        if (wo >= p.Wo) continue;
+        const int wo = p.stride == 2 ? (wn >> 1) : wn;
+        const bool ok = hok && wn >= 0 && (p.stride == 1 || (wn & 1) == 0) && wo < p.Wo;
         float dv[CE], wv[CE];
-        Chunk<T>::unpack(*(const uint4*)(zb + ((long long)ho * p.Wo + wo) * p.C + c0), dv);
-        const float* wp = p.w + (long long)(kh * p.k + kw) * p.C + c0;
+        Chunk<T>::unpack(srd_load16(rz, ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C) * ES : EFFDET_OOB), dv);
+        const float* wp = p.w + (kh * K + kw) * p.C + c0;
 #pragma unroll
         for (int q = 0; q < CE; q += 4) { f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
 #pragma unroll
@@ -179,7 +187,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
   f32x4 g[K * K], ds = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < K * K; ++t) g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const T* xb = (const T*)p.x + (long long)b * p.H * p.W * p.C;
+  // 8-byte (4-channel) bounds-checked SRD loads, all K*K taps in flight per pixel (no per-tap branch)
+  constexpr unsigned ES = sizeof(T);
+  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
+  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES) + (unsigned)c0 * ES;
   const T* zb = (const T*)p.aux + (long long)b * HoWo * p.C;   // p.aux carries dz here
   for (int i = 0; i < p.ppt; ++i) {
     const int pix = tile * pixb + i * TY + ty;
@@ -194,36 +205,53 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
 #pragma unroll
       for (int kw = 0; kw < K; ++kw) {
         const int wi = wi0 + kw;
-        if (hi >= 0 && hi < p.H && wi >= 0 && wi < p.W) {
-          const f32x4 xv = load4(xb + ((long long)hi * p.W + wi) * p.C + c0);
-          g[kh * K + kw] += d * xv;
-        }
+        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        g[kh * K + kw] += d * srd_load4<T>(rx, ok ? img_off + (unsigned)((hi * p.W + wi) * p.C) * ES : EFFDET_OOB);
       }
     }
   }
-  // reduce over the pixel lanes of the wave (same tx), then one atomic per (wave, tap, channel)
-  const int lane = threadIdx.x & 63;
-  auto red = [&](f32x4 v) {
+  // Block-level reduction (shuffles inside the wave, LDS across the 4 waves), then ONE plain 16-byte store per
+  // (block, tap, channel group) into this block's slab row; dw_wgrad_reduce_kernel sums the rows.  (The first
+  // version issued k*k*4 global atomics per wave onto only k*k*C addresses: ~4000 colliding atomics per address.)
+  __shared__ f32x4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wtx = p.tx < 64 ? p.tx : 64;
+  float* slab = (float*)p.y + (long long)blockIdx.x * (K * K + 1) * p.C;      // p.y carries the slab
+  auto flush = [&](f32x4 v, int row) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { float s = v[r]; for (int o = 32; o >= p.tx; o >>= 1) s += __shfl_xor(s, o, 64); v[r] = s; }
-    return v;
+    for (int r = 0; r < 4; ++r) { float sacc = v[r]; for (int o = 32; o >= p.tx; o >>= 1) sacc += __shfl_xor(sacc, o, 64); v[r] = sacc; }
+    __syncthreads();
+    if (lane < wtx) red[wave][lane] = v;
+    __syncthreads();
+    if (threadIdx.x < wtx) {
+      // tx == 64: each wave holds a different ty of the same 64 channel groups; tx < 64: every wave holds all tx
+      const f32x4 t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      const int cg = (blockIdx.y * p.tx + threadIdx.x) * 4;
+      if (cg < p.C) *(f32x4*)(slab + (long long)row * p.C + cg) = t;
+    }
   };
-  const bool writer = cok && (lane < p.tx || p.tx >= 64);
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) {
-    const f32x4 v = red(g[t]);
-    if (writer) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(p.pool + (long long)t * p.C + c0 + r, v[r]);   // p.pool carries g
-    }
+  for (int t = 0; t < K * K; ++t) flush(g[t], t);
+  flush(ds, K * K);
+}
+
+// out[row][c] = sum_blocks slab[block][row][c]   (rows = k*k taps + 1 dsum row)
+__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ g, float* __restrict__ dsum,
+                                       int nblocks, int rows, int C) {
+  const int n = rows * C;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float sacc = 0.f;
+    for (int b = 0; b < nblocks; ++b) sacc += slab[(long long)b * n + i];
+    const int row = i / C, c = i - row * C;
+    if (row < rows - 1) g[i] = sacc; else if (dsum) dsum[c] = sacc;
   }
-  if (p.z) {                                                                            // p.z carries dsum
-    const f32x4 v = red(ds);
-    if (writer) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd((float*)p.z + c0 + r, v[r]);
-    }
-  }
+}
+
+bool extent(DwK& k, long long elems, int dtype) {
+  const long long bytes = elems * (dtype == EFFDET_F32 ? 4 : 2);
+  if (bytes >= 0xFFFF0000LL) return false;
+  k.x_bytes = (unsigned)bytes;
+  return true;
 }
 
 int fill(DwK& k, int dtype, int B, int H, int W, int C, int kk, int stride, int pad_t, int pad_l, int Ho, int Wo,
@@ -255,8 +283,10 @@ extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* sca
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, ce, Ho * Wo, grid);
   if (rc) return rc;
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y; a.z = z; a.pool = pool;
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(dw_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dw_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EFFDET_F32) { if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<float, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_fwd_kernel<float, 5>), grid, dim3(256), 0, st, a); }
+  else { if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_fwd_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a); }
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -270,28 +300,45 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, ce, H * W, grid);
   if (rc) return rc;
   a.x = dz; a.w = w; a.scale = scale; a.aux = zprev; a.y = dx;
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(dw_dgrad_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(dw_dgrad_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (!extent(a, (long long)B * Ho * Wo * C, dtype)) return EFFDET_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EFFDET_F32) { if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<float, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_dgrad_kernel<float, 5>), grid, dim3(256), 0, st, a); }
+  else { if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_dgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a); }
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
-extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, float* dsum, int dtype, int B, int H,
-                                   int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                   effdet_stream_t stream) {
-  if (!x || !dz || !g) return EFFDET_EINVAL;
-  DwK a{}; dim3 grid;
+namespace {
+int wgrad_plan(DwK& a, dim3& grid, int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo) {
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, Ho * Wo, grid);
   if (rc) return rc;
-  // fewer, fatter blocks: every block ends in k*k*4 atomics per channel lane
-  {
-    const int TY = 256 / a.tx;
-    int ppt = 64;
-    while (ppt > 1 && (long long)B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)) * ((a.nch + a.tx - 1) / a.tx) < 512) ppt >>= 1;
-    a.ppt = ppt;
-    grid = dim3(B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)), (a.nch + a.tx - 1) / a.tx);
-  }
-  a.x = x; a.aux = dz; a.pool = g; a.z = dsum;
+  // fat blocks (every block ends in a slab row write + is one term of the reduce), but >= ~512 of them
+  const int TY = 256 / a.tx;
+  int ppt = 64;
+  while (ppt > 1 && (long long)B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)) * ((a.nch + a.tx - 1) / a.tx) < 512) ppt >>= 1;
+  a.ppt = ppt;
+  grid = dim3(B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)), (a.nch + a.tx - 1) / a.tx);
+  return EFFDET_OK;
+}
+}  // namespace
+
+extern "C" long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t,
+                                                          int pad_l, int Ho, int Wo) {
+  DwK a{}; dim3 grid;
+  if (wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo)) return -1;
+  return (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float);
+}
+
+extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, float* dsum, void* workspace,
+                                   long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
+                                   int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
+  if (!x || !dz || !g || !workspace) return EFFDET_EINVAL;
+  DwK a{}; dim3 grid;
+  int rc = wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo);
+  if (rc) return rc;
+  if (workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
+  a.x = x; a.aux = dz; a.y = workspace;
+  if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EFFDET_F32) {
     if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<float, 3>), grid, dim3(256), 0, st, a);
@@ -300,6 +347,10 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
     if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a);
   }
+  EFFDET_CHECK_LAUNCH();
+  const int rows = k * k + 1;
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, st, (const float*)workspace, g, dsum,
+                     (int)grid.x, rows, C);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

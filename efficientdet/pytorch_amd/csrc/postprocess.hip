@@ -43,10 +43,32 @@ __global__ void anchors_kernel(const AnchorK p) {
 }
 
 // ------------------------------------------------------------------ decode + clip + class max
-__global__ void decode_score_kernel(const float* __restrict__ anchors, const float* __restrict__ reg,
-                                    const float* __restrict__ cls, float* __restrict__ boxes, float* __restrict__ score,
-                                    int* __restrict__ label, long long A, int nc, float img_w, float img_h, long long total) {
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+// 64 anchors per 256-thread block: the 64 x nc probability tile is read with fully coalesced loads into LDS
+// (row stride nc+1 -> conflict-free), 4 lanes scan each anchor's row and combine with shuffles keeping the
+// FIRST maximum (torch.max tie order); lane 0 of each quad also decodes + clips the box.
+__global__ __launch_bounds__(256) void decode_score_kernel(const float* __restrict__ anchors, const float* __restrict__ reg,
+                                                           const float* __restrict__ cls, float* __restrict__ boxes,
+                                                           float* __restrict__ score, int* __restrict__ label, long long A,
+                                                           int nc, float img_w, float img_h, long long total) {
+  extern __shared__ float tile[];                 // [64][nc + 1]
+  const long long i0 = (long long)blockIdx.x * 64;
+  const int na = (int)min(64LL, total - i0);
+  const int ld = nc + 1;
+  const float* src = cls + i0 * nc;
+  for (int e = threadIdx.x; e < na * nc; e += 256) { const int r = e / nc, k = e - r * nc; tile[r * ld + k] = src[e]; }
+  __syncthreads();
+  const int r = threadIdx.x >> 2, q = threadIdx.x & 3;
+  float m = -1.0f; int arg = 0x7fffffff;
+  if (r < na) {
+    for (int k = q; k < nc; k += 4) { const float v = tile[r * ld + k]; if (v > m) { m = v; arg = k; } }
+  }
+#pragma unroll
+  for (int o = 1; o <= 2; o <<= 1) {
+    const float om = __shfl_xor(m, o, 64); const int oa = __shfl_xor(arg, o, 64);
+    if (om > m || (om == m && oa < arg)) { m = om; arg = oa; }
+  }
+  if (r < na && q == 0) {
+    const long long i = i0 + r;
     const long long a = i % A;
     const float4 an = ((const float4*)anchors)[a];
     const float4 d = ((const float4*)reg)[i];
@@ -59,9 +81,6 @@ __global__ void decode_score_kernel(const float* __restrict__ anchors, const flo
     b.x = fmaxf(pcx - 0.5f * pw, 0.f); b.y = fmaxf(pcy - 0.5f * ph, 0.f);
     b.z = fminf(pcx + 0.5f * pw, img_w); b.w = fminf(pcy + 0.5f * ph, img_h);
     ((float4*)boxes)[i] = b;
-    const float* c = cls + i * nc;
-    float m = c[0]; int arg = 0;
-    for (int k = 1; k < nc; ++k) { const float v = c[k]; if (v > m) { m = v; arg = k; } }
     score[i] = m; label[i] = arg;
   }
 }
@@ -84,10 +103,14 @@ __device__ __forceinline__ bool suppresses(const float4& a, float aa, const floa
   return inter / (aa + ab - inter) > thr;
 }
 
-__global__ void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals, int* nvalid,
-                                int* offsets, int* kept, unsigned* dead, long long A, int B) {
-  const long long total = A * B;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals,
+                                                       int* nvalid, int* offsets, int* kept, unsigned* dead, long long A, int B) {
+  // grid (x, B): one image per blockIdx.y, so the valid count is a ballot + one atomic per wave-leader block sum
+  const int b = blockIdx.y;
+  __shared__ int cnt[4];
+  int mine = 0;
+  for (long long a = blockIdx.x * 256LL + threadIdx.x; a < A; a += (long long)gridDim.x * 256) {
+    const long long i = (long long)b * A + a;
     const float s = score[i];
     unsigned k = 0xffffffffu;
     if (s > thr) {
@@ -95,13 +118,21 @@ __global__ void nms_keys_kernel(const float* __restrict__ score, float thr, unsi
       u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;     // ascending-orderable
       k = ~u;                                         // descending score
       if (k == 0xffffffffu) k = 0xfffffffeu;
-      atomicAdd(nvalid + i / A, 1);
+      ++mine;
     }
-    keys[i] = k; vals[i] = (unsigned)(i % A); dead[i] = 0u;
+    keys[i] = k; vals[i] = (unsigned)a; dead[i] = 0u;
   }
-  const long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (t <= B) offsets[t] = (int)(t * A);
-  if (t < B) kept[t] = 0;
+  mine = (int)wave_sum((float)mine);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (t) atomicAdd(nvalid + b, t);
+    if (blockIdx.x == 0) {
+      kept[b] = 0; offsets[b] = (int)(b * A);
+      if (b == B - 1) offsets[B] = (int)((long long)B * A);
+    }
+  }
 }
 
 __global__ void nms_gather_kernel(const float* __restrict__ boxes, const unsigned* __restrict__ idx, const int* __restrict__ nvalid,
@@ -328,7 +359,10 @@ extern "C" int effdet_decode_score(const float* anchors, const float* reg, const
                                    effdet_stream_t stream) {
   if (!anchors || !reg || !cls || !boxes || !score || !label || num_classes < 1) return EFFDET_EINVAL;
   const long long n = (long long)B * A;
-  hipLaunchKernelGGL(decode_score_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, anchors, reg, cls, boxes, score, label, A, num_classes, img_w, img_h, n);
+  const size_t lds = (size_t)64 * (num_classes + 1) * sizeof(float);
+  if (lds > 150 * 1024) return EFFDET_EUNSUPPORTED;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)decode_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(decode_score_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), lds, (hipStream_t)stream, anchors, reg, cls, boxes, score, label, A, num_classes, img_w, img_h, n);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -348,7 +382,8 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * A;
   if (hipMemsetAsync(w.nvalid, 0, (size_t)B * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-  hipLaunchKernelGGL(nms_keys_kernel, dim3(grid_for(n)), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B);
+  { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(nms_keys_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B); }
   EFFDET_CHECK_LAUNCH();
   size_t tb = w.temp_bytes;
   if (rocprim::segmented_radix_sort_pairs<rocprim::default_config>(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out,

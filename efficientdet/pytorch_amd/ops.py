@@ -12,6 +12,39 @@ from ._lib import (ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE
                    RES_RELU_MASK, RES_SWISH_GRAD)
 
 
+class LaunchProfile:
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's live roofline measurement).
+    Events are recorded on the SAME stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = []          # (kernel symbol, algorithmic flops, start event, end event, shape note)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, e0, e1, _ in self.records:
+            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+            d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
+PROFILE = None     # set to a LaunchProfile() to time every conv launch
+
+
+def _timed(name, flops, fn, note=''):
+    if PROFILE is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record(); r = fn(); e1.record()
+    PROFILE.records.append((name, flops, e0, e1, note))
+    return r
+
+
+def _igemm_symbol(dtype, cout):
+    bn = 128 if cout > 64 else 64 if cout > 32 else 32 if cout > 16 else 16
+    return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', bn)
+
+
 class Map:
     """An NHWC feature-map view: element (b,h,w,c) at  t.data_ptr() + (off + b*bstride + (h*W+w)*ld + c)*itemsize."""
     __slots__ = ('t', 'B', 'H', 'W', 'C', 'ld', 'bstride', 'off')
@@ -103,7 +136,10 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
     d.ldx, d.ldy = x0.ld, y0.ld
     d.act, d.res_mode = act, res_mode
     _segs(d, xs, ys, base_x, base_y, isx, isy)
-    L.check(L.lib().effdet_conv2d(C.byref(d), L.stream_ptr()), 'effdet_conv2d')
+    flops = 2.0 * KH * KW * Cin * Cout * sum(y.B * y.H * y.W for y in ys)
+    _timed(_igemm_symbol(x0.dtype, Cout), flops,
+           lambda: L.check(L.lib().effdet_conv2d(C.byref(d), L.stream_ptr()), 'effdet_conv2d'),
+           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
 
 def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0):
@@ -122,7 +158,15 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.lddz = x0.ld, z0.ld
     _segs(d, xs, dzs, base_x, base_z, isz, z0.t.element_size())
-    L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.stream_ptr()), 'effdet_conv2d_wgrad')
+    flops = 2.0 * KH * KW * Cin * Cout * sum(z.B * z.H * z.W for z in dzs)
+    nbytes = int(L.lib().effdet_conv2d_wgrad_workspace_bytes(C.byref(d)))
+    if nbytes < 0:
+        raise RuntimeError('effdet_conv2d_wgrad: unsupported geometry')
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x0.t.device)
+    _timed('conv_wgrad_kernel<%s>' % ('bf16' if x0.dtype == torch.bfloat16 else 'f32'), flops,
+           lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
+                           'effdet_conv2d_wgrad'),
+           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
 
 
 def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None):
@@ -200,10 +244,14 @@ def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
 
 
 def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
-    g = torch.zeros((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum
-    L.check(L.lib().effdet_dwconv_wgrad(L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.dtype_code(x.dtype),
-                                        x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W, L.stream_ptr()),
-            'effdet_dwconv_wgrad')
+    g = torch.empty((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum
+    geo = (L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W)
+    nbytes = int(L.lib().effdet_dwconv_wgrad_workspace_bytes(*geo))
+    if nbytes < 0:
+        raise RuntimeError('effdet_dwconv_wgrad: unsupported geometry')
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
+    L.check(L.lib().effdet_dwconv_wgrad(L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws),
+                                        C.c_longlong(nbytes), *geo, L.stream_ptr()), 'effdet_dwconv_wgrad')
     return g[:k * k], g[k * k]
 
 

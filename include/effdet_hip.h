@@ -67,7 +67,7 @@ typedef struct {
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
 
 /* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]
- * (fp32, packed [Cout][KH*KW][Cin], accumulated with atomics so levels / K-splits can add up),
+ * (fp32, packed [Cout][KH*KW][Cin]; split-K partial slabs + a reduce pass, so levels / K-splits add up),
  * and optionally dbias[n] += sum_m dz[m][n].  Replaces autograd of F.conv2d w.r.t. weight/bias.
  * Segment geometry: in_* addresses x, out_* addresses dz (Ho,Wo rows). */
 typedef struct {
@@ -78,7 +78,9 @@ typedef struct {
   int nseg;
   effdet_seg_t seg[EFFDET_MAX_SEG];
 } effdet_wgrad_t;
-int effdet_conv2d_wgrad(const effdet_wgrad_t* p, effdet_stream_t stream);
+/* workspace: effdet_conv2d_wgrad_workspace_bytes(p) bytes of scratch for the split-K partial slabs. */
+long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p);
+int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes, effdet_stream_t stream);
 
 /* OIHW fp32 master weight -> packed [Cout][KH*KW][Kpad] (mode 0, forward; channels >= Cin are
  * zero: the stem pads its 3 image channels to one 16-byte chunk) or the data-gradient operand
@@ -120,10 +122,13 @@ int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, con
 int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,
                         void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
-/* weight gradient g[tap][c] += sum dz*x (unscaled), dsum[c] += sum dz. fp32 atomics. */
-int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, int dtype, int B,
-                        int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                        effdet_stream_t stream);
+/* weight gradient g[tap][c] = sum dz*x (unscaled), dsum[c] = sum dz (both OVERWRITTEN).  Per-block partial
+ * slabs in `workspace` (effdet_dwconv_wgrad_workspace_bytes) + a reduce pass; no atomics. */
+long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t,
+                                              int pad_l, int Ho, int Wo);
+int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, void* workspace,
+                        long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
 /* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
  * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);
