@@ -1,0 +1,77 @@
+"""CPU tier: architecture arithmetic, state_dict layout (checkpoint ABI) and the no-CPU-fallback contract."""
+import pytest
+import torch
+
+from oracle import effdet_oracle as O
+
+
+@pytest.mark.parametrize('net', ['efficientdet-d%d' % i for i in range(8)])
+def test_backbone_plan_matches_oracle(net):
+    from efficientdet.pytorch_amd.config import MODEL_MAP, backbone_plan, EFFICIENTDET
+    stem_c, stem_pad, blocks, head_c, native = backbone_plan(MODEL_MAP[net])
+    ostem, oblocks, ohead, onative = O.backbone_blocks(net)
+    assert (stem_c, stem_pad, head_c, native) == (ostem['cout'], ostem['pad'], ohead, onative)
+    assert len(blocks) == len(oblocks)
+    for b, o in zip(blocks, oblocks):
+        assert (b.k, b.stride, b.expand, b.cin, b.cout, b.cexp, b.cse, b.pad, b.skip, b.stage_end) == \
+            (o['k'], o['s'], o['e'], o['cin'], o['cout'], o['cexp'], o['cse'], o['pad'], o['skip'], o['stage_end'])
+    assert EFFICIENTDET[net] == {**O.EFFICIENTDET[net], 'backbone': EFFICIENTDET[net]['backbone']}
+
+
+def test_d0_shapes_and_strides():
+    from efficientdet.pytorch_amd.config import backbone_plan, conv_out
+    _, pad, blocks, _, _ = backbone_plan('efficientnet-b0')
+    s = conv_out(512, 3, 2, pad)
+    sizes = []
+    for b in blocks:
+        s = conv_out(s, b.k, b.stride, b.pad)
+        if b.stage_end:
+            sizes.append((b.cout, s))
+    assert sizes == [(16, 256), (24, 128), (40, 64), (80, 32), (112, 16), (192, 8), (320, 4)]
+
+
+@pytest.mark.parametrize('net,nc', [('efficientdet-d0', 80), ('efficientdet-d2', 20), ('efficientdet-d4', 4)])
+def test_state_dict_layout_is_the_reference_layout(net, nc):
+    from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET
+    c = EFFICIENTDET[net]
+    m = EfficientDet(nc, network=net, W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'])
+    sd = O.make_state_dict(net, nc)          # key order / shapes verified against the real reference (make_golden.py)
+    got = m.state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    assert all(tuple(got[k].shape) == tuple(sd[k].shape) for k in sd)
+    m.load_state_dict(sd)
+    if net == 'efficientdet-d0':
+        assert len(sd) == 426 and sum(p.numel() for p in m.parameters()) == 11_505_854
+        assert sum(p.numel() for p in m.live_parameters()) == 11_505_854 - 1_693_160
+
+
+def test_constructor_surface_and_errors():
+    from efficientdet.pytorch_amd import EfficientDet, MODEL_MAP
+    import inspect
+    sig = inspect.signature(EfficientDet.__init__)
+    names = list(sig.parameters)[1:9]
+    assert names == ['num_classes', 'network', 'D_bifpn', 'W_bifpn', 'D_class', 'is_training', 'threshold', 'iou_threshold']
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d['network'], d['D_bifpn'], d['W_bifpn'], d['D_class'], d['is_training'], d['threshold'], d['iou_threshold']) == \
+        ('efficientdet-d0', 3, 88, 3, True, 0.01, 0.5)
+    assert set(MODEL_MAP) == {'efficientdet-d%d' % i for i in range(8)}
+    with pytest.raises(KeyError):
+        EfficientDet(3, network='efficientdet-d9')
+    m = EfficientDet(3, W_bifpn=64, D_bifpn=1)
+    for attr in ('backbone', 'neck', 'bbox_head', 'anchors', 'criterion', 'threshold', 'iou_threshold', 'is_training',
+                 'freeze_bn', 'extract_feat'):
+        assert hasattr(m, attr)
+    # re-init like models/efficientdet.py:47-53: BN gamma 1 / beta 0, conv ~ N(0, sqrt(2/(k*k*Cout)))
+    assert float(m.backbone._bn0.weight.min()) == 1.0 and float(m.backbone._bn0.bias.abs().max()) == 0.0
+    w = m.bbox_head.cls_convs[1].conv.weight
+    assert abs(float(w.std()) - (2.0 / (9 * 256)) ** 0.5) < 2e-3
+
+
+def test_refuses_cpu_tensors():
+    from efficientdet.pytorch_amd import EfficientDet
+    m = EfficientDet(3, W_bifpn=64, D_bifpn=1, is_training=False)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.zeros(1, 3, 128, 128))
+    m.is_training = True
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m([torch.zeros(1, 3, 128, 128), torch.zeros(1, 2, 5)])
