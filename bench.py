@@ -143,6 +143,8 @@ def main():
         step()
         summ = ops.PROFILE.summary(); ops.PROFILE = None
         peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
+        hbm = {k: v for k, v in summ.items() if not k.startswith('conv_')}       # byte-counted (HBM-bound) kernels
+        summ = {k: v for k, v in summ.items() if k.startswith('conv_')}          # flop-counted MFMA kernels
         dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
         name, d = dom
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
@@ -151,7 +153,9 @@ def main():
                            'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                            'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                            'all_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                               'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()}}
+                                               'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
+                           'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
+                                               'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)} for k, v in hbm.items()}}
     if world > 1:
         dist.barrier()
 

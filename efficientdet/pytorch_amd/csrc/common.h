@@ -113,6 +113,16 @@ __device__ __forceinline__ uint4 srd_load16(__amdgpu_buffer_rsrc_t r, unsigned b
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// Direct-to-LDS DMA of one 16-byte chunk per lane: `buffer_load_dwordx4 ... lds`.  The LDS destination is
+// wave-uniform `lds` + lane*16 (lane-linear, 1 KiB per wave instruction); the global side is the per-lane
+// bounds-checked SRD offset (EFFDET_OOB lanes write zeros).  Tracked by vmcnt; hipcc drains it before the next
+// __syncthreads().  Kept in a __device__ helper: used directly inside a __global__ template, hipcc's host pass
+// silently drops the kernel's stub (deferred target-feature diagnostic).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ void srd_dma16(__amdgpu_buffer_rsrc_t r, void* lds, unsigned byte_off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, (int)byte_off, 0, 0, 0);
+}
+
 // 4 consecutive elements (16 B fp32 / 8 B bf16) through an SRD -> 4 floats
 template <typename T> __device__ __forceinline__ f32x4 srd_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
 template <> __device__ __forceinline__ f32x4 srd_load4<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {

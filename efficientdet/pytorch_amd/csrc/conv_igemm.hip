@@ -15,8 +15,9 @@
 //     residual / activation-gradient masks).
 //   * bf16: v_mfma_f32_16x16x32_bf16 (8 k per lane); fp32: 4 x v_mfma_f32_16x16x4_f32 fed from the
 //     same 16-byte chunk (exact fp32, = fmaf chain) -- identical byte geometry for both dtypes.
-//   * software pipeline: global loads of K-step t+1 are issued before the MFMAs of step t and
-//     written to the other LDS buffer afterwards; one barrier per K-step.
+//   * staging is direct-to-LDS DMA (buffer_load_dwordx4 ... lds through a bounds-checked SRD): the DMA of
+//     K-step t+1 into the other LDS buffer flies under the MFMAs of step t; one barrier per K-step; no
+//     staging VGPRs and no ds_write (the VGPR->LDS store path was a co-bottleneck of the 128x128 tile).
 //   * im2col-free: per-thread (tap, channel-chunk) cursors advance incrementally, halo / tail
 //     lanes load zeros.  Several pyramid levels that share weights run as ONE grouped launch
 //     (segments), which keeps the tiny 8x8 / 4x4 levels from being launch-bound.
@@ -62,16 +63,22 @@ template <> struct Mma<float> {
   }
 };
 
-// BN: block tile width in n; WAVES_N: waves along n (WAVES_M = 4 / WAVES_N)
-template <typename T, int BN, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
+// BN: block tile width in n; WAVES_N: waves along n; NWAVES: waves per workgroup (WAVES_M = NWAVES / WAVES_N).
+// The 128x128 tile runs with 8 waves (wave tile 32x64): same 64 KiB of LDS, i.e. still 2 workgroups per CU, but
+// 4 waves per SIMD instead of 2 -- the kernel is latency-bound (PMC: 49 % of wave time in s_waitcnt/barrier at 2
+// waves/SIMD, 0 LDS bank conflicts, MFMA pipe 26 % busy), so thread-level parallelism is the lever.
+template <typename T, int BN, int WAVES_N, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
   constexpr int CE = Elem<T>::CE;
-  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int NTHREADS = NWAVES * 64;
+  constexpr int WAVES_M = NWAVES / WAVES_N;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MT = WTM / 16, NT = WTN / 16;
   constexpr int XLD = BM * 8;               // uint4 per X buffer
   constexpr int WLD = BN * 8;
-  constexpr int WROWS = (BN + 31) / 32;     // weight rows per thread per K-step
+  constexpr int RSTEP = NTHREADS / 8;       // tile rows covered by one DMA pass of the whole workgroup
+  constexpr int XROWS = BM / RSTEP;         // X pieces per thread per K-step (4 or 2)
+  constexpr int WROWS = (BN + RSTEP - 1) / RSTEP;     // weight pieces per thread per K-step
 
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* xs = smem;                // [2][BM*8]
@@ -92,16 +99,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   const int n_base = nt * BN;
   const int HoWo = sg.Ho * sg.Wo;
 
-  // ---- per-thread load bookkeeping: chunk column kc, rows tid/8 + 32*j ----
-  // All staging loads are bounds-checked SRD buffer loads with 32-bit BYTE offsets (common.h: srd_load16):
-  // halo / tail / K-padding lanes pass EFFDET_OOB and receive zeros from the hardware.
+  // ---- per-thread staging bookkeeping: LDS position (row tid/8 + 32*j, slot tid&7) ----
+  // Staging is direct-to-LDS DMA: `buffer_load_dwordx4 ... lds` through a bounds-checked SRD.  A wave's 64 lanes
+  // own 8 consecutive tile rows x 8 slots = 1 KiB that is lane-linear in LDS (what the DMA requires); the XOR
+  // swizzle therefore moves to the SOURCE: slot p of row r holds global chunk p ^ ((r>>1)&7), which for this
+  // thread mapping is the per-thread constant (tid&7) ^ ((tid>>4)&7).  Halo / tail / K-padding lanes pass
+  // EFFDET_OOB and the hardware writes zeros.  No staging VGPRs, no ds_write, no per-lane branches.
   constexpr unsigned ES = sizeof(T);
   const __amdgpu_buffer_rsrc_t rx = make_srd((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd(p.w, p.w_bytes);
-  const int kc = tid & 7, r0 = tid >> 3;
-  unsigned xoff[4]; int hi0[4], wi0[4];
+  const int kc = (tid & 7) ^ ((tid >> 4) & 7), r0 = tid >> 3;
+  const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * 8;     // first tile row of this wave's 1-KiB DMA piece
+  unsigned xoff[XROWS]; int hi0[XROWS], wi0[XROWS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m_base + r0 + 32 * j;
+  for (int j = 0; j < XROWS; ++j) {
+    const int m = m_base + r0 + RSTEP * j;
     if (m < sg.M) {
       const int b = m / HoWo, rem = m - b * HoWo;
       const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
@@ -112,43 +123,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   unsigned woff[WROWS]; bool wok[WROWS];
 #pragma unroll
   for (int j = 0; j < WROWS; ++j) {
-    const int r = r0 + 32 * j, n = n_base + r;
+    const int r = r0 + RSTEP * j, n = n_base + r;
     wok[j] = (r < BN) && (n < p.Cout);
     woff[j] = (unsigned)((long long)(wok[j] ? n : 0) * p.Kc * 16);
   }
-  // K cursor of this thread's chunk column: chunk index kq = tap*cpt + cc
+  // K cursor of this thread's source chunk: chunk index kq = tap*cpt + cc
   int kq = kc, tap = 0, cc = kc;
   while (cc >= p.cpt) { cc -= p.cpt; ++tap; }
   int kh = tap / p.KW, kw = tap - kh * p.KW;
 
-  uint4 xr[4], wr[WROWS];
-  auto gload = [&]() {
+  auto stage = [&](int buf) {
     const bool kok = kq < p.Kc;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < XROWS; ++j) {
       const int hi = hi0[j] + kh, wi = wi0[j] + kw;
       const bool ok = kok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
       const unsigned off = xoff[j] + (unsigned)((hi * sg.W + wi) * p.ldx + cc * CE) * ES;
-      xr[j] = srd_load16(rx, ok ? off : EFFDET_OOB);
-    }
-#pragma unroll
-    for (int j = 0; j < WROWS; ++j)
-      wr[j] = srd_load16(rw, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
-    // advance the cursor by one K-step (8 chunks)
-    kq += 8; cc += 8;
-    while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = r0 + 32 * j;
-      xs[buf * XLD + r * 8 + (kc ^ ((r >> 1) & 7))] = xr[j];
+      srd_dma16(rx, (void*)(xs + buf * XLD + (wrow0 + RSTEP * j) * 8), ok ? off : EFFDET_OOB);
     }
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
-      const int r = r0 + 32 * j;
-      if (r < BN) ws[buf * WLD + r * 8 + (kc ^ ((r >> 1) & 7))] = wr[j];
+      if (wrow0 + RSTEP * j < BN)     // wave-uniform: the whole 8-row piece is inside the weight tile
+        srd_dma16(rw, (void*)(ws + buf * WLD + (wrow0 + RSTEP * j) * 8), (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     }
+    // advance the cursor by one K-step (8 chunks)
+    kq += 8; cc += 8;
+    while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
   };
 
   f32x4 acc[NT][MT];
@@ -158,12 +158,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
     for (int b = 0; b < MT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.Kc + 7) >> 3;
-  gload(); sstore(0);
-  __syncthreads();
+  stage(0);
+  __syncthreads();                       // (the compiler drains the DMA with vmcnt(0) ahead of the barrier)
   const int l15 = lane & 15, lq = lane >> 4, lsw = l15 >> 1;  // swizzle term (row>>1)&7 for row%16 = l15
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) gload();
+    if (kt + 1 < nk) stage(cur ^ 1);     // DMA of the next K-step flies under this step's MFMAs
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint4 wf[NT], xf[MT];
@@ -177,7 +177,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
     }
-    if (kt + 1 < nk) sstore(cur ^ 1);
     __syncthreads();
   }
 
@@ -236,16 +235,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvK p) {
   }
 }
 
-template <typename T, int BN, int WAVES_N>
+template <typename T, int BN, int WAVES_N, int NWAVES>
 int launch(const ConvK& k, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);
   const int grid = k.mtiles * k.ntiles;
   static bool attr_set = false;  // idempotent; benign race
   if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, WAVES_N>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, WAVES_N, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N>), dim3(grid), dim3(256), lds, st, k);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -256,10 +255,10 @@ int dispatch(ConvK& k, hipStream_t st) {
   if (k.Cout > 64) bn = 128; else if (k.Cout > 32) bn = 64; else if (k.Cout > 16) bn = 32; else bn = 16;
   k.ntiles = (k.Cout + bn - 1) / bn;
   switch (bn) {
-    case 128: return launch<T, 128, 2>(k, st);
-    case 64: return launch<T, 64, 1>(k, st);
-    case 32: return launch<T, 32, 1>(k, st);
-    default: return launch<T, 16, 1>(k, st);
+    case 128: return launch<T, 128, 2, 8>(k, st);
+    case 64: return launch<T, 64, 1, 4>(k, st);
+    case 32: return launch<T, 32, 1, 4>(k, st);
+    default: return launch<T, 16, 1, 4>(k, st);
   }
 }
 

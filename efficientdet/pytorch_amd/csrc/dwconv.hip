@@ -235,15 +235,29 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
   flush(ds, K * K);
 }
 
-// out[row][c] = sum_blocks slab[block][row][c]   (rows = k*k taps + 1 dsum row)
-__global__ void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ g, float* __restrict__ dsum,
-                                       int nblocks, int rows, int C) {
+// out[row][c] = sum_blocks slab[block][row][c]   (rows = k*k taps + 1 dsum row).
+// 256 threads = 64 consecutive elements x 4 block-slices; each thread strides its slice (4 loads in flight),
+// the 4 slices are combined through LDS.
+__global__ __launch_bounds__(256) void dw_wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ g,
+                                                              float* __restrict__ dsum, int nblocks, int rows, int C) {
+  __shared__ float part[4][64];
   const int n = rows * C;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float sacc = 0.f;
-    for (int b = 0; b < nblocks; ++b) sacc += slab[(long long)b * n + i];
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int b = q;
+    for (; b + 12 < nblocks; b += 16) {
+      s0 += slab[(long long)b * n + i]; s1 += slab[(long long)(b + 4) * n + i];
+      s2 += slab[(long long)(b + 8) * n + i]; s3 += slab[(long long)(b + 12) * n + i];
+    }
+    for (; b < nblocks; b += 4) s0 += slab[(long long)b * n + i];
+  }
+  part[q][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (q == 0 && i < n) {
+    const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
     const int row = i / C, c = i - row * C;
-    if (row < rows - 1) g[i] = sacc; else if (dsum) dsum[c] = sacc;
+    if (row < rows - 1) g[i] = t; else if (dsum) dsum[c] = t;
   }
 }
 
@@ -349,7 +363,7 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
   }
   EFFDET_CHECK_LAUNCH();
   const int rows = k * k + 1;
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 255) / 256), dim3(256), 0, st, (const float*)workspace, g, dsum,
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum,
                      (int)grid.x, rows, C);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;

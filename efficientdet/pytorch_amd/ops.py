@@ -229,17 +229,21 @@ def dw_unpack_wgrad(g_kkc, scale, w_c1kk, wsum=None):
 def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None):
     y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device)
     z = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_z else None
-    L.check(L.lib().effdet_dwconv_fwd(L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t),
-                                      L.ptr(z.t if z else None), L.ptr(pool), L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k,
-                                      stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd')
+    nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (2 if save_z else 1))
+    _timed('dw_fwd_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_fwd(
+        L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t), L.ptr(z.t if z else None), L.ptr(pool),
+        L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd'),
+        'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return y, z
 
 
 def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
     dx = Map.new(dz.B, H, W, dz.C, dz.dtype, dz.t.device)
-    L.check(L.lib().effdet_dwconv_dgrad(L.ptr(dz.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(zprev.tensor() if zprev else None),
-                                        L.ptr(dx.t), L.dtype_code(dz.dtype), dz.B, H, W, dz.C, k, stride, pad_t, pad_l,
-                                        dz.H, dz.W, L.stream_ptr()), 'effdet_dwconv_dgrad')
+    nbytes = dz.t.element_size() * dz.B * dz.C * (dz.H * dz.W + H * W * (2 if zprev else 1))
+    _timed('dw_dgrad_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_dgrad(
+        L.ptr(dz.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(zprev.tensor() if zprev else None), L.ptr(dx.t),
+        L.dtype_code(dz.dtype), dz.B, H, W, dz.C, k, stride, pad_t, pad_l, dz.H, dz.W, L.stream_ptr()), 'effdet_dwconv_dgrad'),
+        'BYTES k%d s%d C%d %dx%d' % (k, stride, dz.C, H, W))
     return dx
 
 
@@ -250,8 +254,10 @@ def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
     if nbytes < 0:
         raise RuntimeError('effdet_dwconv_wgrad: unsupported geometry')
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
-    L.check(L.lib().effdet_dwconv_wgrad(L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws),
-                                        C.c_longlong(nbytes), *geo, L.stream_ptr()), 'effdet_dwconv_wgrad')
+    traffic = x.t.element_size() * x.B * x.C * (x.H * x.W + dz.H * dz.W)
+    _timed('dw_wgrad_kernel', traffic, lambda: L.check(L.lib().effdet_dwconv_wgrad(
+        L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws), C.c_longlong(nbytes), *geo, L.stream_ptr()),
+        'effdet_dwconv_wgrad'), 'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return g[:k * k], g[k * k]
 
 

@@ -26,5 +26,6 @@ print('total conv ms %.2f over %d launches' % (tot, len(rec)))
 agg = {}
 for n, f, ms, note in rec:
     k = (n, note); a = agg.setdefault(k, [0, 0.0, 0.0]); a[0] += 1; a[1] += ms; a[2] += f
-for (n, note), (c, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:32]:
-    print('%-28s %-34s x%-2d %7.3f ms  %6.1f TF/s' % (n, note, c, ms, f / ms / 1e9))
+for (n, note), (c, ms, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOPN', '32'))]:
+    unit = 'GB/s' if note.startswith('BYTES') else 'TF/s'
+    print('%-28s %-34s x%-2d %7.3f ms  %7.1f %s' % (n, note, c, ms, f / ms / (1e6 if unit == 'GB/s' else 1e9), unit))
