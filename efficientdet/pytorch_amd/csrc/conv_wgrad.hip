@@ -33,6 +33,7 @@ struct WgradK {
   const void* x; const void* dz; float* dw; float* dbias; float* slab;
   int Cin, Cout, KW, stride, pad_t, pad_l;
   int ldx, lddz;
+  int B;
   int Kc, cpt;      // j extent in 16-byte chunks, chunks per tap
   int K;            // taps*Cin
   int mchunk;       // pixels per split (multiple of the K-step)
@@ -69,8 +70,9 @@ template <> struct Transpose<float> {
     out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
   }
 };
-__device__ __forceinline__ uint32_t lo16(uint32_t a, uint32_t b) { return (a & 0xffffu) | (b << 16); }
-__device__ __forceinline__ uint32_t hi16(uint32_t a, uint32_t b) { return (a >> 16) | (b & 0xffff0000u); }
+// one v_perm_b32 each: result bytes picked from {b (bytes 7..4), a (bytes 3..0)}
+__device__ __forceinline__ uint32_t lo16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x05040100u); }   // a.lo | b.lo << 16
+__device__ __forceinline__ uint32_t hi16(uint32_t a, uint32_t b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }   // a.hi | b.hi << 16
 template <> struct Transpose<bf16_t> {
   static __device__ __forceinline__ void run(const uint4 (&in)[8], uint4 (&out)[8]) {
     // element e of pixel-row r lives in dword e/2 (x,y,z,w), half e%2
@@ -97,13 +99,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn0 = (wave >> 1) * 64, wj0 = (wave & 1) * 64;
-  const int nt = blockIdx.x, jt = blockIdx.y;
+  // 1-D grid with the bijective XCD remap: logical order is (n-tile fastest, j-tile, split slowest), so the ~N/8
+  // consecutive logical blocks that land on one XCD share one pixel range -> its dz / x tiles are fetched into
+  // that XCD's private L2 once instead of into all eight.
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = logical % p.ntiles, jt = (logical / p.ntiles) % p.jtiles, split = logical / (p.ntiles * p.jtiles);
   int si = 0;
 #pragma unroll
   for (int s = 1; s < EFFDET_MAX_SEG; ++s)
-    if (s < p.nseg && (int)blockIdx.z >= p.seg[s].split_start) si = s;
+    if (s < p.nseg && split >= p.seg[s].split_start) si = s;
   const WSeg sg = p.seg[si];
-  const int m_begin = ((int)blockIdx.z - sg.split_start) * p.mchunk;
+  const int m_begin = (split - sg.split_start) * p.mchunk;
   const int m_end = min(sg.M, m_begin + p.mchunk);
   const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
 
@@ -161,17 +167,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   };
   auto gload = [&]() {
     if (rowfast && p.vec_a) {
-      const unsigned abase = a_off0 + (unsigned)b0 * a_bs + (unsigned)(ho0 * sg.Wo + wo0) * a_ld;
+      // No per-pixel tail test here: a pixel index >= M decodes to image index >= B, whose offset lies beyond
+      // this segment's SRD extent, so the hardware zero-fills it (the host sizes the extents exactly).
+      const unsigned abase = a_in ? a_off0 + (unsigned)b0 * a_bs + (unsigned)(ho0 * sg.Wo + wo0) * a_ld : EFFDET_OOB;
       const int hi = ho0 * p.stride - p.pad_t + kh, wi0 = wo0 * p.stride - p.pad_l + kw;
-      const bool rowok = jok && hi >= 0 && hi < sg.H;
+      const bool rowok = jok && hi >= 0 && hi < sg.H && b0 < p.B;
       const unsigned bbase = b_off0 + (unsigned)b0 * b_bs + (unsigned)(hi * sg.W + wi0) * b_ld;
       const unsigned bstep = (unsigned)p.stride * b_ld;
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
-        const bool mok = (m0 + e) < m_end;
         const int wi = wi0 + e * p.stride;
-        const unsigned oa = (mok && a_in) ? abase + (unsigned)e * a_ld : EFFDET_OOB;
-        const unsigned ob = (mok && rowok && wi >= 0 && wi < sg.W) ? bbase + (unsigned)e * bstep : EFFDET_OOB;
+        const unsigned oa = a_in ? abase + (unsigned)e * a_ld : EFFDET_OOB;
+        const unsigned ob = (rowok && wi >= 0 && wi < sg.W) ? bbase + (unsigned)e * bstep : EFFDET_OOB;
         if constexpr (SPLIT) { if (do_a) ra[e] = srd_load16(rz, oa); else ra[e] = srd_load16(rx, ob); }
         else { ra[e] = srd_load16(rz, oa); rb[e] = srd_load16(rx, ob); }
       }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     }
     // ---- epilogue: D[row = n (4 per lane)][col = j (lane&15)] -> this split's fp32 slab (plain coalesced stores;
     //      cross-XCD float atomics from every split serialise at the memory side and were 10x the MFMA time) ----
-    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.K;
+    float* slab = p.slab + (long long)split * p.Cout * p.K;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
 #pragma unroll
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
     }
   } else {
     // empty split (cannot happen with the host's split table, but keep the slab defined)
-    float* slab = p.slab + (long long)blockIdx.z * p.Cout * p.K;
+    float* slab = p.slab + (long long)split * p.Cout * p.K;
     for (int i = tid; i < 128 * 128; i += 256) {
       const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
       if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
@@ -301,7 +308,7 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
   if (p->Cin % ce || p->ldx % ce) return EFFDET_EUNSUPPORTED;
   k.x = p->x; k.dz = p->dz; k.dw = p->dw; k.dbias = p->dbias; k.slab = nullptr;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
-  k.ldx = p->ldx; k.lddz = p->lddz;
+  k.ldx = p->ldx; k.lddz = p->lddz; k.B = p->B;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt; k.K = p->KH * p->KW * p->Cin;
   k.nseg = p->nseg;
   k.ntiles = (p->Cout + 127) / 128; k.jtiles = (k.K + 127) / 128;
@@ -309,13 +316,35 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
   const int bkm = 8 * ce;
   long long Mtot = 0;
   for (int s = 0; s < p->nseg; ++s) Mtot += (long long)p->B * p->seg[s].Ho * p->seg[s].Wo;
-  // split the pixel range so that the launch has ~512 blocks = ONE resident round (2 per CU x 256 CUs), but keep >= 8
-  // K-steps per block so the slab write + reduce stay a small fraction of the MFMA work
+  // Split-K planning.  512 workgroups are resident at once (2 per CU x 256 CUs, LDS- and register-limited) and all
+  // blocks of a launch do (almost) equal work, so pick the split count s that maximises the slot efficiency
+  // tiles*s / (ceil(tiles*s / 512) * 512): 36 tiles -> s = 14 (504 blocks, one round); 108 tiles -> s = 14 (1512
+  // blocks, 3 rounds at 98 %).  Rounding the count up blindly (540 blocks = a second, empty round) or collapsing it
+  // (108 long blocks on 256 CUs) each cost ~2x.  Keep >= 8 K-steps per block; prefer fewer splits on near-ties
+  // (slab traffic).  Small pyramid levels add a few short blocks of their own, which is harmless.
   const long long tiles = (long long)k.ntiles * k.jtiles;
-  long long want = (512 + tiles - 1) / tiles;
-  long long mchunk = (Mtot + want - 1) / want;
-  if (mchunk < 8LL * bkm) mchunk = 8LL * bkm;
-  mchunk = (mchunk + bkm - 1) / bkm * bkm;
+  auto chunk_for = [&](long long sc) {
+    long long mc = (Mtot + sc - 1) / sc;
+    if (mc < 8LL * bkm) mc = 8LL * bkm;
+    return (mc + bkm - 1) / bkm * bkm;
+  };
+  auto blocks_for = [&](long long mc) {      // every pyramid level is split on its own (each rounds up)
+    long long sp = 0;
+    for (int s = 0; s < p->nseg; ++s) sp += ((long long)p->B * p->seg[s].Ho * p->seg[s].Wo + mc - 1) / mc;
+    return sp * tiles;
+  };
+  long long best_mc = chunk_for(1); double best_eff = 0.0;
+  const long long smax = 1024 / tiles > 32 ? 1024 / tiles : 32;
+  long long prev_mc = -1;
+  for (long long sc = 1; sc <= smax; ++sc) {
+    const long long mc = chunk_for(sc);
+    if (mc == prev_mc) continue;
+    prev_mc = mc;
+    const long long nb = blocks_for(mc), rounds = (nb + 511) / 512;
+    const double eff = (double)nb / (double)(rounds * 512);
+    if (eff > best_eff + 0.02) { best_eff = eff; best_mc = mc; }
+  }
+  long long mchunk = best_mc;
   k.mchunk = (int)mchunk;
   splits = 0;
   for (int s = 0; s < p->nseg; ++s) {
@@ -361,7 +390,7 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   k.slab = (float*)workspace;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(k.ntiles, k.jtiles, splits);
+  dim3 grid((unsigned)(k.ntiles * k.jtiles * splits));
   if (p->dtype == EFFDET_F32) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, k);
