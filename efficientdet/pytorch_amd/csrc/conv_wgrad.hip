@@ -392,10 +392,12 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)(k.ntiles * k.jtiles * splits));
   if (p->dtype == EFFDET_F32) {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
     hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, k);
   } else {
-    (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
     hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, k);
   }
   EFFDET_CHECK_LAUNCH();

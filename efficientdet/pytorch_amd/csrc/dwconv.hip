@@ -172,6 +172,233 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwK p) {
   }
 }
 
+// ---------------------------------------------------------------- LDS-tiled forward / data gradient
+// One workgroup = one image x one TH x TW output tile x one slab of 8 channel chunks (64 bf16 / 32 fp32 channels).
+// The halo'd source tile is staged ONCE by direct-to-LDS DMA (srd_dma16: 8 pixels x 8 chunks = 1 KiB per wave
+// instruction, lane-linear; out-of-image / out-of-slab lanes pass EFFDET_OOB = the zero padding of TF-"same"),
+// then every tap is a ds_read_b128.  This replaces k*k L1/TA round trips per output by one HBM/L2 read per input
+// element (x ~1.3-1.6 halo overhead).  Stride 2: the LDS pixel order de-interleaves even / odd columns so that the
+// 8 pixels a wave reads together are contiguous (no bank conflicts); the stride-2 data gradient walks the four
+// (row, column) parity classes one after the other so that the valid-tap set is uniform across the wave.
+template <int K, int S> struct DwTile {
+  static constexpr int TH = (S == 1) ? 16 : 8, TW = 8;                        // forward OUTPUT tile (4 / 2 outputs per thread)
+  static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;         // staged input tile
+  static constexpr int IWH = (IW + 1) / 2, IWP = (S == 1) ? IW : 2 * IWH;    // padded row length of the LDS image
+  static constexpr int NPIX = IH * IWP, NPIECE = (NPIX + 7) / 8;
+  static __device__ __forceinline__ int slot(int ih, int iw) {
+    return (S == 1) ? ih * IWP + iw : ih * IWP + (iw & 1) * IWH + (iw >> 1);
+  }
+};
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
+  typedef DwTile<K, S> TL;
+  constexpr int CE = Elem<T>::CE;
+  constexpr unsigned ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];
+  uint4* xt = sm;                                       // [NPIECE*8][8] chunks
+  float* wt = (float*)(sm + TL::NPIECE * 64);           // [K*K][8*CE] weights of this slab
+  __shared__ float red[4][8 * 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int oh0 = (tr / tiles_x) * TL::TH, ow0 = (tr % tiles_x) * TL::TW;
+  const int chunk0 = blockIdx.y * 8;                    // first channel chunk of the slab
+  const int hi_org = oh0 * S - p.pad_t, wi_org = ow0 * S - p.pad_l;
+  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
+  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
+  // ---- stage the input tile ----
+  {
+    const int pl = lane >> 3, cq = lane & 7;
+    const bool cok = chunk0 + cq < p.nch;
+    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
+      const int q = piece * 8 + pl;                     // LDS pixel slot
+      int ih = q / TL::IWP, r = q - ih * TL::IWP, iw;
+      if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
+      const int hi = hi_org + ih, wi = wi_org + iw;
+      const bool ok = cok && q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      srd_dma16(rx, (void*)(xt + piece * 64), ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
+    }
+    for (int i = tid; i < K * K * 8 * CE; i += 256) {
+      const int t = i / (8 * CE), c = chunk0 * CE + (i - t * 8 * CE);
+      wt[i] = c < p.C ? p.w[t * p.C + c] : 0.f;
+    }
+  }
+  __syncthreads();
+  // ---- compute: thread = (chunk cq, pixel slot ps); NOUT outputs per thread ----
+  constexpr int NOUT = TL::TH * TL::TW / 32;
+  const int cq = tid & 7, ps = tid >> 3;
+  const int c0 = (chunk0 + cq) * CE;
+  const bool cok = chunk0 + cq < p.nch;
+  float acc[NOUT][CE];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+  for (int kh = 0; kh < K; ++kh) {           // NOT unrolled: the full K*K*NOUT unroll spilled to scratch (occupancy 1)
+#pragma unroll
+    for (int kw = 0; kw < K; ++kw) {
+      float wv[CE];
+      const float* wp = wt + (kh * K + kw) * 8 * CE + cq * CE;
+#pragma unroll
+      for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        const int op = ps + 32 * o, oh = op / TL::TW, ow = op - oh * TL::TW;
+        float xv[CE];
+        Chunk<T>::unpack(xt[TL::slot(oh * S + kh, ow * S + kw) * 8 + cq], xv);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(xv[e], wv[e], acc[o][e]);
+      }
+    }
+  }
+  float sc[CE], sh[CE], psum[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; psum[e] = 0.f; }
+  if (cok) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
+  }
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    const int op = ps + 32 * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
+    if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
+    const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
+    float zv[CE], yv[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { zv[e] = acc[o][e] * sc[e] + sh[e]; yv[e] = swishf_(zv[e]); }
+    if (p.z) *(uint4*)((T*)p.z + off) = Chunk<T>::pack(zv);
+    const uint4 packed = Chunk<T>::pack(yv);
+    *(uint4*)((T*)p.y + off) = packed;
+    float yr[CE];
+    Chunk<T>::unpack(packed, yr);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) psum[e] += yr[e];
+  }
+  if (p.pool) {
+    // sum over the 32 pixel slots: lanes with equal (lane & 7) inside the wave, then the 4 waves through LDS
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { float v = psum[e]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); psum[e] = v; }
+    if (lane < 8) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) red[wave][lane * 8 + e] = psum[e];
+    }
+    __syncthreads();
+    if (tid < 8 * CE) {
+      const int l = tid / CE, e = tid - l * CE;
+      const float v = red[0][l * 8 + e] + red[1][l * 8 + e] + red[2][l * 8 + e] + red[3][l * 8 + e];
+      const int cch = (chunk0 + l) * CE + e;
+      if (cch < p.C) atomicAdd(p.pool + (long long)b * p.C + cch, v);
+    }
+  }
+}
+
+// Data gradient.  Output tile = 16 x 16 pixels of dx (input resolution); staged tile = the dz pixels they touch.
+template <int K, int S> struct DgTile {
+  static constexpr int TH = 16, TW = (S == 1) ? 8 : 16;                       // 4 / 8 (= 4 classes x 2) outputs per thread
+  static constexpr int IH = (S == 1) ? TH + K - 1 : TH / 2 + (K + 1) / 2, IW = (S == 1) ? TW + K - 1 : TW / 2 + (K + 1) / 2;
+  static constexpr int NPIX = IH * IW, NPIECE = (NPIX + 7) / 8;
+};
+__device__ __forceinline__ int floordiv2(int v) { return v >> 1; }       // arithmetic shift = floor for negatives
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
+  typedef DgTile<K, S> TL;
+  constexpr int CE = Elem<T>::CE;
+  constexpr unsigned ES = sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];
+  uint4* zt = sm;
+  float* wt = (float*)(sm + TL::NPIECE * 64);           // [K*K][8*CE], scale folded in
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.W + TL::TW - 1) / TL::TW, tiles_y = (p.H + TL::TH - 1) / TL::TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
+  const int h0 = (tr / tiles_x) * TL::TH, w0 = (tr % tiles_x) * TL::TW;
+  const int chunk0 = blockIdx.y * 8;
+  // first dz row / column the tile can touch
+  const int ro0 = (S == 1) ? h0 + p.pad_t - (K - 1) : floordiv2(h0 + p.pad_t - (K - 1) + 1);
+  const int co0 = (S == 1) ? w0 + p.pad_l - (K - 1) : floordiv2(w0 + p.pad_l - (K - 1) + 1);
+  const __amdgpu_buffer_rsrc_t rz = make_srd(p.x, p.x_bytes);          // p.x carries dz
+  const unsigned img_off = (unsigned)((long long)b * p.Ho * p.Wo * p.C * ES);
+  {
+    const int pl = lane >> 3, cq = lane & 7;
+    const bool cok = chunk0 + cq < p.nch;
+    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
+      const int q = piece * 8 + pl;
+      const int ih = q / TL::IW, iw = q - ih * TL::IW;
+      const int ho = ro0 + ih, wo = co0 + iw;
+      const bool ok = cok && q < TL::NPIX && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
+      srd_dma16(rz, (void*)(zt + piece * 64), ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
+    }
+    for (int i = tid; i < K * K * 8 * CE; i += 256) {
+      const int t = i / (8 * CE), c = chunk0 * CE + (i - t * 8 * CE);
+      wt[i] = c < p.C ? p.w[t * p.C + c] * (p.scale ? p.scale[c] : 1.f) : 0.f;
+    }
+  }
+  __syncthreads();
+  const int cq = tid & 7, ps = tid >> 3;
+  const int c0 = (chunk0 + cq) * CE;
+  const bool cok = chunk0 + cq < p.nch;
+  const int HW = p.H * p.W;
+  // S == 1: 8 outputs per thread, all taps valid.  S == 2: 4 parity classes x 2 outputs per thread; in class (ph, pw)
+  // only taps with (h + pad_t - kh) even, i.e. kh = (h + pad_t) & 1, +2, ... are valid (same for columns).
+  constexpr int NCLS = (S == 1) ? 1 : 4;
+  constexpr int NOUT = TL::TH * TL::TW / 32 / NCLS;
+#pragma unroll
+  for (int cls = 0; cls < NCLS; ++cls) {
+    const int ph = cls >> 1, pw = cls & 1;
+    float acc[NOUT][CE];
+    int lh[NOUT], lw[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const int op = ps + 32 * o;
+      if (S == 1) { lh[o] = op / TL::TW; lw[o] = op - lh[o] * TL::TW; }
+      else { const int hh = op / (TL::TW / 2), ww = op - hh * (TL::TW / 2); lh[o] = 2 * hh + ph; lw[o] = 2 * ww + pw; }   // TW = 16 here
+#pragma unroll
+      for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+    }
+    // tile origin h0, w0 are multiples of 16, so the parity of (h + pad) is that of (lh + pad)
+    const int kh0 = (S == 1) ? 0 : ((ph + p.pad_t) & 1), kw0 = (S == 1) ? 0 : ((pw + p.pad_l) & 1);
+#pragma unroll 1
+    for (int a = 0; a < (S == 1 ? K : (K + 1) / 2); ++a) {
+      const int kh = (S == 1) ? a : kh0 + 2 * a;
+      if (kh >= K) continue;
+#pragma unroll
+      for (int c = 0; c < (S == 1 ? K : (K + 1) / 2); ++c) {
+        const int kw = (S == 1) ? c : kw0 + 2 * c;
+        if (kw >= K) continue;
+        float wv[CE];
+        const float* wp = wt + (kh * K + kw) * 8 * CE + cq * CE;
+#pragma unroll
+        for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          const int hn = h0 + lh[o] + p.pad_t - kh, wn = w0 + lw[o] + p.pad_l - kw;
+          const int ih = ((S == 1) ? hn : (hn >> 1)) - ro0, iw = ((S == 1) ? wn : (wn >> 1)) - co0;
+          float dv[CE];
+          Chunk<T>::unpack(zt[(ih * TL::IW + iw) * 8 + cq], dv);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(dv[e], wv[e], acc[o][e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const int h = h0 + lh[o], w = w0 + lw[o];
+      if (!cok || h >= p.H || w >= p.W) continue;
+      const long long off = ((long long)b * HW + (long long)h * p.W + w) * p.C + c0;
+      if (p.aux) {
+        float av[CE];
+        Chunk<T>::unpack(*(const uint4*)((const T*)p.aux + off), av);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[o][e] *= swish_gradf_(av[e]);
+      }
+      *(uint4*)((T*)p.y + off) = Chunk<T>::pack(acc[o]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // g[tap][c] += sum_{b,ho,wo} dz * x(tap),  dsum[c] += sum dz.   4 channels per thread, K*K taps in registers.
 template <typename T, int K>
@@ -288,6 +515,40 @@ int fill(DwK& k, int dtype, int B, int H, int W, int C, int kk, int stride, int 
 
 }  // namespace
 
+namespace {
+template <template <typename, int, int> class Kern> struct LdsLaunch {};
+template <typename T, int K, int S>
+int launch_fwd_lds(const DwK& a, hipStream_t st) {
+  typedef DwTile<K, S> TL;
+  const size_t lds = (size_t)TL::NPIECE * 1024 + (size_t)K * K * 8 * Elem<T>::CE * 4;
+  dim3 grid(a.B * ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), (a.nch + 7) / 8);
+  static bool once = false;   // per instantiation; idempotent, benign race
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_fwd_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  return EFFDET_OK;
+}
+template <typename T, int K, int S>
+int launch_dgrad_lds(const DwK& a, hipStream_t st) {
+  typedef DgTile<K, S> TL;
+  const size_t lds = (size_t)TL::NPIECE * 1024 + (size_t)K * K * 8 * Elem<T>::CE * 4;
+  dim3 grid(a.B * ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), (a.nch + 7) / 8);
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  return EFFDET_OK;
+}
+#define DW_DISPATCH(FN, dtype, k, s, a, st)                                                    \
+  do {                                                                                         \
+    if ((dtype) == EFFDET_F32) {                                                               \
+      if ((k) == 3) { if ((s) == 1) FN<float, 3, 1>(a, st); else FN<float, 3, 2>(a, st); }     \
+      else { if ((s) == 1) FN<float, 5, 1>(a, st); else FN<float, 5, 2>(a, st); }              \
+    } else {                                                                                   \
+      if ((k) == 3) { if ((s) == 1) FN<bf16_t, 3, 1>(a, st); else FN<bf16_t, 3, 2>(a, st); }   \
+      else { if ((s) == 1) FN<bf16_t, 5, 1>(a, st); else FN<bf16_t, 5, 2>(a, st); }            \
+    }                                                                                          \
+  } while (0)
+}  // namespace
+
 extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* scale, const float* shift, void* y,
                                  void* z, float* pool, int dtype, int B, int H, int W, int C, int k, int stride,
                                  int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
@@ -299,8 +560,7 @@ extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* sca
   a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y; a.z = z; a.pool = pool;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) { if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<float, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_fwd_kernel<float, 5>), grid, dim3(256), 0, st, a); }
-  else { if (k == 3) hipLaunchKernelGGL((dw_fwd_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_fwd_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a); }
+  DW_DISPATCH(launch_fwd_lds, dtype, k, stride, a, st);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -316,8 +576,7 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
   a.x = dz; a.w = w; a.scale = scale; a.aux = zprev; a.y = dx;
   if (!extent(a, (long long)B * Ho * Wo * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) { if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<float, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_dgrad_kernel<float, 5>), grid, dim3(256), 0, st, a); }
-  else { if (k == 3) hipLaunchKernelGGL((dw_dgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a); else hipLaunchKernelGGL((dw_dgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a); }
+  DW_DISPATCH(launch_dgrad_lds, dtype, k, stride, a, st);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
