@@ -160,6 +160,12 @@ def main():
         dist.barrier()
 
     if rank == 0 and world == 1 and not a.no_inference:
+        # configs[1] is quoted on RANDOM-INIT weights (every anchor passes the 0.01 threshold = NMS worst case); the model
+        # above has been updated by the timed AdamW steps, so use a fresh one
+        del opt
+        torch.manual_seed(0)
+        model = EfficientDet(num_classes=80, network=a.network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'],
+                             D_class=cfg['D_class'], is_training=False, compute_dtype=dtype).to(dev)
         model.eval(); model.is_training = False
         with torch.no_grad():
             for _ in range(2):

@@ -379,9 +379,15 @@ extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p
   return (long long)splits * p->Cout * k.K * (long long)sizeof(float);
 }
 
+extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
+  WgradK k; int splits = 0;
+  if (plan(p, k, splits) != EFFDET_OK) return -1;
+  return splits;
+}
+
 extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
                                    effdet_stream_t stream) {
-  if (!p || !p->x || !p->dz || !p->dw || !workspace) return EFFDET_EINVAL;
+  if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
   WgradK k; int splits = 0;
   const int rc = plan(p, k, splits);
   if (rc != EFFDET_OK) return rc;
@@ -401,8 +407,10 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
     hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, k);
   }
   EFFDET_CHECK_LAUNCH();
-  long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
-  EFFDET_CHECK_LAUNCH();
+  if (p->dw) {   // optional packed accumulate; with dw == NULL the caller reduces the slabs in effdet_unpack_conv_wgrad
+    long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
+    EFFDET_CHECK_LAUNCH();
+  }
   return EFFDET_OK;
 }

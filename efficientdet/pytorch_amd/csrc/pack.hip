@@ -29,20 +29,39 @@ __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restri
   }
 }
 
-// one block per output channel
-__global__ void unpack_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ scale,
-                                    const float* __restrict__ w, float* __restrict__ dw, float* __restrict__ wsum,
-                                    int accumulate, int Cin, int KH, int KW, int Cin_pad) {
-  const int co = blockIdx.x, taps = KH * KW, n = Cin * taps;
+// grid (Cout, chunks of the packed [tap][Cin_pad] row).  Threads walk the PACKED index so the (split-K) slab reads
+// are coalesced; the OIHW writes scatter inside one channel's few-KiB row (merged in L2).  With wsum the row is
+// handled by a single block (gridDim.y == 1) so the dot product needs no atomics.
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ scale,
+                                                           const float* __restrict__ w, float* __restrict__ dw,
+                                                           float* __restrict__ wsum, int accumulate, int Cin, int KH, int KW,
+                                                           int Cin_pad, int nslabs, long long slab_stride) {
+  const int co = blockIdx.x, taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
+  const float* grow = g + (long long)co * np;
   float part = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    // i indexes OIHW within this co: i = ci*taps + tap
-    const int ci = i / taps, tap = i - ci * taps;
-    const float gv = g[((long long)co * taps + tap) * Cin_pad + ci];
-    const long long o = (long long)co * n + i;
-    if (wsum) part += w[o] * gv;
-    dw[o] = accumulate ? dw[o] + s * gv : s * gv;
+  // 4 consecutive packed elements (same tap, 4 channels: Cin_pad % 4 == 0) per thread, 16-byte slab loads,
+  // slab loop unrolled x4 so the loads of different slabs are in flight together
+  for (int q4 = blockIdx.y * 256 + threadIdx.x; q4 * 4 < np; q4 += gridDim.y * 256) {
+    const int pidx = q4 * 4;
+    const int tap = pidx / Cin_pad, ci = pidx - tap * Cin_pad;
+    f32x4 a0 = *(const f32x4*)(grow + pidx), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    int sl = 1;
+    for (; sl + 3 < nslabs; sl += 4) {
+      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride);
+      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride);
+      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride);
+      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride);
+    }
+    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride);
+    const f32x4 gv = (a0 + a1) + (a2 + a3);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ci + e >= Cin) continue;
+      const long long o = (long long)co * n + (ci + e) * taps + tap;
+      if (wsum) part += w[o] * gv[e];
+      dw[o] = accumulate ? dw[o] + s * gv[e] : s * gv[e];
+    }
   }
   if (wsum) {
     __shared__ float red[4];
@@ -104,9 +123,13 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
 }
 
 extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w, float* dw, float* wsum,
-                                        int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream) {
-  if (!g || !dw || (wsum && !w) || Cin_pad < Cin) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW, Cin_pad);
+                                        int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
+                                        effdet_stream_t stream) {
+  if (!g || !dw || (wsum && !w) || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
+  const int np = KH * KW * Cin_pad;
+  const int gy = wsum ? 1 : (np / 4 + 255) / 256;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, gy), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW,
+                     Cin_pad, nslabs, (long long)Cout * np);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

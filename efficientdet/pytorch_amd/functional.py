@@ -66,9 +66,9 @@ def stem_bwd(saved, dy):
     x, z, s, inv, mean, w, pad = saved
     Cout, ce = w.shape[0], x.C
     dz = ops.act_bwd(dy, z, ACT_SWISH)
-    ar = ZeroArena(ZeroArena.need(Cout * 9 * ce, Cout), w.device)
-    G, dsum = ar.take(Cout, 9, ce), ar.take(Cout)
-    ops.conv2d_wgrad(x, dz, G, dsum, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
+    ar = ZeroArena(ZeroArena.need(Cout), w.device)
+    dsum = ar.take(Cout)
+    G = ops.conv2d_wgrad(x, dz, None, dsum, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
     dw = torch.empty_like(w); wsum = torch.empty(Cout, dtype=torch.float32, device=w.device)
     ops.unpack_wgrad(G, dw, scale=s, w_oihw=w, wsum=wsum, cin_pad=ce)
     dg, db = ops.bn_param_grad(wsum, dsum, mean, inv)
@@ -118,12 +118,12 @@ def mbconv_bwd(sv, dy):
     B, H, W = x.B, x.H, x.W
     g = {}
     Ce, Co, Ci, Cs, kk = blk.cexp, blk.cout, blk.cin, blk.cse, blk.k * blk.k
-    ar = ZeroArena(ZeroArena.need(Co * Ce, Co, Cs * Ce, Cs, Ce * Cs, Ce, Ce * Ci, Ce), dev)
+    ar = ZeroArena(ZeroArena.need(Co, Cs * Ce, Cs, Ce * Cs, Ce, Ce), dev)
     # ---- project conv (+ drop_connect scale on the branch) ----
     rs = sv['rowscale'] if blk.skip else None
     dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
-    G2, dsum2 = ar.take(Co, 1, Ce), ar.take(Co)
-    ops.conv2d_wgrad(sv['xs'], dz2, G2, dsum2, Cin=Ce, Cout=Co, KH=1, KW=1)
+    dsum2 = ar.take(Co)
+    G2 = ops.conv2d_wgrad(sv['xs'], dz2, None, dsum2, Cin=Ce, Cout=Co, KH=1, KW=1)
     wp = P['project.weight']
     dwp = torch.empty_like(wp); wsum2 = torch.empty(Co, dtype=torch.float32, device=dev)
     ops.unpack_wgrad(G2, dwp, scale=sv['s2'], w_oihw=wp, wsum=wsum2)
@@ -150,8 +150,8 @@ def mbconv_bwd(sv, dy):
     if blk.expand == 1:
         return dze, g           # block 0: depthwise acts on the block input directly, no skip
     # ---- expand conv; the identity-skip gradient is added in the data-gradient epilogue ----
-    G0, dsum0 = ar.take(Ce, 1, Ci), ar.take(Ce)
-    ops.conv2d_wgrad(x, dze, G0, dsum0, Cin=Ci, Cout=Ce, KH=1, KW=1)
+    dsum0 = ar.take(Ce)
+    G0 = ops.conv2d_wgrad(x, dze, None, dsum0, Cin=Ci, Cout=Ce, KH=1, KW=1)
     we = P['expand.weight']
     dwe = torch.empty_like(we); wsum0 = torch.empty(Ce, dtype=torch.float32, device=dev)
     ops.unpack_wgrad(G0, dwe, scale=sv['s0'], w_oihw=we, wsum=wsum0)
@@ -178,9 +178,8 @@ def lateral_bwd(feats, weights, douts, dtype):
     dfs, dws, dbs = [], [], []
     for f, w, dy in zip(feats, weights, douts):
         W, Cin = w.shape[0], w.shape[1]
-        ar = ZeroArena(ZeroArena.need(W * Cin, W), w.device)
-        G, db = ar.take(W, 1, Cin), ar.take(W)
-        ops.conv2d_wgrad(f, dy, G, db, Cin=Cin, Cout=W, KH=1, KW=1)
+        db = torch.zeros(W, dtype=torch.float32, device=w.device)
+        G = ops.conv2d_wgrad(f, dy, None, db, Cin=Cin, Cout=W, KH=1, KW=1)
         dw = torch.empty_like(w)
         ops.unpack_wgrad(G, dw)
         df = Map.new(f.B, f.H, f.W, Cin, dtype, w.device)
@@ -234,7 +233,7 @@ def bifpn_module_bwd(saved, douts, dtype):
     grads = {}                                   # tensor name -> Map (private, safe to accumulate into)
     for n, d in zip(out_names, douts):
         grads[n] = Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
-    ar = ZeroArena(ZeroArena.need(*([Wc * 9 * Wc, Wc] * 8), 10, 9), dev)
+    ar = ZeroArena(ZeroArena.need(*([Wc] * 8), 10, 9), dev)
     dn1, dn2 = ar.take(2, w1.shape[1]), ar.take(3, w2.shape[1])
     dcw, dcb = [None] * 8, [None] * 8
 
@@ -247,8 +246,8 @@ def bifpn_module_bwd(saved, douts, dtype):
 
     for (mode, col, wsel, a_n, b_n, c_n, out_n, f, ci) in reversed(nodes):
         dz = grads[out_n]                                            # conv has bias only: dz = dy
-        G, db = ar.take(Wc, 9, Wc), ar.take(Wc)
-        ops.conv2d_wgrad(f, dz, G, db, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+        db = ar.take(Wc)
+        G = ops.conv2d_wgrad(f, dz, None, db, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
         dw = torch.empty_like(cw[ci]); ops.unpack_wgrad(G, dw)
         dcw[ci], dcb[ci] = dw, db
         df = Map.new(f.B, f.H, f.W, Wc, dtype, dev)
@@ -326,11 +325,7 @@ def head_bwd(saved, dcls_logit, dreg, dtype):
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     g = {}
-    need = []
-    for name, w in HP.items():
-        if name.endswith('weight'):
-            need += [w.numel(), w.shape[0]]
-    ar = ZeroArena(ZeroArena.need(*need), dev)
+    ar = ZeroArena(ZeroArena.need(*[w.shape[0] for name, w in HP.items() if name.endswith('weight')]), dev)
     dp_maps = None
     for tower, dout, per in (('cls', dcls_logit, nc), ('reg', dreg, 4)):
         fin = f'retina_{tower}'
@@ -341,8 +336,8 @@ def head_bwd(saved, dcls_logit, dreg, dtype):
         Cfp = (Cf + ce - 1) // ce * ce
         if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
             dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
-        G, db = ar.take(Cf, 9, 256), ar.take(Cf)
-        ops.conv2d_wgrad(acts[tower][3], dzmaps, G, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
+        db = ar.take(Cf)
+        G = ops.conv2d_wgrad(acts[tower][3], dzmaps, None, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
         dw = torch.empty_like(wf); ops.unpack_wgrad(G, dw)
         g[fin + '.weight'], g[fin + '.bias'] = dw, db
         # data gradient with the ReLU mask of the producing tower layer fused into the epilogue
@@ -353,8 +348,8 @@ def head_bwd(saved, dcls_logit, dreg, dtype):
             w = HP[f'{tower}_convs.{t}.weight']
             xin = acts[tower][t - 1] if t > 0 else p
             Cin = w.shape[1]
-            G, db = ar.take(256, 9, Cin), ar.take(256)
-            ops.conv2d_wgrad(xin, dz, G, db, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
+            db = ar.take(256)
+            G = ops.conv2d_wgrad(xin, dz, None, db, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
             dw = torch.empty_like(w); ops.unpack_wgrad(G, dw)
             g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
             wd = ops.pack_weight(w, dtype, mode=1)

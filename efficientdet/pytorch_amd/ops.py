@@ -143,7 +143,9 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
 
 
 def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0):
-    """dw[Cout][taps][Cin] (fp32) += dz^T * im2col(x);  dbias[Cout] += colsum(dz)."""
+    """Weight gradient.  dw given: packed dw[Cout][taps][Cin] (fp32) += dz^T * im2col(x).  dw None: returns the
+    UNREDUCED split-K slabs (tensor [splits][Cout][taps][Cin] fp32) for unpack_wgrad to sum while unpacking.
+    dbias[Cout] += colsum(dz) either way."""
     if isinstance(xs, Map):
         xs, dzs = [xs], [dzs]
     d = L.WgradDesc()
@@ -151,7 +153,8 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     isz = x0.t.element_size()
     base_x = min(x.addr() for x in xs)
     base_z = min(z.addr() for z in dzs)
-    d.x, d.dz, d.dw = base_x, base_z, dw.data_ptr()
+    d.x, d.dz = base_x, base_z
+    d.dw = dw.data_ptr() if dw is not None else None
     d.dbias = dbias.data_ptr() if dbias is not None else None
     d.dtype = L.dtype_code(x0.dtype)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
@@ -159,21 +162,25 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     d.ldx, d.lddz = x0.ld, z0.ld
     _segs(d, xs, dzs, base_x, base_z, isz, z0.t.element_size())
     flops = 2.0 * KH * KW * Cin * Cout * sum(z.B * z.H * z.W for z in dzs)
-    nbytes = int(L.lib().effdet_conv2d_wgrad_workspace_bytes(C.byref(d)))
-    if nbytes < 0:
+    splits = int(L.lib().effdet_conv2d_wgrad_splits(C.byref(d)))
+    if splits < 1:
         raise RuntimeError('effdet_conv2d_wgrad: unsupported geometry')
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=x0.t.device)
+    slabs = torch.empty((splits, Cout, KH * KW, Cin), dtype=torch.float32, device=x0.t.device)
+    nbytes = slabs.numel() * 4
     _timed('conv_wgrad_kernel<%s>' % ('bf16' if x0.dtype == torch.bfloat16 else 'f32'), flops,
-           lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
+           lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(slabs), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
+    return slabs
 
 
 def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None):
+    """g: packed gradient [Cout][taps][Cin_pad] or unreduced slabs [splits][Cout][taps][Cin_pad] (summed here)."""
     Cout, Cin, KH, KW = dw_oihw.shape
+    nslabs = g.shape[0] if g.dim() == 4 else 1
     L.check(L.lib().effdet_unpack_conv_wgrad(L.ptr(g), L.ptr(scale), L.ptr(w_oihw), L.ptr(dw_oihw), L.ptr(wsum),
                                              int(accumulate), Cout, Cin, KH, KW, Cin if cin_pad is None else cin_pad,
-                                             L.stream_ptr()), 'effdet_unpack_conv_wgrad')
+                                             nslabs, L.stream_ptr()), 'effdet_unpack_conv_wgrad')
 
 
 def nhwc_to_nchw(m):

@@ -80,6 +80,9 @@ typedef struct {
 } effdet_wgrad_t;
 /* workspace: effdet_conv2d_wgrad_workspace_bytes(p) bytes of scratch for the split-K partial slabs. */
 long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p);
+/* number of split-K slabs the launch writes; with p->dw == NULL the slabs are left unreduced in `workspace`
+ * ([splits][Cout][KH*KW][Cin] fp32) for effdet_unpack_conv_wgrad(..., nslabs = splits) to sum while unpacking. */
+int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p);
 int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes, effdet_stream_t stream);
 
 /* OIHW fp32 master weight -> packed [Cout][KH*KW][Kpad] (mode 0, forward; channels >= Cin are
@@ -89,10 +92,10 @@ int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long work
  * (frozen-BN fold).  `Cin_pad` is that inner-dimension padding Kpad.  dtype = packed element type. */
 int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, int dtype, int mode,
                             int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream);
-/* packed fp32 gradient [Cout][KH*KW][Cin_pad] -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
+/* packed fp32 gradient [nslabs][Cout][KH*KW][Cin_pad] (slabs summed) -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
  * If wsum != NULL also wsum[cout] = sum_{tap,c} w_oihw * g  (needed for the frozen-BN gamma grad). */
 int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
-                             float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad,
+                             float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
                              effdet_stream_t stream);
 
 /* Frozen (eval-mode) BatchNorm2d as a per-channel affine (models/efficientdet.py:88-92, eps 1e-3):
