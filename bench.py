@@ -148,8 +148,20 @@ def main():
         dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
         name, d = dom
         ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
+        # the one measured by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, FETCH x2 gfx950
+        # correction) on this same command and committed under profiles/ (null when no such file / other dtype)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))
+            if a.dtype == 'bf16' and a.batch == 32 and a.size == 512:
+                traffic = tj['kernels'].get(name, {}).get('hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
         out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': d['launches'],
+                           'frac': round(ach / peak, 4), 'traffic': traffic,
+                           'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 PMC, per launch)' if traffic else None,
+                           'launches_per_step': d['launches'],
                            'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                            'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                            'all_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),

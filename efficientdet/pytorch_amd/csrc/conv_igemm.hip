@@ -127,20 +127,28 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     wok[j] = (r < BN) && (n < p.Cout);
     woff[j] = (unsigned)((long long)(wok[j] ? n : 0) * p.Kc * 16);
   }
-  // K cursor of this thread's source chunk: chunk index kq = tap*cpt + cc
+  // K cursor of this thread's source chunk: chunk index kq = tap*cpt + cc.  The per-row byte offset / halo test is
+  // recomputed only when the TAP changes; inside a tap (cpt > 8, e.g. 4 K-steps per tap at Cin = 256) a K-step just
+  // advances every offset by 8 chunks = 128 B.  (PMC: ~3 address VALU per MFMA before this.)
   int kq = kc, tap = 0, cc = kc;
   while (cc >= p.cpt) { cc -= p.cpt; ++tap; }
   int kh = tap / p.KW, kw = tap - kh * p.KW;
+  unsigned xcur[XROWS];          // current byte offset per row, or EFFDET_OOB when the tap falls outside the image
+  auto retap = [&]() {
+#pragma unroll
+    for (int j = 0; j < XROWS; ++j) {
+      const int hi = hi0[j] + kh, wi = wi0[j] + kw;
+      const bool ok = hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
+      xcur[j] = ok ? xoff[j] + (unsigned)((hi * sg.W + wi) * p.ldx + cc * CE) * ES : EFFDET_OOB;
+    }
+  };
+  retap();
 
   auto stage = [&](int buf) {
     const bool kok = kq < p.Kc;
 #pragma unroll
-    for (int j = 0; j < XROWS; ++j) {
-      const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-      const bool ok = kok && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
-      const unsigned off = xoff[j] + (unsigned)((hi * sg.W + wi) * p.ldx + cc * CE) * ES;
-      srd_dma16(rx, (void*)(xs + buf * XLD + (wrow0 + RSTEP * j) * 8), ok ? off : EFFDET_OOB);
-    }
+    for (int j = 0; j < XROWS; ++j)
+      srd_dma16(rx, (void*)(xs + buf * XLD + (wrow0 + RSTEP * j) * 8), kok ? xcur[j] : EFFDET_OOB);
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       if (wrow0 + RSTEP * j < BN)     // wave-uniform: the whole 8-row piece is inside the weight tile
@@ -148,7 +156,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     }
     // advance the cursor by one K-step (8 chunks)
     kq += 8; cc += 8;
-    while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
+    if (cc < p.cpt) {
+#pragma unroll
+      for (int j = 0; j < XROWS; ++j) xcur[j] = (xcur[j] == EFFDET_OOB) ? EFFDET_OOB : xcur[j] + 128u;
+    } else {
+      while (cc >= p.cpt) { cc -= p.cpt; ++kw; if (kw == p.KW) { kw = 0; ++kh; } }
+      retap();
+    }
   };
 
   f32x4 acc[NT][MT];

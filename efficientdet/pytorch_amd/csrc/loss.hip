@@ -112,22 +112,25 @@ __device__ __forceinline__ float focal_elem(float praw, bool target_one, float& 
 }
 
 __global__ __launch_bounds__(256) void loss_cls_kernel(const LossK p) {
+  // 32-bit index arithmetic (A*nc < 2^31 is checked by the host): the 64-bit divisions per element of the first
+  // version made this HBM pass ALU-bound.  When nc % 4 == 0 a 4-element group never straddles two anchors.
   const int b = blockIdx.y;
-  const long long per = p.A * p.nc;                 // elements per image
-  const long long e0 = (blockIdx.x * 256LL + threadIdx.x) * 4;
+  const int per = (int)(p.A * p.nc);
+  const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   float s = 0.f;
   if (e0 < per && p.stat[b * 4 + 3] > 0.f) {
     const float* c = p.cls + (long long)b * per;
-    float v[4]; int cnt = (int)min(4LL, per - e0);
-    if (cnt == 4 && ((per & 3) == 0)) { const f32x4 t = *(const f32x4*)(c + e0); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    const int* asg = p.assign + (long long)b * p.A;
+    float v[4]; const int cnt = min(4, per - e0);
+    const bool vec = cnt == 4 && ((per & 3) == 0);
+    if (vec) { const f32x4 t = *(const f32x4*)(c + e0); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
     else for (int q = 0; q < cnt; ++q) v[q] = c[e0 + q];
+    int a = e0 / p.nc, k = e0 - a * p.nc;
+    int code = asg[a];
+    int lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1;
     for (int q = 0; q < cnt; ++q) {
-      const long long e = e0 + q; const long long a = e / p.nc; const int k = (int)(e - a * p.nc);
-      const int code = p.assign[(long long)b * p.A + a];
-      if (code == -2) continue;
-      bool one = false;
-      if (code >= 0) one = ((int)p.annots[((long long)b * p.N + code) * 5 + 4] == k);
-      float d; s += focal_elem(v[q], one, d);
+      if (code != -2) { float d; s += focal_elem(v[q], lab == k, d); }
+      if (++k == p.nc && q + 1 < cnt) { k = 0; ++a; code = asg[a]; lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1; }
     }
   }
   __shared__ float red[4];
@@ -153,27 +156,31 @@ __global__ void loss_final_kernel(const LossK p) {
 template <typename T>
 __global__ __launch_bounds__(256) void loss_bwd_cls_kernel(const LossK p) {
   const int b = blockIdx.y;
-  const long long per = p.A * p.nc;
-  const long long e0 = (blockIdx.x * 256LL + threadIdx.x) * 4;
+  const int per = (int)(p.A * p.nc);
+  const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (e0 >= per) return;
   const float* st = p.stat + b * 4;
   const bool active = st[3] > 0.f;
   const float gs = active ? p.gscale[0] / ((float)p.B * fmaxf(st[2], 1.0f)) : 0.f;
   const float* c = p.cls + (long long)b * per;
+  const int* asg = p.assign + (long long)b * p.A;
   T* out = (T*)p.dcls + (long long)b * per;
-  const int cnt = (int)min(4LL, per - e0);
-  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cnt = min(4, per - e0);
+  const bool vec = cnt == 4 && ((per & 3) == 0);
+  float v[4] = {0.f, 0.f, 0.f, 0.f}, g[4] = {0.f, 0.f, 0.f, 0.f};
+  if (vec) { const f32x4 t = *(const f32x4*)(c + e0); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+  else for (int q = 0; q < cnt; ++q) v[q] = c[e0 + q];
+  int a = e0 / p.nc, k = e0 - a * p.nc;
+  int code = asg[a];
+  int lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1;
   for (int q = 0; q < cnt; ++q) {
-    const long long e = e0 + q; const long long a = e / p.nc; const int k = (int)(e - a * p.nc);
-    const int code = p.assign[(long long)b * p.A + a];
-    if (!active || code == -2) continue;
-    bool one = false;
-    if (code >= 0) one = ((int)p.annots[((long long)b * p.N + code) * 5 + 4] == k);
-    const float pr = c[e];
-    float d; (void)focal_elem(pr, one, d);
-    g[q] = gs * d * pr * (1.f - pr);                 // through the sigmoid
+    if (active && code != -2) {
+      float d; (void)focal_elem(v[q], lab == k, d);
+      g[q] = gs * d * v[q] * (1.f - v[q]);                 // through the sigmoid
+    }
+    if (++k == p.nc && q + 1 < cnt) { k = 0; ++a; code = asg[a]; lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1; }
   }
-  if (cnt == 4 && ((per & 3) == 0)) store4(out + e0, f32x4{g[0], g[1], g[2], g[3]});
+  if (vec) store4(out + e0, f32x4{g[0], g[1], g[2], g[3]});
   else for (int q = 0; q < cnt; ++q) Elem<T>::st(out + e0 + q, g[q]);
 }
 
@@ -226,6 +233,7 @@ extern "C" int effdet_focal_loss_fwd(const float* cls, const float* reg, const f
                                      int num_classes, int N, effdet_stream_t stream) {
   if (!cls || !reg || !anchors || !annots || !losses || !workspace) return EFFDET_EINVAL;
   if (workspace_bytes < effdet_loss_workspace_bytes(B, A) || B > 65535 || N < 1) return EFFDET_EINVAL;
+  if (A * num_classes >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
   LossK k{}; k.cls = cls; k.reg = reg; k.anchors = anchors; k.annots = annots; k.losses = losses;
   k.B = B; k.nc = num_classes; k.N = N; k.A = A;
   carve_loss(k, workspace, B, A);
