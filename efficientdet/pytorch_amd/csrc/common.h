@@ -16,12 +16,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
   } while (0)
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+// fp32 -> bf16, round-to-nearest-even, through the native v_cvt_pk_bf16_f32 (one instruction per PAIR; the software
+// rounding sequence was ~6 VALU per value and made the conv epilogues VALU-bound)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, 0.f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -47,8 +49,8 @@ __device__ __forceinline__ f32x4 load4(const bf16_t* p) {
 __device__ __forceinline__ void store4(float* p, f32x4 v) { *(f32x4*)p = v; }
 __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   uint2 u;
-  u.x = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-  u.y = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+  u.x = pack2bf(v[0], v[1]);
+  u.y = pack2bf(v[2], v[3]);
   *(uint2*)p = u;
 }
 
@@ -71,15 +73,13 @@ template <> struct Chunk<bf16_t> {
   }
   static __device__ __forceinline__ uint4 pack(const float* f) {
     uint4 u;
-    u.x = (uint32_t)f2bf(f[0]) | ((uint32_t)f2bf(f[1]) << 16);
-    u.y = (uint32_t)f2bf(f[2]) | ((uint32_t)f2bf(f[3]) << 16);
-    u.z = (uint32_t)f2bf(f[4]) | ((uint32_t)f2bf(f[5]) << 16);
-    u.w = (uint32_t)f2bf(f[6]) | ((uint32_t)f2bf(f[7]) << 16);
+    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]); u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
     return u;
   }
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp) instead of an IEEE division sequence (~10 VALU): error ~1e-7, far inside every tolerance
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx [x*sigmoid(x)] = s*(1 + x*(1-s))     (models/utils.py:45-48 of the reference)
 __device__ __forceinline__ float swish_gradf_(float x) {

@@ -40,7 +40,7 @@ struct ConvK {
   int ldx, ldy;
   int Kc;    // K in 16-byte chunks (= KH*KW*Cin/CE)
   int cpt;   // chunks per tap (= Cin/CE)
-  int act, res_mode, out_f32, vec_ok;
+  int act, res_mode, out_f32, vec_ok, vec16_ok;
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   SegD seg[EFFDET_MAX_SEG];
@@ -195,6 +195,22 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   }
 
   // ---- epilogue: lane holds channels n0..n0+3 (rows of D) of pixel m (column of D) ----
+  // (An LDS-transposed variant with full-row 16-byte stores was measured: no gain -- PMC showed the epilogue of the
+  //  HBM-bound pointwise convs VALU-bound (~1100 VALU per wave for 16 MFMAs), not store-bound; hence the hoisted
+  //  16-byte scale/shift loads here and the v_rcp_f32 / v_cvt_pk_bf16_f32 helpers in common.h.)
+  f32x4 scv[NT], shv[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const int n0 = n_base + wn0 + a * 16 + lq * 4;
+    scv[a] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n0 + 3 < p.Cout) {
+      if (p.scale) scv[a] = *(const f32x4*)(p.scale + n0);
+      if (p.shift) shv[a] = *(const f32x4*)(p.shift + n0);
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (n0 + r < p.Cout) { if (p.scale) scv[a][r] = p.scale[n0 + r]; if (p.shift) shv[a][r] = p.shift[n0 + r]; }
+    }
+  }
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
     const int m = m_base + wm0 + b * 16 + l15;
@@ -206,17 +222,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     for (int a = 0; a < NT; ++a) {
       const int n0 = n_base + wn0 + a * 16 + lq * 4;
       if (n0 >= p.Cout) continue;
-      f32x4 v = acc[a][b];
+      f32x4 v = acc[a][b] * scv[a] + shv[a];
       const bool full = p.vec_ok && (n0 + 3 < p.Cout);
-      float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n0 + r < p.Cout) {
-          if (p.scale) sc[r] = p.scale[n0 + r];
-          if (p.shift) sh[r] = p.shift[n0 + r];
-        }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = v[r] * sc[r] + sh[r];
       const long long o = orow + n0;
       if (p.z) {
         if (full) store4((T*)p.z + o, v);
@@ -226,13 +233,13 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
       if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
       else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
       else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
-      for (int r = 0; r < 4; ++r) v[r] *= rs;
+      if (p.rowscale) v *= rs;
       if (p.res_mode != EFFDET_RES_NONE) {
         f32x4 q;
         if (full) q = load4((const T*)p.res + o);
         else
           for (int r = 0; r < 4; ++r) q[r] = (n0 + r < p.Cout) ? Elem<T>::ld((const T*)p.res + o + r) : 0.f;
-        if (p.res_mode == EFFDET_RES_ADD) { for (int r = 0; r < 4; ++r) v[r] += q[r]; }
+        if (p.res_mode == EFFDET_RES_ADD) { v += q; }
         else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
         else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
       }
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 
 template <typename T, int BN, int WAVES_N, int NWAVES>
 int launch(const ConvK& k, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);
+  const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);                     // double-buffered operand tiles
   const int grid = k.mtiles * k.ntiles;
   static bool attr_set = false;  // idempotent; benign race
   if (!attr_set && lds > 48 * 1024) {
@@ -296,6 +303,9 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   k.nseg = p->nseg;
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
+  // 16-byte row stores of the LDS-transposed epilogue: rows / level offsets aligned to 8 elements (bf16) or 4 (fp32)
+  const int al16 = (p->dtype == EFFDET_F32 || p->out_f32) ? 4 : 8;
+  bool vec16 = (p->ldy % al16 == 0);
   for (int s = 0; s < p->nseg; ++s) {
     const effdet_seg_t& g = p->seg[s];
     SegD& d = k.seg[s];
@@ -306,10 +316,11 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     if (d.M <= 0) return EFFDET_EINVAL;
     if (g.in_off % ce || g.in_bstride % ce) return EFFDET_EUNSUPPORTED;
     if (g.out_off % 4 || g.out_bstride % 4) vec = false;
+    if (g.out_off % al16 || g.out_bstride % al16) vec16 = false;
     tiles += (d.M + BM - 1) / BM;
   }
   for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
-  k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
+  k.mtiles = tiles; k.vec_ok = vec ? 1 : 0; k.vec16_ok = (vec && vec16) ? 1 : 0;
   // byte extents actually addressed through each segment's SRD (32-bit offsets): refuse tensors beyond 4 GiB - 64 KiB
   const long long es = p->dtype == EFFDET_F32 ? 4 : 2;
   for (int s = 0; s < p->nseg; ++s) {
