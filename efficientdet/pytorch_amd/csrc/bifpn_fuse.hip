@@ -10,7 +10,9 @@
 // into the load so no resampled tensor is ever materialised.  Backward walks the COARSE grid so
 // that each thread owns a 2x2 patch: the up-sample gradient (sum over the patch) and the
 // max-pool gradient (route to the arg-max) need no atomics; only the 2-3 weight gradients are
-// reduced (wave shuffles -> one fp32 atomic per wave).
+// reduced: wave shuffles -> LDS -> ONE fp32 atomic set per workgroup, spread over EFFDET_FUSE_SLOTS
+// 256-byte slots.  (Same-cache-line atomics serialise at ~8 ns each on gfx950: one atomic per wave into a
+// single [wrows][wcols] array cost 100 us of a 140 us launch.)
 #include "common.h"
 
 namespace {
@@ -175,11 +177,14 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseK p) {
       }
     }
   }
+  __shared__ float red[3][4];
   g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2);
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(p.dn + 0 * p.wcols + p.col, g0);
-    atomicAdd(p.dn + 1 * p.wcols + p.col, g1);
-    if (p.mode == 1) atomicAdd(p.dn + 2 * p.wcols + p.col, g2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = g0; red[1][threadIdx.x >> 6] = g1; red[2][threadIdx.x >> 6] = g2; }
+  __syncthreads();
+  if (threadIdx.x < 3 && (threadIdx.x < 2 || p.mode == 1)) {
+    const int r = threadIdx.x;
+    float* slot = p.dn + (blockIdx.x % EFFDET_FUSE_SLOTS) * EFFDET_FUSE_SLOT_FLOATS;
+    atomicAdd(slot + r * p.wcols + p.col, red[r][0] + red[r][1] + red[r][2] + red[r][3]);
   }
 }
 
@@ -188,18 +193,21 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseK p) {
 __global__ void fuse_weight_bwd_kernel(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   if (col >= wcols) return;
-  float r[3] = {0, 0, 0}, T = 0.f;
-  for (int i = 0; i < wrows; ++i) { r[i] = fmaxf(wraw[i * wcols + col], 0.f); T += r[i]; }
+  float r[3] = {0, 0, 0}, d[3] = {0, 0, 0}, T = 0.f;
+  for (int i = 0; i < wrows; ++i) {
+    r[i] = fmaxf(wraw[i * wcols + col], 0.f); T += r[i];
+    for (int s = 0; s < EFFDET_FUSE_SLOTS; ++s) d[i] += dn[s * EFFDET_FUSE_SLOT_FLOATS + i * wcols + col];
+  }
   const float ti = 1.0f / (T + FEPS);
   float dot = 0.f;
-  for (int i = 0; i < wrows; ++i) dot += dn[i * wcols + col] * r[i] * ti;
+  for (int i = 0; i < wrows; ++i) dot += d[i] * r[i] * ti;
   for (int i = 0; i < wrows; ++i) {
     const float m = wraw[i * wcols + col] > 0.f ? 1.f : 0.f;
-    dwraw[i * wcols + col] += m * ti * (dn[i * wcols + col] - dot);
+    dwraw[i * wcols + col] += m * ti * (d[i] - dot);
   }
 }
 
-inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+inline int grid_for(long long n, int cap = 4096) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > cap ? cap : g)); }
 
 }  // namespace
 
@@ -229,13 +237,14 @@ extern "C" int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void
   if (!dout || !a || !b || !da || !db || !wraw || !dn || mode < 0 || mode > 2 || C % ce) return EFFDET_EINVAL;
   if (mode == 1 && (!c || !dc)) return EFFDET_EINVAL;
   if (mode == 0 && ((H | W) & 1)) return EFFDET_EUNSUPPORTED;
+  if (wrows * wcols > EFFDET_FUSE_SLOT_FLOATS) return EFFDET_EUNSUPPORTED;
   FuseK k{}; k.a = a; k.b = b; k.c = c; k.dout = dout; k.da = da; k.db = db; k.dc = dc; k.wraw = wraw; k.dn = dn;
   k.wrows = wrows; k.wcols = wcols; k.col = col; k.mode = mode; k.B = B; k.H = H; k.W = W; k.C = C;
   k.da_acc = da_accum; k.db_acc = db_accum; k.dc_acc = dc_accum;
   const long long n = (long long)B * (mode == 0 ? (H / 2) * (W / 2) : H * W) * (C / ce);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, k);
-  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(fuse_bwd_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, k);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(grid_for(n, 2048)), dim3(256), 0, st, k);
+  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(fuse_bwd_kernel<bf16_t>, dim3(grid_for(n, 2048)), dim3(256), 0, st, k);
   else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
@@ -244,6 +253,7 @@ extern "C" int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void
 extern "C" int effdet_bifpn_weight_bwd(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols,
                                        effdet_stream_t stream) {
   if (!wraw || !dn || !dwraw || wrows < 2 || wrows > 3) return EFFDET_EINVAL;
+  if (wrows * wcols > EFFDET_FUSE_SLOT_FLOATS) return EFFDET_EUNSUPPORTED;
   hipLaunchKernelGGL(fuse_weight_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wraw, dn, dwraw, wrows, wcols);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;

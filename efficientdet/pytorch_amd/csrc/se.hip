@@ -9,65 +9,117 @@ inline int grid_for(long long n, int block = 256) {
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
 }
 
-// ---- gate = sigmoid(W2 * swish(W1 * mean + b1) + b2); one workgroup per image ----
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2,
-                                                          const float* __restrict__ b2, float* __restrict__ gate,
-                                                          float* __restrict__ mid, int C, int Cse, float inv_hw) {
+// ---- gate = sigmoid(W2 * swish(W1 * mean + b1) + b2); one 1024-thread workgroup per image ----
+// Latency-bound (a few KB of data per image): the win is the LENGTH OF THE DEPENDENT CHAIN, so every stage
+// issues all of its loads before the first use (16 waves, squeezed channels unrolled x3).
+constexpr int SE_T = 1024;
+__global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, float* __restrict__ gate,
+                                                           float* __restrict__ mid, int C, int Cse, float inv_hw) {
   extern __shared__ float sm[];          // mean[C] | sw[Cse]
   float* mean = sm; float* sw = sm + C;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 256) mean[c] = pool[(long long)b * C + c] * inv_hw;
+  for (int c = tid; c < C; c += SE_T) mean[c] = pool[(long long)b * C + c] * inv_hw;
   __syncthreads();
-  for (int j = wave; j < Cse; j += 4) {          // one wave per squeezed channel
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w1[(long long)j * C + c], mean[c], s);
-    s = wave_sum(s);
-    if (lane == 0) { const float m = s + b1[j]; if (mid) mid[(long long)b * Cse + j] = m; sw[j] = swishf_(m); }
+  for (int j0 = wave; j0 < Cse; j0 += 48) {          // one wave per squeezed channel, 3 channels in flight per wave
+    float s[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = j0 + 16 * u;
+      if (j < Cse)
+        for (int c = lane; c < C; c += 64) s[u] = fmaf(w1[(long long)j * C + c], mean[c], s[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int j = j0 + 16 * u;
+      if (j < Cse) {
+        const float t = wave_sum(s[u]);
+        if (lane == 0) { const float m = t + b1[j]; if (mid) mid[(long long)b * Cse + j] = m; sw[j] = swishf_(m); }
+      }
+    }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float s = b2[c];
-    for (int j = 0; j < Cse; ++j) s = fmaf(w2[(long long)c * Cse + j], sw[j], s);
-    gate[(long long)b * C + c] = sigmoidf_(s);
+  for (int c = tid; c < C; c += SE_T) {
+    const float* row = w2 + (long long)c * Cse;
+    float s0 = b2[c], s1 = 0.f;
+    int j = 0;
+    for (; j + 1 < Cse; j += 2) { s0 = fmaf(row[j], sw[j], s0); s1 = fmaf(row[j + 1], sw[j + 1], s1); }
+    if (j < Cse) s0 = fmaf(row[j], sw[j], s0);
+    gate[(long long)b * C + c] = sigmoidf_(s0 + s1);
   }
 }
 
-// ---- backward of the gate MLP; one workgroup per image, parameter grads via fp32 atomics ----
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
-                                                          const float* __restrict__ mid, const float* __restrict__ pool,
-                                                          const float* __restrict__ w1, const float* __restrict__ w2,
-                                                          float* __restrict__ dpool, float* __restrict__ dw1,
-                                                          float* __restrict__ db1, float* __restrict__ dw2,
-                                                          float* __restrict__ db2, int C, int Cse, float inv_hw) {
-  extern __shared__ float sm[];          // du[C] | mean[C] | sw[Cse] | dmid[Cse]
-  float* du = sm; float* mean = sm + C; float* sw = mean + C; float* dmid = sw + Cse;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += 256) {
+// ---- backward of the gate MLP, phase A: one workgroup per image -> du, dmid, sw (workspace) and dpool ----
+//   du[c]   = dgate[c]*g(1-g)                       (through the sigmoid)
+//   dmid[j] = swish'(mid[j]) * sum_c w2[c][j]*du[c]
+//   dpool[c]= inv_hw * sum_j w1[j][c]*dmid[j]       (gradient wrt the pooled SUM)
+__global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+                                                             const float* __restrict__ mid, const float* __restrict__ w1,
+                                                             const float* __restrict__ w2, float* __restrict__ dpool,
+                                                             float* __restrict__ ws_du, float* __restrict__ ws_dmid,
+                                                             float* __restrict__ ws_sw, int C, int Cse, float inv_hw) {
+  extern __shared__ float sm[];          // du[C] | dmid[Cse] | part[R][Cse]
+  float* du = sm; float* dmid = sm + C; float* part = dmid + Cse;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += SE_T) {
     const float g = gate[(long long)b * C + c];
-    const float d = dgate[(long long)b * C + c] * g * (1.f - g);      // through the sigmoid
-    du[c] = d; mean[c] = pool[(long long)b * C + c] * inv_hw;
-    atomicAdd(db2 + c, d);
-  }
-  for (int j = tid; j < Cse; j += 256) sw[j] = swishf_(mid[(long long)b * Cse + j]);
-  __syncthreads();
-  // dw2[c][j] += du[c]*sw[j]
-  for (int i = tid; i < C * Cse; i += 256) { const int c = i / Cse, j = i - c * Cse; atomicAdd(dw2 + i, du[c] * sw[j]); }
-  // dsw[j] = sum_c w2[c][j]*du[c];  dmid = dsw * swish'(mid)
-  for (int j = wave; j < Cse; j += 4) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w2[(long long)c * Cse + j], du[c], s);
-    s = wave_sum(s);
-    if (lane == 0) { const float d = s * swish_gradf_(mid[(long long)b * Cse + j]); dmid[j] = d; atomicAdd(db1 + j, d); }
+    const float d = dgate[(long long)b * C + c] * g * (1.f - g);
+    du[c] = d; ws_du[(long long)b * C + c] = d;
   }
   __syncthreads();
-  // dw1[j][c] += dmid[j]*mean[c];  dmean[c] = sum_j w1[j][c]*dmid[j];  dpool (wrt the SUM) = dmean*inv_hw
-  for (int i = tid; i < C * Cse; i += 256) { const int j = i / C, c = i - j * C; atomicAdd(dw1 + i, dmid[j] * mean[c]); }
-  for (int c = tid; c < C; c += 256) {
+  // thread (r, j): rows c = r, r+R, ... of w2[c][j] -- each pass of the workgroup reads one contiguous R x Cse chunk
+  const int R = SE_T / Cse;
+  const int r = tid / Cse, j = tid - r * Cse;
+  if (r < R) {
     float s = 0.f;
-    for (int j = 0; j < Cse; ++j) s = fmaf(w1[(long long)j * C + c], dmid[j], s);
-    dpool[(long long)b * C + c] = s * inv_hw;
+    for (int c = r; c < C; c += R) s = fmaf(w2[(long long)c * Cse + j], du[c], s);
+    part[r * Cse + j] = s;
   }
+  __syncthreads();
+  if (tid < Cse) {
+    float s = 0.f;
+    for (int q = 0; q < R; ++q) s += part[q * Cse + tid];
+    const float m = mid[(long long)b * Cse + tid];
+    const float d = s * swish_gradf_(m);
+    dmid[tid] = d; ws_dmid[(long long)b * Cse + tid] = d; ws_sw[(long long)b * Cse + tid] = swishf_(m);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += SE_T) {
+    float s0 = 0.f, s1 = 0.f;
+    int q = 0;
+    for (; q + 1 < Cse; q += 2) { s0 = fmaf(w1[(long long)q * C + c], dmid[q], s0); s1 = fmaf(w1[(long long)(q + 1) * C + c], dmid[q + 1], s1); }
+    if (q < Cse) s0 = fmaf(w1[(long long)q * C + c], dmid[q], s0);
+    dpool[(long long)b * C + c] = (s0 + s1) * inv_hw;
+  }
+}
+
+// ---- phase B: parameter gradients as batch reductions, one thread per parameter (no atomics, deterministic) ----
+//   dw2[c][j] = sum_b du[b][c]*sw[b][j]   dw1[j][c] = sum_b dmid[b][j]*mean[b][c]   db2[c] = sum_b du   db1[j] = sum_b dmid
+__global__ __launch_bounds__(256) void se_gate_bwd_b_kernel(const float* __restrict__ ws_du, const float* __restrict__ ws_dmid,
+                                                            const float* __restrict__ ws_sw, const float* __restrict__ pool,
+                                                            float* __restrict__ dw1, float* __restrict__ db1,
+                                                            float* __restrict__ dw2, float* __restrict__ db2, int B, int C,
+                                                            int Cse, float inv_hw) {
+  const int n = C * Cse;
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {                                   // dw2[c][j]
+    const int c = i / Cse, j = i - c * Cse;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s);
+    dw2[i] = s; return;
+  }
+  i -= n;
+  if (i < n) {                                   // dw1[j][c]
+    const int j = i / C, c = i - j * C;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s);
+    dw1[i] = s * inv_hw; return;
+  }
+  i -= n;
+  if (i < C) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_du[(long long)b * C + i]; db2[i] = s; return; }
+  i -= C;
+  if (i < Cse) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_dmid[(long long)b * Cse + i]; db1[i] = s; }
 }
 
 // ---- y = x * gate[b][c] ----
@@ -233,19 +285,29 @@ extern "C" int effdet_se_gate_fwd(const float* pool, const float* w1, const floa
   if (!pool || !w1 || !b1 || !w2 || !b2 || !gate) return EFFDET_EINVAL;
   const size_t lds = (size_t)(C + Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(SE_T), lds, ST, pool, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
+extern "C" long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse) { return (long long)B * (C + 2 * Cse); }
+
 extern "C" int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool, const float* w1,
                                   const float* b1, const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
-                                  int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
+                                  float* workspace, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
   (void)b1;
-  if (!dgate || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2) return EFFDET_EINVAL;
-  const size_t lds = (size_t)(2 * C + 2 * Cse) * sizeof(float);
+  if (!dgate || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2 || !workspace) return EFFDET_EINVAL;
+  if (Cse < 1 || Cse > SE_T) return EFFDET_EUNSUPPORTED;
+  const int R = SE_T / Cse;
+  const size_t lds = (size_t)(C + Cse + R * Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
-  hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), lds, ST, dgate, gate, mid, pool, w1, w2, dpool, dw1, db1, dw2, db2, C, Cse, inv_hw);
+  float* ws_du = workspace; float* ws_dmid = ws_du + (size_t)B * C; float* ws_sw = ws_dmid + (size_t)B * Cse;
+  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
+                     Cse, inv_hw);
+  EFFDET_CHECK_LAUNCH();
+  const long long n = 2LL * C * Cse + C + Cse;
+  hipLaunchKernelGGL(se_gate_bwd_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, ws_du, ws_dmid, ws_sw, pool, dw1, db1,
+                     dw2, db2, B, C, Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -273,7 +335,7 @@ extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate, int 
                                effdet_stream_t stream) {
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   if (!dy || !x || !dgate || C % ce) return EFFDET_EINVAL;
-  int slabs = (int)((HW + 255) / 256); if (slabs > 64) slabs = 64; if (slabs < 1) slabs = 1;
+  int slabs = (int)((HW + 15) / 16); if (slabs > 64) slabs = 64; if (slabs < 1) slabs = 1;     // >= 16 pixels per workgroup
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const float*)dy, (const float*)x, dgate, HW, C, slabs);
   else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate, HW, C, slabs);
   EFFDET_CHECK_LAUNCH();

@@ -118,7 +118,7 @@ def mbconv_bwd(sv, dy):
     B, H, W = x.B, x.H, x.W
     g = {}
     Ce, Co, Ci, Cs, kk = blk.cexp, blk.cout, blk.cin, blk.cse, blk.k * blk.k
-    ar = ZeroArena(ZeroArena.need(Co, Cs * Ce, Cs, Ce * Cs, Ce, Ce), dev)
+    ar = ZeroArena(ZeroArena.need(Co, Ce), dev)
     # ---- project conv (+ drop_connect scale on the branch) ----
     rs = sv['rowscale'] if blk.skip else None
     dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
@@ -133,10 +133,9 @@ def mbconv_bwd(sv, dy):
     ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
     # ---- squeeze-excite ----
     dgate = ops.se_dgate(dxs, sv['xd'])
-    dw1, db1, dw2, db2 = ar.take(Cs, Ce), ar.take(Cs), ar.take(Ce, Cs), ar.take(Ce)
     w1 = P['se_reduce.weight'].view(Cs, Ce); w2 = P['se_expand.weight'].view(Ce, Cs)
-    dpool = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2, sv['inv_hw'],
-                            dw1, db1, dw2, db2)
+    dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
+                                                sv['inv_hw'])
     g['se_reduce.weight'], g['se_reduce.bias'] = dw1.view(Cs, Ce, 1, 1), db1
     g['se_expand.weight'], g['se_expand.bias'] = dw2.view(Ce, Cs, 1, 1), db2
     dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
@@ -233,8 +232,8 @@ def bifpn_module_bwd(saved, douts, dtype):
     grads = {}                                   # tensor name -> Map (private, safe to accumulate into)
     for n, d in zip(out_names, douts):
         grads[n] = Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
-    ar = ZeroArena(ZeroArena.need(*([Wc] * 8), 10, 9), dev)
-    dn1, dn2 = ar.take(2, w1.shape[1]), ar.take(3, w2.shape[1])
+    ar = ZeroArena(ZeroArena.need(*([Wc] * 8), ops.FUSE_DN_FLOATS, ops.FUSE_DN_FLOATS), dev)
+    dn1, dn2 = ar.take(ops.FUSE_DN_FLOATS), ar.take(ops.FUSE_DN_FLOATS)
     dcw, dcb = [None] * 8, [None] * 8
 
     def target(name):

@@ -293,13 +293,23 @@ def se_dgate(dy, x):
     return dg
 
 
-def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, dw1, db1, dw2, db2):
+def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw):
+    """-> (dpool, dw1, db1, dw2, db2); the parameter grads are fresh tensors (overwritten, not accumulated)."""
     B, Cc = pool.shape
+    Cse = w1.shape[0]
+    dev = pool.device
     dpool = torch.empty_like(pool)
+    out = torch.empty(2 * Cc * Cse + Cc + Cse + B * (Cc + 2 * Cse), dtype=torch.float32, device=dev)
+    dw1 = out[:Cse * Cc].view(Cse, Cc); o = Cse * Cc
+    dw2 = out[o:o + Cc * Cse].view(Cc, Cse); o += Cc * Cse
+    db1 = out[o:o + Cse]; o += Cse
+    db2 = out[o:o + Cc]; o += Cc
+    ws = out[o:]
+    assert ws.numel() >= L.lib().effdet_se_gate_bwd_workspace_floats(B, Cc, Cse)
     L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
-                                       L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), B, Cc,
-                                       w1.shape[0], C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
-    return dpool
+                                       L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(ws),
+                                       B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
+    return dpool, dw1, db1, dw2, db2
 
 
 def se_bwd_apply(dy, gate, dpool, z):
@@ -342,7 +352,11 @@ def bifpn_fuse_fwd(a, b, c, wraw, col, mode):
     return out
 
 
+FUSE_DN_FLOATS = 32 * 64          # EFFDET_FUSE_SLOTS x EFFDET_FUSE_SLOT_FLOATS (include/effdet_hip.h)
+
+
 def bifpn_fuse_bwd(dout, a, b, c, da, db, dc, da_acc, db_acc, dc_acc, wraw, dn, col, mode):
+    assert dn.numel() == FUSE_DN_FLOATS
     wr, wc = wraw.shape
     L.check(L.lib().effdet_bifpn_fuse_bwd(L.ptr(dout.tensor()), L.ptr(a.tensor()), L.ptr(b.tensor()),
                                           L.ptr(c.tensor() if c is not None else None), L.ptr(da.tensor()), L.ptr(db.tensor()),

@@ -155,10 +155,13 @@ int effdet_channel_scale(const void* x, const float* gate, void* y, int dtype, i
 int effdet_se_dgate(const void* dy, const void* x, float* dgate, int dtype, int B, long long HW, int C,
                     effdet_stream_t stream);
 /* tiny FC backward: from dgate[b][c] (grad wrt gate), gate, mid, pool -> dpool[b][c] (grad wrt the
- * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (+=, fp32). */
+ * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (OVERWRITTEN, fp32; batch reductions with one
+ * thread per parameter: no atomics, deterministic).  workspace: effdet_se_gate_bwd_workspace_floats() fp32. */
+long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse);
 int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool,
                        const float* w1, const float* b1, const float* w2, float* dpool, float* dw1, float* db1,
-                       float* dw2, float* db2, int B, int C, int Cse, float inv_hw, effdet_stream_t stream);
+                       float* dw2, float* db2, float* workspace, int B, int C, int Cse, float inv_hw,
+                       effdet_stream_t stream);
 /* dx = (dy*gate[b][c] + dpool[b][c]) * swish'(z)   -- gradient wrt the depthwise pre-activation z */
 int effdet_se_bwd_apply(const void* dy, const float* gate, const float* dpool, const void* z, void* dzout,
                         int dtype, int B, long long HW, int C, effdet_stream_t stream);
@@ -184,8 +187,12 @@ int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                           effdet_stream_t stream);
 /* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and
- * dn[r][col] += d loss / d n_r  (grad wrt the ONCE-normalised weights, fp32 [wrows][wcols], zeroed by
- * the caller).  effdet_bifpn_weight_bwd then maps dn -> dwraw (+=) through the first normalisation. */
+ * dn[slot][r*wcols + col] += d loss / d n_r  (grad wrt the ONCE-normalised weights).  dn is an fp32 scratch of
+ * EFFDET_FUSE_SLOTS x EFFDET_FUSE_SLOT_FLOATS, zeroed by the caller: workgroups scatter their partial sums over
+ * the 256-byte slots (same-cache-line atomics serialise on gfx950); wrows*wcols <= EFFDET_FUSE_SLOT_FLOATS.
+ * effdet_bifpn_weight_bwd then sums the slots and maps dn -> dwraw (+=) through the first normalisation. */
+#define EFFDET_FUSE_SLOTS 32
+#define EFFDET_FUSE_SLOT_FLOATS 64
 int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, void* da, void* db,
                           void* dc, int da_accum, int db_accum, int dc_accum, const float* wraw, float* dn,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,

@@ -69,7 +69,7 @@ def test_dwconv_fwd_bwd(dtype, cfg):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8)])
+@pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8), (5, 3, 3, 144, 6), (2, 4, 4, 672, 28)])
 def test_squeeze_excite_fwd_bwd(dtype, cfg):
     """pool -> gate MLP -> channel scale, and the whole backward chain, vs torch autograd."""
     from efficientdet.pytorch_amd import ops
@@ -103,9 +103,7 @@ def test_squeeze_excite_fwd_bwd(dtype, cfg):
     assert_close(nchw(ymm), y.detach(), TOL[dtype], 'se scale')
     dym = nhwc(dy, dtype)
     dg = ops.se_dgate(dym, xm)
-    dw1 = torch.zeros(Cse, C, device=dev); db1 = torch.zeros(Cse, device=dev)
-    dw2 = torch.zeros(C, Cse, device=dev); db2 = torch.zeros(C, device=dev)
-    dpool = ops.se_gate_bwd(dg, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv, dw1, db1, dw2, db2)
+    dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dg, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
     dzm = ops.se_bwd_apply(dym, gd, dpool, zm)
     torch.cuda.synchronize()
     t = 5 * TOL[dtype]
