@@ -123,6 +123,22 @@ __device__ __forceinline__ void srd_dma16(__amdgpu_buffer_rsrc_t r, void* lds, u
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)lds, 16, (int)byte_off, 0, 0, 0);
 }
 
+// The same DMA as hand-written asm, for software-pipelined loops.  hipcc treats the builtin above as an LDS write
+// that may alias every later ds_read and puts `s_waitcnt vmcnt(0)` in front of the next LDS read -- i.e. the
+// prefetch of K-step k+1 is drained BEFORE the MFMAs of K-step k and overlaps with nothing.  Issued from asm the
+// load is invisible to the waitcnt pass; the loop itself waits (`dma_wait_all()` ahead of the barrier that
+// publishes the tile).  The 1 wait state between the M0 write and the LDS-DMA is the s_nop.
+__device__ __forceinline__ u32x4_t make_srd_raw(const void* base, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  return u32x4_t{(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)(lds_ptr_t)p; }
+__device__ __forceinline__ void dma16_async(u32x4_t rsrc, unsigned lds_byte_addr, unsigned byte_off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_byte_addr), "v"(byte_off), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // 4 consecutive elements (16 B fp32 / 8 B bf16) through an SRD -> 4 floats
 template <typename T> __device__ __forceinline__ f32x4 srd_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off);
 template <> __device__ __forceinline__ f32x4 srd_load4<float>(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {

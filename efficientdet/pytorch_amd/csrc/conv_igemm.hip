@@ -106,7 +106,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   // thread mapping is the per-thread constant (tid&7) ^ ((tid>>4)&7).  Halo / tail / K-padding lanes pass
   // EFFDET_OOB and the hardware writes zeros.  No staging VGPRs, no ds_write, no per-lane branches.
   constexpr unsigned ES = sizeof(T);
-  const __amdgpu_buffer_rsrc_t rx = make_srd((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd(p.w, p.w_bytes);
+  const u32x4_t rx = make_srd_raw((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd_raw(p.w, p.w_bytes);
+  const unsigned xs_a = lds_addr(xs), ws_a = lds_addr(ws);
   const int kc = (tid & 7) ^ ((tid >> 4) & 7), r0 = tid >> 3;
   const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * 8;     // first tile row of this wave's 1-KiB DMA piece
   unsigned xoff[XROWS]; int hi0[XROWS], wi0[XROWS];
@@ -148,11 +149,11 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     const bool kok = kq < p.Kc;
 #pragma unroll
     for (int j = 0; j < XROWS; ++j)
-      srd_dma16(rx, (void*)(xs + buf * XLD + (wrow0 + RSTEP * j) * 8), kok ? xcur[j] : EFFDET_OOB);
+      dma16_async(rx, xs_a + (unsigned)(buf * XLD + (wrow0 + RSTEP * j) * 8) * 16u, kok ? xcur[j] : EFFDET_OOB);
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       if (wrow0 + RSTEP * j < BN)     // wave-uniform: the whole 8-row piece is inside the weight tile
-        srd_dma16(rw, (void*)(ws + buf * WLD + (wrow0 + RSTEP * j) * 8), (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
+        dma16_async(rw, ws_a + (unsigned)(buf * WLD + (wrow0 + RSTEP * j) * 8) * 16u, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     }
     // advance the cursor by one K-step (8 chunks)
     kq += 8; cc += 8;
@@ -173,11 +174,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 
   const int nk = (p.Kc + 7) >> 3;
   stage(0);
-  __syncthreads();                       // (the compiler drains the DMA with vmcnt(0) ahead of the barrier)
   const int l15 = lane & 15, lq = lane >> 4, lsw = l15 >> 1;  // swizzle term (row>>1)&7 for row%16 = l15
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1);     // DMA of the next K-step flies under this step's MFMAs
+    dma_wait_all();                      // this wave's pieces of K-step kt have landed ...
+    __syncthreads();                     // ... and so have everyone else's; all waves are done reading buffer cur^1
+    if (kt + 1 < nk) stage(cur ^ 1);     // DMA of the next K-step flies under this step's MFMAs (asm: no compiler drain)
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       uint4 wf[NT], xf[MT];
@@ -191,7 +193,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
         for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
     }
-    __syncthreads();
   }
 
   // ---- epilogue: lane holds channels n0..n0+3 (rows of D) of pixel m (column of D) ----

@@ -22,6 +22,10 @@
 //     operand (blocks of j-tile 0 only).
 #include "common.h"
 
+#ifndef EFFDET_WGRAD_TR_WAVES
+#define EFFDET_WGRAD_TR_WAVES 8
+#endif
+
 namespace {
 
 struct WSeg {
@@ -282,6 +286,189 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// bf16 fast path: direct-to-LDS DMA staging + the gfx950 LDS transpose read (ds_read_b64_tr_b16).
+//
+// The register transpose above costs ~7 VALU per MFMA (PMC: MFMA pipe 24 % busy).  Here the tiles go from global
+// memory to LDS untouched -- [pixel][channel], the NHWC order -- and the transposition happens in the LDS read:
+// within a 16-lane group, lane s points at 4 consecutive channels of pixel-row (s>>2), columns 4*(s&3).., and
+// receives channel-column s of those 4 pixel rows, i.e. 4 consecutive REDUCTION elements of its MFMA row.  Two
+// such reads make one 16x16x32 operand.  Which pixel sits in which k-slot is irrelevant as long as both operands
+// agree: group q takes rows {4q..4q+3} and {16+4q..16+4q+3} of the 32-pixel k-step, so the 32 lanes that share an
+// LDS cycle read 8 consecutive pixel rows.
+//   LDS image, per operand and stage (64 pixels x 128 channels = 16 KiB): 16 pieces of 8 pixels x 64 channels
+//   (1 KiB = ONE wave-wide DMA instruction, 8 fully used 128-byte lines of global memory).  Inside a piece row r
+//   is 128 B and its 32-byte channel blocks are XOR-swizzled at the SOURCE (slot c holds block c ^ ((r>>1)&3)),
+//   which makes the 8 rows x 32 B of a half-wave read tile all 64 banks (probe: tools/probe/tr_bank.hip).
+//   Halo taps, ragged channel tails, K padding and the pixels past the split's end are EFFDET_OOB lanes = zeros.
+//   Addressing is scalar: a piece's 8 pixels are part of one image row (Wo % 8 == 0) or whole rows of one image
+//   (Wo = 4, 2, 1), so the wave keeps ONE pixel cursor in SGPRs, border validity is an OR of precomputed 64-bit lane
+//   masks, and a lane spends 2 VALU per piece.
+// Eligibility (host, per pyramid level): stride 1, 'same' geometry with taps in [-1, 1] (3x3 pad 1 or 1x1), the
+// row condition above, 16-byte aligned rows; contiguous pointwise convs are canonicalised to one long image row.
+// Levels that do not qualify (e.g. the stride-2 stem) run the register-transpose kernel in a second launch.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ unsigned oob_if(unsigned long long mask, unsigned val) {   // mask[lane] ? EFFDET_OOB : val
+  return __builtin_amdgcn_inverse_ballot_w64(mask) ? EFFDET_OOB : val;                 // one v_cndmask on an SGPR-pair mask
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) {
+  constexpr int WJ = NW / 2;                    // waves along j (2 along n): 4 waves = 2x2 of 64x64, 8 waves = 2x4 of 64x32
+  constexpr int WTJ = 128 / WJ, JT = WTJ / 16;
+  constexpr int BKM = 64;                       // pixels per stage (two 32-pixel MFMA k-steps)
+  constexpr unsigned OPB = 16384, BUFB = 2 * OPB;
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn0 = (wave / WJ) * 64, wj0 = (wave % WJ) * WTJ;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = logical % p.ntiles, jt = (logical / p.ntiles) % p.jtiles, split = logical / (p.ntiles * p.jtiles);
+  int si = 0;
+#pragma unroll
+  for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+    if (s < p.nseg && split >= p.seg[s].split_start) si = s;
+  const WSeg sg = p.seg[si];
+  const int m_begin = (split - sg.split_start) * p.mchunk;
+  const int m_end = min(sg.M, m_begin + p.mchunk);
+  const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
+
+  // ---- staging: wave w owns row groups w, w+NW, .. (8 pixels each) of every stage and issues all four pieces of a
+  //      group -- dz / x operand x two 64-channel halves -- from ONE scalar pixel cursor (the scalar unit is shared
+  //      by the CU's four SIMDs: per-piece cursors cost 8 SALU per MFMA and were the bottleneck) ----
+  const int Wr = sg.Wo < 8 ? sg.Wo : 8, RP = 8 / Wr;                        // pixels per image row / image rows per piece
+  const int r = lane >> 3, g = (lane & 7) ^ (((r >> 1) & 3) << 1);       // pixel in the piece, SOURCE 16-byte chunk
+  const int dho = r / Wr, dwo = r - dho * Wr;
+  int off_z[2], off_x[2];
+  unsigned long long mz_inv[2], mx_inv[2], mx_up[2], mx_dn[2], mx_lf[2], mx_rt[2];
+#pragma unroll
+  for (int hf = 0; hf < 2; ++hf) {
+    const int n = nt * 128 + hf * 64 + g * 8;
+    off_z[hf] = (r * p.lddz + n) * 2;
+    mz_inv[hf] = __ballot(n + 8 > p.lddz);
+    const int jq = jt * 16 + hf * 8 + g;
+    const bool jok = jq < p.Kc;
+    const int tap = jok ? jq / p.cpt : 0, cc = jok ? jq - tap * p.cpt : 0;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dkh = kh - p.pad_t, dkw = kw - p.pad_l;
+    off_x[hf] = ((dkh * sg.W + dkw + r) * p.ldx + cc * 8) * 2;
+    mx_inv[hf] = __ballot(!jok);
+    mx_up[hf] = __ballot(dkh < 0 && dho == 0); mx_dn[hf] = __ballot(dkh > 0 && dho == RP - 1);
+    mx_lf[hf] = __ballot(dkw < 0 && dwo == 0); mx_rt[hf] = __ballot(dkw > 0 && dwo == Wr - 1);
+  }
+  const u32x4_t srd_x = make_srd_raw((const bf16_t*)p.x + sg.in_off, sg.x_bytes);
+  const u32x4_t srd_z = make_srd_raw((const bf16_t*)p.dz + sg.out_off, sg.dz_bytes);
+  const unsigned x_bs = (unsigned)(sg.in_bs * 2), x_ld = (unsigned)(p.ldx * 2), z_bs = (unsigned)(sg.out_bs * 2), z_ld = (unsigned)(p.lddz * 2);
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned dst0 = lds0 + (unsigned)wave * 2048u;
+
+  // scalar pixel cursor of the wave's next row group (an aligned run of 8 pixels = RP whole image rows or part of one)
+  const int HoWo = sg.Ho * sg.Wo;
+  int cm = m_begin + 8 * wave;
+  int cb = cm / HoWo, crem = cm - cb * HoWo;
+  int cho = crem / sg.Wo, cwo = crem - cho * sg.Wo;
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 8 / NW; ++i) {
+      const unsigned long long past = (cm >= m_end) ? ~0ull : 0ull;
+      const unsigned long long c_up = (cho == 0) ? ~0ull : 0ull, c_dn = (cho == sg.Ho - RP) ? ~0ull : 0ull;
+      const unsigned long long c_lf = (cwo == 0) ? ~0ull : 0ull, c_rt = (cwo == sg.Wo - Wr) ? ~0ull : 0ull;
+      const unsigned pix = (unsigned)(cho * sg.Wo + cwo);
+      const unsigned zb = (unsigned)cb * z_bs + pix * z_ld, xb = (unsigned)cb * x_bs + pix * x_ld;
+      const unsigned dst = dst0 + (unsigned)buf * BUFB + (unsigned)(i * NW) * 2048u;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        dma16_async(srd_z, dst + (unsigned)hf * 1024u, oob_if(mz_inv[hf] | past, zb + (unsigned)off_z[hf]));
+        const unsigned long long inv = mx_inv[hf] | past | (c_up & mx_up[hf]) | (c_dn & mx_dn[hf]) | (c_lf & mx_lf[hf]) | (c_rt & mx_rt[hf]);
+        dma16_async(srd_x, dst + OPB + (unsigned)hf * 1024u, oob_if(inv, xb + (unsigned)off_x[hf]));
+      }
+      cm += 8 * NW; cwo += 8 * NW;
+      while (cwo >= sg.Wo) { cwo -= sg.Wo; if (++cho == sg.Ho) { cho = 0; ++cb; } }
+    }
+  };
+
+  // ---- fragment read addresses (bytes, stage-relative): see the layout note above ----
+  const int s16 = lane & 15, q = lane >> 4, jrow = s16 >> 2;
+  const unsigned lane_base = (unsigned)(q >> 1) * 2048u + (unsigned)((q & 1) * 4 + jrow) * 128u + (unsigned)(s16 & 3) * 8u;
+  const int xr = (q & 1) * 2 + (jrow >> 1);
+  unsigned a_addr[4], b_addr[JT];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) a_addr[a] = lds0 + lane_base + (unsigned)(wn0 >> 6) * 1024u + (unsigned)((a ^ xr) * 32);
+#pragma unroll
+  for (int b = 0; b < JT; ++b) {
+    const int cbk = (wj0 >> 4) + b;
+    b_addr[b] = lds0 + OPB + lane_base + (unsigned)(cbk >> 2) * 1024u + (unsigned)(((cbk & 3) ^ xr) * 32);
+  }
+  auto frag = [&](unsigned addr) -> uint4 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(addr + 4096u));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  };
+
+  f32x4 acc[4][JT], bsum[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    bsum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < JT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_bias = (p.dbias != nullptr) && (jt == 0) && (wj0 == 0);
+  const uint4 ones = WMma<bf16_t>::ones();
+  const int l15 = lane & 15, lq = lane >> 4;
+  float* slab = p.slab + (long long)split * p.Cout * p.K;
+
+  if (nsteps > 0) {
+    stage(0);
+    for (int kt = 0; kt < nsteps; ++kt) {
+      const unsigned cur = (unsigned)(kt & 1) * BUFB;
+      dma_wait_all();
+      __syncthreads();
+      if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        uint4 af[4], bf[JT];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) af[a] = frag(a_addr[a] + cur + (unsigned)ks * 8192u);
+#pragma unroll
+        for (int b = 0; b < JT; ++b) bf[b] = frag(b_addr[b] + cur + (unsigned)ks * 8192u);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < JT; ++b) WMma<bf16_t>::run(af[a], bf[b], acc[a][b]);
+        if (want_bias) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) WMma<bf16_t>::run(af[a], ones, bsum[a]);
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int n = nt * 128 + wn0 + a * 16 + lq * 4 + rr;
+        if (n >= p.Cout) continue;
+#pragma unroll
+        for (int b = 0; b < JT; ++b) {
+          const int j = jt * 128 + wj0 + b * 16 + l15;
+          if (j < p.K) slab[(long long)n * p.K + j] = acc[a][b][rr];
+        }
+        if (want_bias && l15 == 0) atomicAdd(p.dbias + n, bsum[a][rr]);
+      }
+    }
+  } else {
+    for (int i = tid; i < 128 * 128; i += NW * 64) {
+      const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
+      if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
+    }
+  }
+}
+
 // dw[i] += sum_s slab[s][i]      (16-byte vectorised, fully coalesced)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int splits) {
   const long long n4 = n >> 2;
@@ -385,6 +572,24 @@ extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
   return splits;
 }
 
+namespace {
+// Does pyramid level s qualify for the DMA + transpose-read kernel?  (see the eligibility note at that kernel)
+bool tr_eligible(const effdet_wgrad_t* p, const WgradK& k, int s) {
+  if (p->dtype != EFFDET_BF16 || !k.vec_a) return false;
+  const effdet_seg_t& g = p->seg[s];
+  if (p->stride != 1 || g.Ho != g.H || g.Wo != g.W) return false;
+  if (p->KH > 3 || p->KW > 3 || p->pad_t > 1 || p->pad_l > 1 || p->KH - 1 - p->pad_t > 1 || p->KW - 1 - p->pad_l > 1) return false;
+  if (p->ldx % 8 || p->lddz % 8 || g.in_off % 8 || g.out_off % 8 || g.in_bstride % 8 || g.out_bstride % 8) return false;
+  const long long M = (long long)p->B * g.Ho * g.Wo;
+  const bool pointwise_contig = p->KH == 1 && p->KW == 1 && g.in_bstride == (long long)g.H * g.W * p->ldx &&
+                                g.out_bstride == (long long)g.Ho * g.Wo * p->lddz;
+  if (pointwise_contig) return M % 8 == 0;
+  // an aligned run of 8 pixels must be part of one image row, or a whole number of rows of one image
+  return g.Wo % 8 == 0 || (8 % g.Wo == 0 && (g.Ho * g.Wo) % 8 == 0);
+}
+constexpr int TR_NW = EFFDET_WGRAD_TR_WAVES;
+}  // namespace
+
 extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
                                    effdet_stream_t stream) {
   if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
@@ -396,17 +601,46 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   k.slab = (float*)workspace;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid((unsigned)(k.ntiles * k.jtiles * splits));
-  if (p->dtype == EFFDET_F32) {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, k);
-  } else {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-    hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, k);
+  // Partition the pyramid levels between the two kernels; each launch numbers its own splits from 0 and owns a
+  // contiguous range of slabs (the slab order is irrelevant to the reduction).
+  WgradK kf = k, ks = k;            // fast (DMA + LDS transpose read) / slow (register transpose)
+  int nf = 0, ns = 0, sf = 0, ss = 0;
+  for (int s = 0; s < p->nseg; ++s) {
+    const int cnt = (int)((k.seg[s].M + k.mchunk - 1) / k.mchunk);
+    if (tr_eligible(p, k, s)) {
+      WSeg d = k.seg[s]; d.split_start = sf; sf += cnt;
+      if (p->KH == 1 && p->KW == 1 && d.in_bs == (long long)d.H * d.W * p->ldx && d.out_bs == (long long)d.Ho * d.Wo * p->lddz) {
+        d.H = d.Ho = 1; d.W = d.Wo = d.M;           // contiguous pointwise: one long image row, no wrap, no borders
+      }
+      kf.seg[nf++] = d;
+    } else {
+      WSeg d = k.seg[s]; d.split_start = ss; ss += cnt;
+      ks.seg[ns++] = d;
+    }
   }
-  EFFDET_CHECK_LAUNCH();
+  for (int s = nf; s < EFFDET_MAX_SEG; ++s) { kf.seg[s] = kf.seg[0]; kf.seg[s].split_start = 0x7fffffff; }
+  for (int s = ns; s < EFFDET_MAX_SEG; ++s) { ks.seg[s] = ks.seg[0]; ks.seg[s].split_start = 0x7fffffff; }
+  kf.nseg = nf; ks.nseg = ns;
+  ks.slab = k.slab + (long long)sf * n;
+  if (nf > 0) {
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TR_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    hipLaunchKernelGGL(conv_wgrad_tr_kernel<TR_NW>, dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(TR_NW * 64), lds, st, kf);
+    EFFDET_CHECK_LAUNCH();
+  }
+  if (ns > 0) {
+    dim3 grid((unsigned)(k.ntiles * k.jtiles * ss));
+    if (p->dtype == EFFDET_F32) {
+      static bool once = false;
+      if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+      hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, ks);
+    } else {
+      static bool once = false;
+      if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+      hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, ks);
+    }
+    EFFDET_CHECK_LAUNCH();
+  }
   if (p->dw) {   // optional packed accumulate; with dw == NULL the caller reduces the slabs in effdet_unpack_conv_wgrad
     long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);

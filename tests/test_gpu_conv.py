@@ -159,6 +159,41 @@ def test_wgrad_shapes(dtype):
     _run_wgrad(dtype, 1, 17, 17, 24, 32, 3, stride=2, pad=(0, 1, 0, 1))
     _run_wgrad(dtype, 4, 40, 40, 64, 64, 3)          # several K-splits
     _run_wgrad(dtype, 2, 1, 1, 64, 64, 3)
+    # bf16: shapes that take the DMA + LDS-transpose-read kernel with 8-pixel pieces made of whole image rows
+    _run_wgrad(dtype, 2, 4, 4, 256, 40, 3)
+    _run_wgrad(dtype, 3, 2, 4, 64, 64, 3)
+    _run_wgrad(dtype, 1, 6, 4, 32, 48, 3)
+    _run_wgrad(dtype, 2, 8, 16, 64, 64, 3)
+    _run_wgrad(dtype, 5, 4, 2, 64, 64, 3)
+    _run_wgrad(dtype, 3, 24, 24, 24, 144, 1, pad=(0, 0, 0, 0))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_grouped_pyramid(dtype):
+    """One wgrad launch over 5 pyramid levels that share a weight (levels split between the two bf16 kernels)."""
+    from efficientdet.pytorch_amd import functional as Fn, ops
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout = 3, 64, 72
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    xs = [torch.randn(B, Cin, h, w, generator=g) for h, w in sizes]
+    dzs = [torch.randn(B, Cout, h, w, generator=g) for h, w in sizes]
+    wt = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    sum((F.conv2d(q(x), wt, None, 1, 1) * q(dz)).sum() for x, dz in zip(xs, dzs)).backward()
+    dev = 'cuda'
+    _, xm = Fn.pyramid_alloc(B, sizes, Cin, dtype, dev)
+    _, zm = Fn.pyramid_alloc(B, sizes, Cout, dtype, dev)
+    for m, t in zip(xm + zm, xs + dzs):
+        Fn.level_tensor(m).copy_(t.permute(0, 2, 3, 1).to(dev, dtype))
+    gp = torch.zeros(Cout, 9, Cin, dtype=torch.float32, device=dev)
+    db = torch.zeros(Cout, dtype=torch.float32, device=dev)
+    ops.conv2d_wgrad(xm, zm, gp, db, Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=dev)
+    ops.unpack_wgrad(gp, dw)
+    torch.cuda.synchronize()
+    tol = 3e-4 if dtype == torch.float32 else 1e-2
+    assert_close(dw.cpu(), wt.grad, tol, 'pyramid wgrad')
+    assert_close(db.cpu(), sum(q(dz).sum(dim=(0, 2, 3)) for dz in dzs), tol, 'pyramid dbias')
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
