@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (must be imported first: the .so binds to torch's already-loaded libamdhip64)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libeffdet_hip.so')
+LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
@@ -42,11 +42,17 @@ class WgradDesc(C.Structure):
                 ('ldx', C.c_int), ('lddz', C.c_int), ('nseg', C.c_int), ('seg', Seg * MAX_SEG)]
 
 
+class PrepJob(C.Structure):      # effdet_prep_job_t
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('c', C.c_void_p), ('d', C.c_void_p), ('out', C.c_void_p),
+                ('kind', C.c_int), ('dtype', C.c_int), ('n0', C.c_int), ('n1', C.c_int), ('n2', C.c_int), ('n3', C.c_int),
+                ('n4', C.c_int), ('eps', C.c_float)]
+
+
 _lib = None
 
 # every symbol include/effdet_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    'effdet_conv2d', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad',
+    'effdet_conv2d', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',

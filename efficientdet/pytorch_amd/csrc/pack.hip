@@ -3,6 +3,23 @@
 
 namespace {
 
+// One element of a packed conv weight (shared by the single and the batched kernel).
+__device__ __forceinline__ float pack_elem(const float* __restrict__ w, long long i, int mode, int Cout, int Cin, int KH, int KW,
+                                           int Kpad, const float* __restrict__ scale, const float* __restrict__ gamma,
+                                           const float* __restrict__ var, float eps) {
+  const int taps = KH * KW;
+  const int c = (int)(i % Kpad), tap = (int)((i / Kpad) % taps), n = (int)(i / ((long long)Kpad * taps));
+  const int kh = tap / KW, kw = tap % KW;
+  const int co = mode == 0 ? n : c;
+  const bool in = mode == 0 ? c < Cin : c < Cout;
+  if (!in) return 0.f;
+  float v = mode == 0 ? w[(((long long)n * Cin + c) * KH + kh) * KW + kw]
+                      : w[(((long long)c * Cin + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+  if (scale) v *= scale[co];
+  else if (gamma) v *= gamma[co] * (1.0f / sqrtf(var[co] + eps));          // same expression as bn_fold_kernel
+  return v;
+}
+
 // mode 0: out[co][tap][ci]            = w[co][ci][kh][kw] * scale[co]
 // mode 1: out[ci][tap flipped][co]    = w[co][ci][KH-1-kh][KW-1-kw] * scale[co]   (data-gradient operand)
 template <typename T>
@@ -12,20 +29,35 @@ __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restri
   // mode 0 pads the inner Cin dim to Cin_pad; mode 1 pads the inner Cout dim to Cin_pad (named Kpad in the ABI)
   const long long total = mode == 0 ? (long long)Cout * Cin_pad * taps : (long long)Cin * Cin_pad * taps;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    // i indexes the OUTPUT (coalesced writes)
-    int c, tap, n;
-    if (mode == 0) { c = (int)(i % Cin_pad); tap = (int)((i / Cin_pad) % taps); n = (int)(i / ((long long)Cin_pad * taps)); }
-    else { c = (int)(i % Cin_pad); tap = (int)((i / Cin_pad) % taps); n = (int)(i / ((long long)Cin_pad * taps)); }
-    const int kh = tap / KW, kw = tap % KW;
-    float v;
-    if (mode == 0) {
-      v = c < Cin ? w[(((long long)n * Cin + c) * KH + kh) * KW + kw] : 0.f;   // zero-filled channel padding
-      if (scale) v *= scale[n];
-    } else {
-      v = c < Cout ? w[(((long long)c * Cin + n) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)] : 0.f;
-      if (scale && c < Cout) v *= scale[c];
-    }
-    Elem<T>::st(out + i, v);
+    // i indexes the OUTPUT (coalesced writes); padding entries are zero
+    Elem<T>::st(out + i, pack_elem(w, i, mode, Cout, Cin, KH, KW, Cin_pad, scale, nullptr, nullptr, 0.f));
+  }
+}
+
+// Batched parameter preparation (effdet_prepare_params): workgroup -> (job, 256-element slice) through two small tables.
+__global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_job_t* __restrict__ jobs,
+                                                             const int* __restrict__ block_job,
+                                                             const int* __restrict__ block_first) {
+  const int j = block_job[blockIdx.x];
+  const effdet_prep_job_t jb = jobs[j];
+  const long long i = (long long)(blockIdx.x - block_first[j]) * 256 + threadIdx.x;
+  if (jb.kind == EFFDET_PREP_PACK0 || jb.kind == EFFDET_PREP_PACK1) {
+    const int mode = jb.kind == EFFDET_PREP_PACK1;
+    const long long total = (long long)(mode == 0 ? jb.n0 : jb.n1) * jb.n4 * jb.n2 * jb.n3;
+    if (i >= total) return;
+    const float v = pack_elem(jb.a, i, mode, jb.n0, jb.n1, jb.n2, jb.n3, jb.n4, nullptr, jb.b, jb.c, jb.eps);
+    if (jb.dtype == EFFDET_F32) ((float*)jb.out)[i] = v; else ((bf16_t*)jb.out)[i] = f2bf(v);
+  } else if (jb.kind == EFFDET_PREP_BNFOLD) {
+    if (i >= jb.n0) return;
+    const float is = 1.0f / sqrtf(jb.d[i] + jb.eps);
+    const float sc = jb.a[i] * is;
+    float* o = (float*)jb.out;
+    o[i] = sc; o[jb.n0 + i] = jb.b[i] - jb.c[i] * sc; o[2 * jb.n0 + i] = is;
+  } else {
+    const int C = jb.n0, kk = jb.n2;
+    if (i >= (long long)C * kk) return;
+    const int t = (int)(i / C), c = (int)(i - (long long)t * C);
+    ((float*)jb.out)[i] = jb.a[c * kk + t];
   }
 }
 
@@ -106,6 +138,14 @@ inline int grid_for(long long n, int block = 256) {
 }
 
 }  // namespace
+
+extern "C" int effdet_prepare_params(const effdet_prep_job_t* jobs, const int* block_job, const int* block_first, int nblocks,
+                                     effdet_stream_t stream) {
+  if (!jobs || !block_job || !block_first || nblocks < 1) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(prepare_params_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, jobs, block_job, block_first);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
 
 extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void* out, int dtype, int mode,
                                        int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream) {

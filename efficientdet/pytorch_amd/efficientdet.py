@@ -129,12 +129,14 @@ def _t(m):
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train):
+        ctx.prep = ops.get_prep()
         y, saved = Fn.stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train)
         ctx.saved = saved if train else None
         return _t(y)
 
     @staticmethod
     def backward(ctx, dy):
+        ops.set_prep(ctx.prep)
         dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()))
         ctx.saved = None
         return None, dw, dg, db, None, None, None, None, None
@@ -147,6 +149,7 @@ _MB_KEYS = ('expand.weight', 'bn0.weight', 'bn0.bias', 'dw.weight', 'bn1.weight'
 class _MBConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, dtype, rowscale, buffers, train, *params):
+        ctx.prep = ops.get_prep()
         P = dict(buffers)
         keys = [k for k in _MB_KEYS if not (blk.expand == 1 and k in ('expand.weight', 'bn0.weight', 'bn0.bias'))]
         P.update(dict(zip(keys, params)))
@@ -156,6 +159,7 @@ class _MBConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        ops.set_prep(ctx.prep)
         dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
             ops.add_inplace(dx, Map.of(dy.contiguous()))
@@ -169,6 +173,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, nlev, stack, train, *args):
+        ctx.prep = ops.get_prep()
         feats = [Map.of(t) for t in args[:nlev]]
         rest = args[nlev:]
         lw, lb = rest[0:nlev], rest[nlev:2 * nlev]
@@ -187,6 +192,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
+        ops.set_prep(ctx.prep)
         feats, lw, saved_mods, dtype, nlev, stack = ctx.saved
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
@@ -211,6 +217,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, num_classes, anchors, annots, train, *args):
+        ctx.prep = ops.get_prep()
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
@@ -220,6 +227,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gcls, greg):
+        ops.set_prep(ctx.prep)
         saved, cls, reg, anchors, annots, ws, dtype = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
         dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
@@ -242,6 +250,8 @@ class EfficientDet(nn.Module):
         self.iou_threshold = iou_threshold
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
+        self._prep = {}                                         # (compute dtype, device) -> ops.ParamPrep (batched per-step repacks)
+        self.batched_prep = True                                # False: every repack is its own launch (debug / A-B)
         for m in self.modules():                                # models/efficientdet.py:47-53
             if isinstance(m, nn.Conv2d):
                 n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
@@ -274,8 +284,21 @@ class EfficientDet(nn.Module):
         if not img.is_cuda:
             raise RuntimeError('efficientdet.pytorch_amd runs on MI355X only: inputs must be on a GPU (no CPU fallback)')
 
+    def _apply(self, fn, *a, **k):
+        self._prep = {}                                         # parameter storage may move: drop the recorded job tables
+        return super()._apply(fn, *a, **k)
+
     def _backbone(self, img):
         bb, dt = self.backbone, self.compute_dtype
+        # every forward path starts here: replay (or start recording) this model's batched parameter preparation
+        key = (dt, img.device)
+        if not self.batched_prep:
+            ops.set_prep(None)
+        else:
+            if key not in self._prep:
+                self._prep[key] = ops.ParamPrep()
+            ops.set_prep(self._prep[key])
+            self._prep[key].begin_step()
         bn = bb._bn0
         train = torch.is_grad_enabled()
         x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train)

@@ -98,6 +98,26 @@ int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_
                              float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
                              effdet_stream_t stream);
 
+/* Batched parameter preparation: every per-step repack of the model's parameters in ONE launch (a D0 train step
+ * issued ~190 of these 4-microsecond kernels one by one: 125 weight packs, 48 BN folds, 16 depthwise packs).
+ * A job is one of
+ *   EFFDET_PREP_PACK0 / _PACK1   effdet_pack_conv_weight mode 0 / 1   (a: OIHW weight; scale = b/sqrt(c+eps) when
+ *                                b (gamma) and c (running_var) are given -- the BN fold is recomputed inline so the
+ *                                jobs of one launch are independent)
+ *   EFFDET_PREP_BNFOLD           effdet_bn_fold      (a gamma, b beta, c mean, d var -> out = scale|shift|invstd, 3*n0)
+ *   EFFDET_PREP_DWPACK           effdet_dw_pack_weight (a: [C][1][k][k] -> out [k*k][C] fp32;  n0 = C, n2 = k*k)
+ * jobs / block_job / block_first are DEVICE arrays: workgroup i handles elements [256*(i - block_first[j]), +256) of job
+ * j = block_job[i].  The table is built once per model (parameter storage is stable) and replayed every step. */
+enum { EFFDET_PREP_PACK0 = 0, EFFDET_PREP_PACK1 = 1, EFFDET_PREP_BNFOLD = 2, EFFDET_PREP_DWPACK = 3 };
+typedef struct {
+  const float* a; const float* b; const float* c; const float* d; void* out;
+  int kind, dtype;         /* dtype of `out` for the PACK jobs (EFFDET_F32 / EFFDET_BF16) */
+  int n0, n1, n2, n3, n4;  /* PACK: Cout, Cin, KH, KW, Kpad;  BNFOLD: C;  DWPACK: C, -, k*k */
+  float eps;
+} effdet_prep_job_t;
+int effdet_prepare_params(const effdet_prep_job_t* jobs, const int* block_job, const int* block_first, int nblocks,
+                          effdet_stream_t stream);
+
 /* Frozen (eval-mode) BatchNorm2d as a per-channel affine (models/efficientdet.py:88-92, eps 1e-3):
  *   scale = gamma/sqrt(var+eps), shift = beta - mean*scale, invstd = 1/sqrt(var+eps). */
 int effdet_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
