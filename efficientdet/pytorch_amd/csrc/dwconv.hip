@@ -462,6 +462,149 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
   flush(ds, K * K);
 }
 
+
+// LDS-tiled weight gradient.  The direct kernel above re-reads every input element k*k times through the L1/TA path
+// (25 eight-byte loads per pixel for k = 5) and ran at ~1 TB/s of algorithmic bytes.  Here a workgroup walks `ppt`
+// forward tiles of one image (same DMA-staged halo tile as the forward kernel), each thread owning CPT channels of a
+// run of consecutive output pixels of one tile row, so that for stride 1 a tap row is a sliding window over
+// NOUT + K - 1 LDS values instead of NOUT * K.  The k*k*CPT accumulators stay in registers across all tiles; one
+// shuffle + LDS reduction per workgroup writes its slab row (summed by dw_wgrad_reduce_kernel).
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
+  typedef DwTile<K, S> TL;
+  constexpr int CE = Elem<T>::CE;
+  constexpr unsigned ES = sizeof(T);
+  constexpr int CPT = (K == 5 && CE == 8) ? 4 : CE;       // channels per thread: K*K*CPT accumulators must fit in registers
+  constexpr int NCG = 8 * CE / CPT, NPS = 256 / NCG;      // channel groups per 8-chunk slab, pixel slots
+  constexpr int NPIX = TL::TH * TL::TW, NOUT = NPIX / NPS;
+  constexpr int ROWS = K * K + 1;
+  static_assert(S == 2 || NOUT <= TL::TW, "stride 1: a thread's pixels are one run inside a tile row");
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];
+  uint4* xt = sm;                                        // [NPIECE*8 pixel slots][8 chunks]; reused for the final reduction
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
+  const int groups = (tpi + p.ppt - 1) / p.ppt;
+  const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = blockIdx.y * 8;
+  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
+  const __amdgpu_buffer_rsrc_t rz = make_srd(p.aux, (unsigned)((long long)p.B * p.Ho * p.Wo * p.C * ES));   // dz (host checks < 4 GiB)
+  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
+  const unsigned dz_img = (unsigned)((long long)b * p.Ho * p.Wo * p.C * ES);
+  const int cg = tid % NCG, ps = tid / NCG;
+  const int c0 = chunk0 * CE + cg * CPT;                  // first channel of this thread
+  const bool cok = c0 < p.C;
+  const unsigned lds_c = (unsigned)(cg * CPT) * ES;       // byte offset of the thread's channels inside a pixel's 128-B row
+  const int st_pl = lane >> 3, st_cq = lane & 7;
+  const bool st_cok = chunk0 + st_cq < p.nch;
+
+  float g[K * K][CPT], ds[CPT];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t)
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) g[t][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < CPT; ++e) ds[e] = 0.f;
+
+  auto ldx = [&](int slot, float* v) {                   // CPT channels of one staged pixel
+    const char* q = (const char*)xt + (unsigned)slot * 128u + lds_c;
+    if constexpr (CPT * ES == 16) {
+      Chunk<T>::unpack(*(const uint4*)q, v);
+    } else {                                              // bf16, 4 channels = 8 bytes
+      const uint2 u = *(const uint2*)q;
+      v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+      v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    }
+  };
+
+  for (int tile = t0; tile < t1; ++tile) {
+    const int oh0 = (tile / tiles_x) * TL::TH, ow0 = (tile % tiles_x) * TL::TW;
+    const int hi_org = oh0 * S - p.pad_t, wi_org = ow0 * S - p.pad_l;
+    __syncthreads();                                      // every wave is done reading the previous tile
+    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
+      const int q = piece * 8 + st_pl;
+      int ih = q / TL::IWP, r = q - ih * TL::IWP, iw;
+      if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
+      const int hi = hi_org + ih, wi = wi_org + iw;
+      const bool ok = st_cok && q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      srd_dma16(rx, (void*)(xt + piece * 64), ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + st_cq) * CE) * ES : EFFDET_OOB);
+    }
+    // this thread's dz values (zeros outside the image / channel range: no branches in the accumulation)
+    float d[NOUT][CPT];
+    int oh_l, ow_l;
+    if (S == 1) { oh_l = (ps * NOUT) / TL::TW; ow_l = (ps * NOUT) % TL::TW; } else { oh_l = 0; ow_l = 0; }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      int oh, ow;
+      if (S == 1) { oh = oh0 + oh_l; ow = ow0 + ow_l + o; }
+      else { const int op = ps + NPS * o; oh = oh0 + op / TL::TW; ow = ow0 + op % TL::TW; }
+      const bool ok = cok && oh < p.Ho && ow < p.Wo;
+      const unsigned off = ok ? dz_img + (unsigned)((oh * p.Wo + ow) * p.C + c0) * ES : EFFDET_OOB;
+      if constexpr (CPT == 4) {
+        const f32x4 v = srd_load4<T>(rz, off);
+        d[o][0] = v[0]; d[o][1] = v[1]; d[o][2] = v[2]; d[o][3] = v[3];
+      } else {
+        Chunk<T>::unpack(srd_load16(rz, off), d[o]);
+      }
+#pragma unroll
+      for (int e = 0; e < CPT; ++e) ds[e] += d[o][e];
+    }
+    __syncthreads();                                      // (hipcc drains the DMA ahead of the barrier)
+    if (S == 1) {
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        float xr[NOUT + K - 1][CPT];
+#pragma unroll
+        for (int j = 0; j < NOUT + K - 1; ++j) ldx(TL::slot(oh_l + kh, ow_l + j), xr[j]);
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[kh * K + kw][e] = fmaf(d[o][e], xr[o + kw][e], g[kh * K + kw][e]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) {
+            const int op = ps + NPS * o, oh = op / TL::TW, ow = op % TL::TW;
+            float xv[CPT];
+            ldx(TL::slot(oh * S + kh, ow * S + kw), xv);
+#pragma unroll
+            for (int e = 0; e < CPT; ++e) g[kh * K + kw][e] = fmaf(d[o][e], xv[e], g[kh * K + kw][e]);
+          }
+        __builtin_amdgcn_sched_barrier(0);                // one tap row of LDS reads in flight (the full hoist spilled)
+      }
+    }
+  }
+  // ---- reduce over the pixel slots: shuffles inside the wave, then the 4 waves through LDS (tile memory reused) ----
+  __syncthreads();
+  float* red = (float*)sm;                                // [4 waves][ROWS][8*CE]
+  auto wred = [&](float v) {
+#pragma unroll
+    for (int o = 32; o >= NCG; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+#pragma unroll
+  for (int t = 0; t < ROWS; ++t) {
+#pragma unroll
+    for (int e = 0; e < CPT; ++e) {
+      const float v = wred(t < K * K ? g[t < K * K ? t : 0][e] : ds[e]);
+      if (lane < NCG) red[(wave * ROWS + t) * (8 * CE) + cg * CPT + e] = v;
+    }
+  }
+  __syncthreads();
+  float* slab = (float*)p.y + (long long)blockIdx.x * ROWS * p.C;
+  for (int i = tid; i < ROWS * 8 * CE; i += 256) {
+    const int t = i / (8 * CE), c = i - t * (8 * CE);
+    const int ch = chunk0 * CE + c;
+    if (ch < p.C) slab[(long long)t * p.C + ch] = red[i] + red[ROWS * 8 * CE + i] + red[2 * ROWS * 8 * CE + i] + red[3 * ROWS * 8 * CE + i];
+  }
+}
+
 // out[row][c] = sum_blocks slab[block][row][c]   (rows = k*k taps + 1 dsum row).
 // 256 threads = 64 consecutive elements x 4 block-slices; each thread strides its slice (4 loads in flight),
 // the 4 slices are combined through LDS.
@@ -537,6 +680,19 @@ int launch_dgrad_lds(const DwK& a, hipStream_t st) {
   hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
+template <typename T, int K, int S>
+int launch_wgrad_lds(const DwK& a, hipStream_t st) {
+  typedef DwTile<K, S> TL;
+  size_t lds = (size_t)TL::NPIECE * 1024;
+  const size_t red = (size_t)4 * (K * K + 1) * 8 * Elem<T>::CE * 4;
+  if (red > lds) lds = red;
+  const int tpi = ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW);
+  dim3 grid(a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + 7) / 8);
+  static bool once = false;
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_wgrad_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  return EFFDET_OK;
+}
 #define DW_DISPATCH(FN, dtype, k, s, a, st)                                                    \
   do {                                                                                         \
     if ((dtype) == EFFDET_F32) {                                                               \
@@ -582,15 +738,32 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
 }
 
 namespace {
+// tiny maps (<= 8x8 outputs): a 16x8 tile is mostly halo and padding -- the direct kernel is faster there
+inline bool wgrad_direct(int Ho, int Wo) { return Ho * Wo <= 64; }
+
 int wgrad_plan(DwK& a, dim3& grid, int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo) {
-  int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, Ho * Wo, grid);
+  if (wgrad_direct(Ho, Wo)) {
+    int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, Ho * Wo, grid);
+    if (rc) return rc;
+    const int TY = 256 / a.tx;
+    int ppt = 64;
+    while (ppt > 1 && (long long)B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)) * ((a.nch + a.tx - 1) / a.tx) < 512) ppt >>= 1;
+    a.ppt = ppt;
+    grid = dim3(B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)), (a.nch + a.tx - 1) / a.tx);
+    return EFFDET_OK;
+  }
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, ce, Ho * Wo, grid);
   if (rc) return rc;
-  // fat blocks (every block ends in a slab row write + is one term of the reduce), but >= ~512 of them
-  const int TY = 256 / a.tx;
-  int ppt = 64;
-  while (ppt > 1 && (long long)B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)) * ((a.nch + a.tx - 1) / a.tx) < 512) ppt >>= 1;
-  a.ppt = ppt;
-  grid = dim3(B * ((Ho * Wo + TY * ppt - 1) / (TY * ppt)), (a.nch + a.tx - 1) / a.tx);
+  // forward tiles (16x8 at stride 1, 8x8 at stride 2) walked `ppt` at a time by one workgroup: fat workgroups (each
+  // ends in a reduction + a slab row that the reduce kernel has to sum), but at least ~768 of them
+  const int th = stride == 1 ? 16 : 8, tw = 8;
+  const int tpi = ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw), nslab = (a.nch + 7) / 8;
+  long long ppt = (long long)tpi * B * nslab / 768;
+  if (ppt < 1) ppt = 1;
+  if (ppt > 16) ppt = 16;
+  a.ppt = (int)ppt;
+  grid = dim3(B * ((tpi + a.ppt - 1) / a.ppt), nslab);
   return EFFDET_OK;
 }
 }  // namespace
@@ -613,12 +786,17 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
   a.x = x; a.aux = dz; a.y = workspace;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) {
-    if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<float, 3>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<float, 5>), grid, dim3(256), 0, st, a);
+  if ((long long)B * Ho * Wo * C * (dtype == EFFDET_F32 ? 4 : 2) >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
+  if (wgrad_direct(Ho, Wo)) {
+    if (dtype == EFFDET_F32) {
+      if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<float, 3>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_wgrad_kernel<float, 5>), grid, dim3(256), 0, st, a);
+    } else {
+      if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a);
+    }
   } else {
-    if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a);
+    DW_DISPATCH(launch_wgrad_lds, dtype, k, stride, a, st);
   }
   EFFDET_CHECK_LAUNCH();
   const int rows = k * k + 1;

@@ -26,7 +26,8 @@ def nchw(m):
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cfg', [(2, 16, 16, 32, 3, 1, (1, 1)), (2, 17, 17, 96, 3, 2, (0, 1)), (1, 16, 16, 144, 5, 2, (1, 2)),
                                  (2, 8, 8, 240, 5, 1, (2, 2)), (3, 4, 4, 1152, 3, 2, (0, 1)), (2, 9, 7, 672, 5, 1, (2, 2)),
-                                 (2, 2, 2, 1152, 3, 2, (0, 1))])
+                                 (2, 2, 2, 1152, 3, 2, (0, 1)), (2, 40, 24, 48, 5, 1, (2, 2)), (2, 33, 33, 40, 5, 2, (1, 2)),
+                                 (4, 64, 64, 64, 3, 1, (1, 1))])
 def test_dwconv_fwd_bwd(dtype, cfg):
     from efficientdet.pytorch_amd import ops
     B, H, W, C, k, s, (plo, phi) = cfg
