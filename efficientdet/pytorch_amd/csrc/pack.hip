@@ -67,7 +67,10 @@ __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_j
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ scale,
                                                            const float* __restrict__ w, float* __restrict__ dw,
                                                            float* __restrict__ wsum, int accumulate, int Cin, int KH, int KW,
-                                                           int Cin_pad, int nslabs, long long slab_stride) {
+                                                           int Cin_pad, int nslabs, long long slab_stride,
+                                                           const float* __restrict__ dsum, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
   const int co = blockIdx.x, taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
   const float* grow = g + (long long)co * np;
@@ -91,16 +94,23 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     for (int e = 0; e < 4; ++e) {
       if (ci + e >= Cin) continue;
       const long long o = (long long)co * n + (ci + e) * taps + tap;
-      if (wsum) part += w[o] * gv[e];
+      if (wsum || dgamma) part += w[o] * gv[e];
       dw[o] = accumulate ? dw[o] + s * gv[e] : s * gv[e];
     }
   }
-  if (wsum) {
+  if (wsum || dgamma) {
     __shared__ float red[4];
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) wsum[co] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+      const float ws = red[0] + red[1] + red[2] + red[3];
+      if (wsum) wsum[co] = ws;
+      if (dgamma) {            // frozen-BN parameter gradients (same arithmetic as bn_param_grad_kernel), no extra launch
+        dgamma[co] = invstd[co] * (ws - mean[co] * dsum[co]);
+        dbeta[co] = dsum[co];
+      }
+    }
   }
 }
 
@@ -169,7 +179,19 @@ extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, cons
   const int np = KH * KW * Cin_pad;
   const int gy = wsum ? 1 : (np / 4 + 255) / 256;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, gy), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW,
-                     Cin_pad, nslabs, (long long)Cout * np);
+                     Cin_pad, nslabs, (long long)Cout * np, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w, float* dw, const float* dsum,
+                                           const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout,
+                                           int Cin, int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream) {
+  if (!g || !dw || !w || !dsum || !mean || !invstd || !dgamma || !dbeta || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
+  const int np = KH * KW * Cin_pad;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, 1), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, (float*)nullptr, 0, Cin, KH,
+                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum, mean, invstd, dgamma, dbeta);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

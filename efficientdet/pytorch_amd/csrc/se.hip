@@ -267,13 +267,15 @@ __global__ void dw_pack_kernel(const float* w, float* out, int C, int kk) {
   const int t = i / C, c = i - t * C;
   out[i] = w[c * kk + t];
 }
-__global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const float* w, float* dw, float* wsum, int C, int kk) {
+__global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const float* w, float* dw, float* wsum, int C, int kk,
+                                      const float* dsum, const float* mean, const float* invstd, float* dgamma, float* dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const float s = scale ? scale[c] : 1.f;
   float acc = 0.f;
   for (int t = 0; t < kk; ++t) { const float gv = g[t * C + c]; dw[c * kk + t] = s * gv; acc = fmaf(w[c * kk + t], gv, acc); }
   if (wsum) wsum[c] = acc;
+  if (dgamma) { dgamma[c] = invstd[c] * (acc - mean[c] * dsum[c]); dbeta[c] = dsum[c]; }     // = bn_param_grad_kernel
 }
 
 }  // namespace
@@ -406,7 +408,17 @@ extern "C" int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C,
 extern "C" int effdet_dw_unpack_wgrad(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk, float* wsum,
                                       int C, int k, effdet_stream_t stream) {
   if (!g_kkc || !w_c1kk || !dw_c1kk) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, wsum, C, k * k);
+  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, wsum, C, k * k,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+extern "C" int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk,
+                                         const float* dsum, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                         int C, int k, effdet_stream_t stream) {
+  if (!g_kkc || !w_c1kk || !dw_c1kk || !dsum || !mean || !invstd || !dgamma || !dbeta) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, (float*)nullptr, C,
+                     k * k, dsum, mean, invstd, dgamma, dbeta);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -69,9 +69,7 @@ def stem_bwd(saved, dy):
     ar = ZeroArena(ZeroArena.need(Cout), w.device)
     dsum = ar.take(Cout)
     G = ops.conv2d_wgrad(x, dz, None, dsum, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
-    dw = torch.empty_like(w); wsum = torch.empty(Cout, dtype=torch.float32, device=w.device)
-    ops.unpack_wgrad(G, dw, scale=s, w_oihw=w, wsum=wsum, cin_pad=ce)
-    dg, db = ops.bn_param_grad(wsum, dsum, mean, inv)
+    dw, dg, db = ops.unpack_wgrad_bn(G, w, s, dsum, mean, inv, cin_pad=ce)     # + frozen-BN gamma/beta grads, one launch
     return dw, dg, db
 
 
@@ -125,10 +123,7 @@ def mbconv_bwd(sv, dy):
     dsum2 = ar.take(Co)
     G2 = ops.conv2d_wgrad(sv['xs'], dz2, None, dsum2, Cin=Ce, Cout=Co, KH=1, KW=1)
     wp = P['project.weight']
-    dwp = torch.empty_like(wp); wsum2 = torch.empty(Co, dtype=torch.float32, device=dev)
-    ops.unpack_wgrad(G2, dwp, scale=sv['s2'], w_oihw=wp, wsum=wsum2)
-    g['project.weight'] = dwp
-    g['bn2.weight'], g['bn2.bias'] = ops.bn_param_grad(wsum2, dsum2, P['bn2.running_mean'], sv['i2'])
+    g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'])
     dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
     ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
     # ---- squeeze-excite ----
@@ -141,9 +136,8 @@ def mbconv_bwd(sv, dy):
     dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
     # ---- depthwise ----
     gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0])
-    wsum1 = torch.empty(Ce, dtype=torch.float32, device=dev)
-    g['dw.weight'] = ops.dw_unpack_wgrad(gk, sv['s1'], P['dw.weight'], wsum1)
-    g['bn1.weight'], g['bn1.bias'] = ops.bn_param_grad(wsum1, dsum1, P['bn1.running_mean'], sv['i1'])
+    g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,
+                                                                             P['bn1.running_mean'], sv['i1'])
     dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else None, H, W, blk.k, blk.stride,
                            blk.pad[0], blk.pad[0])
     if blk.expand == 1:
@@ -152,10 +146,7 @@ def mbconv_bwd(sv, dy):
     dsum0 = ar.take(Ce)
     G0 = ops.conv2d_wgrad(x, dze, None, dsum0, Cin=Ci, Cout=Ce, KH=1, KW=1)
     we = P['expand.weight']
-    dwe = torch.empty_like(we); wsum0 = torch.empty(Ce, dtype=torch.float32, device=dev)
-    ops.unpack_wgrad(G0, dwe, scale=sv['s0'], w_oihw=we, wsum=wsum0)
-    g['expand.weight'] = dwe
-    g['bn0.weight'], g['bn0.bias'] = ops.bn_param_grad(wsum0, dsum0, P['bn0.running_mean'], sv['i0'])
+    g['expand.weight'], g['bn0.weight'], g['bn0.bias'] = ops.unpack_wgrad_bn(G0, we, sv['s0'], dsum0, P['bn0.running_mean'], sv['i0'])
     dx = Map.new(B, H, W, Ci, dtype, dev)
     ops.conv2d(dze, ops.pack_weight(we, dtype, mode=1, scale=sv['s0']), dx, Cin=Ce, Cout=Ci, KH=1, KW=1,
                res=dy if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)

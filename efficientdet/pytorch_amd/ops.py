@@ -273,6 +273,19 @@ def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=Fals
                                              nslabs, L.stream_ptr()), 'effdet_unpack_conv_wgrad')
 
 
+def unpack_wgrad_bn(g, w_oihw, scale, dsum, mean, invstd, cin_pad=None):
+    """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta)."""
+    Cout, Cin, KH, KW = w_oihw.shape
+    nslabs = g.shape[0] if g.dim() == 4 else 1
+    dw = torch.empty_like(w_oihw)
+    dgb = torch.empty((2, Cout), dtype=torch.float32, device=dw.device)
+    L.check(L.lib().effdet_unpack_conv_wgrad_bn(L.ptr(g), L.ptr(scale), L.ptr(w_oihw.detach()), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
+                                                L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cout, Cin, KH, KW,
+                                                Cin if cin_pad is None else cin_pad, nslabs, L.stream_ptr()),
+            'effdet_unpack_conv_wgrad_bn')
+    return dw, dgb[0], dgb[1]
+
+
 def nhwc_to_nchw(m):
     out = torch.empty((m.B, m.C, m.H, m.W), dtype=torch.float32, device=m.t.device)
     L.check(L.lib().effdet_nhwc_to_nchw_f32(L.ptr(m.tensor()), L.ptr(out), L.dtype_code(m.dtype), m.B, m.H, m.W, m.C,
@@ -337,6 +350,17 @@ def dw_unpack_wgrad(g_kkc, scale, w_c1kk, wsum=None):
     L.check(L.lib().effdet_dw_unpack_wgrad(L.ptr(g_kkc), L.ptr(scale), L.ptr(w_c1kk.detach()), L.ptr(dw), L.ptr(wsum), Cc, k,
                                            L.stream_ptr()), 'effdet_dw_unpack_wgrad')
     return dw
+
+
+def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
+    """dw_unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta)."""
+    Cc, _, k, _ = w_c1kk.shape
+    dw = torch.empty_like(w_c1kk)
+    dgb = torch.empty((2, Cc), dtype=torch.float32, device=dw.device)
+    L.check(L.lib().effdet_dw_unpack_wgrad_bn(L.ptr(g_kkc), L.ptr(scale), L.ptr(w_c1kk.detach()), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
+                                              L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cc, k, L.stream_ptr()),
+            'effdet_dw_unpack_wgrad_bn')
+    return dw, dgb[0], dgb[1]
 
 
 def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None):

@@ -97,6 +97,11 @@ int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, 
 int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
                              float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
                              effdet_stream_t stream);
+/* The same unpack for a conv followed by a frozen BatchNorm, with effdet_bn_param_grad fused in (one launch instead
+ * of two per BN conv): dw = scale*g, dgamma = invstd*(sum_k w*g - mean*dsum), dbeta = dsum. */
+int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w_oihw, float* dw_oihw, const float* dsum,
+                                const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout, int Cin,
+                                int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream);
 
 /* Batched parameter preparation: every per-step repack of the model's parameters in ONE launch (a D0 train step
  * issued ~190 of these 4-microsecond kernels one by one: 125 weight packs, 48 BN folds, 16 depthwise packs).
@@ -157,6 +162,9 @@ int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);
 int effdet_dw_unpack_wgrad(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk,
                            float* wsum, int C, int k, effdet_stream_t stream);
+int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk, const float* dsum,
+                              const float* mean, const float* invstd, float* dgamma, float* dbeta, int C, int k,
+                              effdet_stream_t stream);       /* + the BN parameter gradients, as above */
 
 /* ---------------------------------------------------------------------------------------------
  * Squeeze-excite gate:  gate[b][c] = sigmoid(W2 * swish(W1 * (pool[b]/HW) + b1) + b2)
