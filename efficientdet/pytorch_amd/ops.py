@@ -257,7 +257,8 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
         raise RuntimeError('effdet_conv2d_wgrad: unsupported geometry')
     slabs = torch.empty((splits, Cout, KH * KW, Cin), dtype=torch.float32, device=x0.t.device)
     nbytes = slabs.numel() * 4
-    _timed('conv_wgrad_kernel<%s>' % ('bf16' if x0.dtype == torch.bfloat16 else 'f32'), flops,
+    # (bf16: DMA + LDS-transpose-read kernel; levels it cannot take -- and fp32 -- use the register-transpose kernel)
+    _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else 'conv_wgrad_kernel<f32>', flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(slabs), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
@@ -367,7 +368,7 @@ def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=F
     y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device)
     z = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_z else None
     nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (2 if save_z else 1))
-    _timed('dw_fwd_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_fwd(
+    _timed('dw_fwd_lds_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_fwd(
         L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t), L.ptr(z.t if z else None), L.ptr(pool),
         L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd'),
         'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
@@ -377,7 +378,7 @@ def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=F
 def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
     dx = Map.new(dz.B, H, W, dz.C, dz.dtype, dz.t.device)
     nbytes = dz.t.element_size() * dz.B * dz.C * (dz.H * dz.W + H * W * (2 if zprev else 1))
-    _timed('dw_dgrad_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_dgrad(
+    _timed('dw_dgrad_lds_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_dgrad(
         L.ptr(dz.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(zprev.tensor() if zprev else None), L.ptr(dx.t),
         L.dtype_code(dz.dtype), dz.B, H, W, dz.C, k, stride, pad_t, pad_l, dz.H, dz.W, L.stream_ptr()), 'effdet_dwconv_dgrad'),
         'BYTES k%d s%d C%d %dx%d' % (k, stride, dz.C, H, W))
@@ -392,7 +393,7 @@ def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
         raise RuntimeError('effdet_dwconv_wgrad: unsupported geometry')
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
     traffic = x.t.element_size() * x.B * x.C * (x.H * x.W + dz.H * dz.W)
-    _timed('dw_wgrad_kernel', traffic, lambda: L.check(L.lib().effdet_dwconv_wgrad(
+    _timed('dw_wgrad_lds_kernel', traffic, lambda: L.check(L.lib().effdet_dwconv_wgrad(
         L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws), C.c_longlong(nbytes), *geo, L.stream_ptr()),
         'effdet_dwconv_wgrad'), 'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return g[:k * k], g[k * k]
