@@ -298,7 +298,7 @@ class EfficientDet(nn.Module):
             if key not in self._prep:
                 self._prep[key] = ops.ParamPrep()
             ops.set_prep(self._prep[key])
-            self._prep[key].begin_step()
+            self._prep[key].begin_step(img.device)
         bn = bb._bn0
         train = torch.is_grad_enabled()
         x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train)

@@ -24,7 +24,7 @@ class ZeroArena:
     """One zero-filled fp32 allocation carved into gradient accumulators (one memset instead of dozens)."""
 
     def __init__(self, nfloats, device):
-        self.buf = torch.zeros(max(int(nfloats), 1), dtype=torch.float32, device=device)
+        self.buf = ops.zeros(max(int(nfloats), 1), device)
         self.pos = 0
 
     def take(self, *shape):
@@ -92,7 +92,7 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
     wk = ops.dw_pack_weight(P['dw.weight'])
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
-    pool = torch.zeros((B, blk.cexp), dtype=torch.float32, device=dev)
+    pool = ops.zeros((B, blk.cexp), dev)
     xd, zd = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=pool)
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
@@ -168,7 +168,7 @@ def lateral_bwd(feats, weights, douts, dtype):
     dfs, dws, dbs = [], [], []
     for f, w, dy in zip(feats, weights, douts):
         W, Cin = w.shape[0], w.shape[1]
-        db = torch.zeros(W, dtype=torch.float32, device=w.device)
+        db = ops.zeros(W, w.device)
         G = ops.conv2d_wgrad(f, dy, None, db, Cin=Cin, Cout=W, KH=1, KW=1)
         dw = torch.empty_like(w)
         ops.unpack_wgrad(G, dw)
@@ -246,7 +246,7 @@ def bifpn_module_bwd(saved, douts, dtype):
         dc, dc_acc = target(c_n) if c_n is not None else (None, False)
         ops.bifpn_fuse_bwd(df, names[a_n], names[b_n], names[c_n] if c_n else None, da, dbm, dc, da_acc, db_acc, dc_acc,
                            w1 if wsel == 1 else w2, dn1 if wsel == 1 else dn2, col, mode)
-    dw1 = torch.zeros_like(w1); dw2 = torch.zeros_like(w2)
+    dw1 = ops.zeros(tuple(w1.shape), w1.device); dw2 = ops.zeros(tuple(w2.shape), w2.device)
     ops.bifpn_weight_bwd(w1, dn1, dw1); ops.bifpn_weight_bwd(w2, dn2, dw2)
     dins = [grads[('in', l)] for l in range(len(out_names))]
     return dins, dw1, dw2, dcw, dcb

@@ -107,8 +107,27 @@ class ParamPrep:
     def __init__(self):
         self.jobs, self.outs, self.bn_src = {}, {}, {}
         self.table, self.dirty, self.replay = None, False, False
+        self.zbuf, self.zpos, self.zreq, self.zsize = None, 0, 0, 0
 
-    def begin_step(self):
+    # -- zero-initialised scratch of one step (SE pools, bias / BN / fusion-weight accumulators): ONE memset per step
+    #    instead of ~60; sized by what the previous step asked for, a fresh buffer every step (gradients may keep views)
+    def _begin_zeros(self, device):
+        self.zsize = max(self.zsize, self.zreq)
+        self.zbuf = torch.zeros(self.zsize, dtype=torch.float32, device=device) if self.zsize else None
+        self.zpos = self.zreq = 0
+
+    def zeros(self, n, device):
+        n64 = (n + 63) // 64 * 64
+        self.zreq += n64
+        if self.zbuf is not None and self.zpos + n64 <= self.zbuf.numel() and self.zbuf.device == device:
+            v = self.zbuf[self.zpos:self.zpos + n]
+            self.zpos += n64
+            return v
+        return torch.zeros(n, dtype=torch.float32, device=device)
+
+    def begin_step(self, device=None):
+        if device is not None:
+            self._begin_zeros(device)
         if self.dirty:
             self._build()
         self.replay = self.table is not None
@@ -168,6 +187,18 @@ def set_prep(p):
 
 def get_prep():
     return getattr(_tls, 'prep', None)
+
+
+def zeros(shape, device):
+    """fp32 zeros, from the running model's per-step zero pool when there is one."""
+    shape = (shape,) if isinstance(shape, int) else tuple(shape)
+    n = 1
+    for d in shape:
+        n *= d
+    prep = get_prep()
+    device = torch.device(device)
+    t = prep.zeros(n, device) if prep is not None else torch.zeros(n, dtype=torch.float32, device=device)
+    return t.view(shape)
 
 
 def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
@@ -418,7 +449,7 @@ def channel_scale(x, gate):
 
 
 def se_dgate(dy, x):
-    dg = torch.zeros((x.B, x.C), dtype=torch.float32, device=x.t.device)
+    dg = zeros((x.B, x.C), x.t.device)
     L.check(L.lib().effdet_se_dgate(L.ptr(dy.tensor()), L.ptr(x.tensor()), L.ptr(dg), L.dtype_code(x.dtype), x.B,
                                     C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_se_dgate')
     return dg
