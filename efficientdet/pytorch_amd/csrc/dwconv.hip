@@ -597,11 +597,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
     }
   }
   __syncthreads();
-  float* slab = (float*)p.y + (long long)blockIdx.x * ROWS * p.C;
+  // One wave-wide fp32 atomic per (row, 64 channels): 64 consecutive addresses = two cache-line transactions, a few
+  // hundred per line over the whole launch (the same-line serialisation that hurts is ONE lane per instruction onto a
+  // shared line).  g / dsum are zeroed by the caller; this replaces the per-workgroup slabs + reduce launch.
+  float* gout = (float*)p.y;                              // [K*K][C]
   for (int i = tid; i < ROWS * 8 * CE; i += 256) {
     const int t = i / (8 * CE), c = i - t * (8 * CE);
     const int ch = chunk0 * CE + c;
-    if (ch < p.C) slab[(long long)t * p.C + ch] = red[i] + red[ROWS * 8 * CE + i] + red[2 * ROWS * 8 * CE + i] + red[3 * ROWS * 8 * CE + i];
+    const float v = red[i] + red[ROWS * 8 * CE + i] + red[2 * ROWS * 8 * CE + i] + red[3 * ROWS * 8 * CE + i];
+    if (ch < p.C) atomicAdd(t < K * K ? gout + (long long)t * p.C + ch : p.pool + ch, v);     // p.pool carries dsum here
   }
 }
 
@@ -772,6 +776,7 @@ extern "C" long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H
                                                           int pad_l, int Ho, int Wo) {
   DwK a{}; dim3 grid;
   if (wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo)) return -1;
+  if (!wgrad_direct(Ho, Wo)) return 256;                   // LDS-tiled path accumulates straight into g / dsum
   return (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float);
 }
 
@@ -782,7 +787,7 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
   DwK a{}; dim3 grid;
   int rc = wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
-  if (workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
+  if (wgrad_direct(Ho, Wo) && workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
   a.x = x; a.aux = dz; a.y = workspace;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -795,13 +800,14 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
       if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a);
     }
+    EFFDET_CHECK_LAUNCH();
+    const int rows = k * k + 1;
+    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum,
+                       (int)grid.x, rows, C);
   } else {
+    a.y = g; a.pool = dsum;                               // accumulated in place (zeroed by the caller)
     DW_DISPATCH(launch_wgrad_lds, dtype, k, stride, a, st);
   }
-  EFFDET_CHECK_LAUNCH();
-  const int rows = k * k + 1;
-  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum,
-                     (int)grid.x, rows, C);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -417,7 +417,7 @@ def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
 
 
 def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
-    g = torch.empty((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum
+    g = zeros((k * k + 1, x.C), x.t.device)       # taps | dsum (accumulated into by the kernel: must start at zero)
     geo = (L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W)
     nbytes = int(L.lib().effdet_dwconv_wgrad_workspace_bytes(*geo))
     if nbytes < 0:

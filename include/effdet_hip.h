@@ -150,8 +150,9 @@ int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, con
 int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,
                         void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
-/* weight gradient g[tap][c] = sum dz*x (unscaled), dsum[c] = sum dz (both OVERWRITTEN).  Per-block partial
- * slabs in `workspace` (effdet_dwconv_wgrad_workspace_bytes) + a reduce pass; no atomics. */
+/* weight gradient g[tap][c] = sum dz*x (unscaled), dsum[c] = sum dz.  g and dsum MUST BE ZERO on entry: maps larger
+ * than 8x8 accumulate into them with one wave-wide fp32 atomic per (workgroup, tap, 64 channels); tiny maps go through
+ * per-workgroup slabs in `workspace` (effdet_dwconv_wgrad_workspace_bytes) + a reduce pass. */
 long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t,
                                               int pad_l, int Ho, int Wo);
 int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, void* workspace,
