@@ -87,7 +87,14 @@ __global__ __launch_bounds__(256) void decode_score_kernel(const float* __restri
 
 // ------------------------------------------------------------------ NMS
 constexpr int NT = 1024;          // threads per NMS workgroup = candidates per tile
-constexpr int ROUND = 8 * NT;     // candidates per round
+#ifndef EFFDET_NMS_SUBS
+#define EFFDET_NMS_SUBS 2
+#endif
+// Tiles per round.  Inside a round the per-image workgroup (ONE CU) checks each tile against the boxes kept earlier in the
+// same round -- VALU-bound work that grows with SUBS^2 -- whereas boxes kept in earlier rounds are handled by the
+// whole-GPU cross kernel; 8 -> 2 tiles per round moved 3/4 of that work onto the 256 CUs for 18 more (small) launches.
+constexpr int SUBS = EFFDET_NMS_SUBS;
+constexpr int ROUND = SUBS * NT;  // candidates per round
 
 struct NmsWs {
   unsigned* keys_in; unsigned* keys_out; unsigned* vals_in; unsigned* vals_out;
@@ -102,6 +109,27 @@ __device__ __forceinline__ bool suppresses(const float4& a, float aa, const floa
   const float inter = iw * ih;
   return inter / (aa + ab - inter) > thr;
 }
+
+// `me` against n kept boxes staged in LDS (tb / ta, padded to a multiple of 8 with boxes that suppress nothing).
+// The obvious loop -- one box per iteration, break on the first hit -- is a chain of dependent LDS round trips (the
+// break forbids hoisting the next read): measured 640 cycles per box, 71 % of the per-image round kernel.  Here 8
+// boxes are fetched and tested per iteration with no exit in between, and the loop ends when the whole WAVE is
+// dead; the extra comparisons cannot change the outcome (the answer is the OR over all n).
+__device__ __forceinline__ bool scan_kept(const float4& me, float ma, const float4* tb, const float* ta, int n, bool alive, float thr) {
+  for (int j0 = 0; j0 < n; j0 += 8) {
+    float4 q[8]; float qa[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { q[u] = tb[j0 + u]; qa[u] = ta[j0 + u]; }
+    bool hit = false;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) hit |= suppresses(me, ma, q[u], qa[u], thr);
+    alive = alive && !hit;
+    if (__ballot(alive) == 0ull) break;
+  }
+  return alive;
+}
+// sentinel for the padding slots: empty box far away -> negative overlap width -> never suppresses
+__device__ __forceinline__ float4 no_box() { return make_float4(-3.0e30f, -3.0e30f, -3.0e30f, -3.0e30f); }
 
 __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals,
                                                        int* nvalid, int* offsets, int* kept, unsigned* dead, long long A, int B) {
@@ -147,8 +175,8 @@ __global__ void nms_gather_kernel(const float* __restrict__ boxes, const unsigne
 // Kernel A: candidates of round `round` vs boxes kept in earlier rounds (split over blockIdx.z).
 __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict__ sbox, const float4* kbox, const int* nvalid,
                                                        const int* kept, unsigned* dead, long long A, int round, int splits, float thr) {
-  __shared__ float4 kb[NT];
-  __shared__ float ka[NT];
+  __shared__ float4 kb[NT + 8];
+  __shared__ float ka[NT + 8];
   const int b = blockIdx.x, sub = blockIdx.y, sp = blockIdx.z;
   const int nv = nvalid[b], kc = kept[b];
   const long long i = (long long)round * ROUND + sub * NT + threadIdx.x;
@@ -163,23 +191,29 @@ __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict_
     const int n = min(NT, k1 - c0);
     __syncthreads();
     if ((int)threadIdx.x < n) { const float4 q = kbox[b * A + c0 + threadIdx.x]; kb[threadIdx.x] = q; ka[threadIdx.x] = (q.z - q.x) * (q.w - q.y); }
+    else if ((int)threadIdx.x < n + 8) { kb[threadIdx.x] = no_box(); ka[threadIdx.x] = 0.f; }
+    if (threadIdx.x < 8) { kb[NT + threadIdx.x] = no_box(); ka[NT + threadIdx.x] = 0.f; }
     __syncthreads();
-    if (alive) {
-      for (int j = 0; j < n; ++j) if (suppresses(me, ma, kb[j], ka[j], thr)) { alive = false; break; }
-    }
+    alive = scan_kept(me, ma, kb, ka, n, alive, thr);
   }
   if (valid && !alive) dead[b * A + i] = 1u;
 }
 
+#ifdef EFFDET_NMS_PROF
+__device__ unsigned long long nms_prof[8];
+#define PROF_T(i) do { if (tid == 0 && b == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); nms_prof[i] += t_ - tp; tp = t_; } } while (0)
+#else
+#define PROF_T(i) do {} while (0)
+#endif
 // Kernel B: finish round `round` for one image per workgroup.
 __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict__ sbox, const unsigned* __restrict__ sidx, float4* kbox,
                                                        const int* nvalid, int* kept, const unsigned* dead, int* out_idx,
                                                        long long A, int round, float thr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* mask = (unsigned long long*)smem_raw;           // [16][NT] word-major
-  float4* tb = (float4*)(smem_raw + (size_t)16 * NT * 8);            // [NT] boxes (kept chunk / survivors)
-  float* ta = (float*)(tb + NT);                                      // [NT] areas
-  unsigned* tidx = (unsigned*)(ta + NT);                              // [NT] survivor anchor idx
+  float4* tb = (float4*)(smem_raw + (size_t)16 * NT * 8);            // [NT + 8] boxes (kept chunk / survivors)
+  float* ta = (float*)(tb + NT + 8);                                  // [NT + 8] areas
+  unsigned* tidx = (unsigned*)(ta + NT + 8);                          // [NT] survivor anchor idx
   unsigned long long* keptb = (unsigned long long*)(tidx + NT);       // [16]
   unsigned long long* deadb = keptb + 16;                             // [16]
   int* wsum = (int*)(deadb + 16);                                     // [16] per-wave counts
@@ -190,8 +224,11 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
   if ((long long)round * ROUND >= nv) return;
   int kc = kept[b];
   const int kc_round0 = kc;
+#ifdef EFFDET_NMS_PROF
+  unsigned long long tp = __builtin_readcyclecounter();
+#endif
 
-  for (int sub = 0; sub < 8; ++sub) {
+  for (int sub = 0; sub < SUBS; ++sub) {
     const long long tile0 = (long long)round * ROUND + (long long)sub * NT;
     if (tile0 >= nv) break;                                            // uniform
     const long long i = tile0 + tid;
@@ -204,12 +241,13 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
       const int n = min(NT, kc - c0);
       __syncthreads();
       if (tid < n) { const float4 q = kbox[b * A + c0 + tid]; tb[tid] = q; ta[tid] = (q.z - q.x) * (q.w - q.y); }
+      else if (tid < n + 8) { tb[tid] = no_box(); ta[tid] = 0.f; }
+      if (tid < 8) { tb[NT + tid] = no_box(); ta[NT + tid] = 0.f; }
       __syncthreads();
-      if (alive) {
-        for (int j = 0; j < n; ++j) if (suppresses(me, ma, tb[j], ta[j], thr)) { alive = false; break; }
-      }
+      alive = scan_kept(me, ma, tb, ta, n, alive, thr);
     }
     __syncthreads();
+    PROF_T(0);
     // ---- order-preserving compaction of the survivors ----
     const unsigned long long bal = __ballot(alive);
     const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -221,19 +259,29 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
     if (alive) { const int s = woff + wrank; tb[s] = me; ta[s] = ma; tidx[s] = myidx; }
     if (tid < 16) { keptb[tid] = 0ull; deadb[tid] = 0ull; }
     __syncthreads();
+    PROF_T(1);
     if (S == 0) continue;                                              // uniform
     // ---- suppression bit-matrix among the S survivors (row s, bits j < s), word-major in LDS ----
     const int nw = (S + 63) >> 6;
     if (tid < S) {
       const float4 mb = tb[tid]; const float mba = ta[tid];
-      for (int w = 0; w <= (tid >> 6); ++w) {
+      for (int w = 0; w <= (tid >> 6); ++w) {          // trip count is wave-uniform (a wave = 64 consecutive rows)
         unsigned long long bits = 0ull;
-        const int j1 = min(tid, (w + 1) * 64);
-        for (int j = w * 64; j < j1; ++j) if (suppresses(mb, mba, tb[j], ta[j], thr)) bits |= 1ull << (j & 63);
+#pragma unroll 1
+        for (int g8 = 0; g8 < 64; g8 += 8) {           // 8 pipelined LDS fetches + tests per step, no data-dependent exit
+          float4 q[8]; float qa[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) { q[u] = tb[w * 64 + g8 + u]; qa[u] = ta[w * 64 + g8 + u]; }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) if (suppresses(mb, mba, q[u], qa[u], thr)) bits |= 1ull << (g8 + u);
+        }
+        // only earlier survivors count: bits j >= tid (incl. stale slots >= S, which lie above every valid row) are dropped
+        if (w == (tid >> 6)) bits &= (1ull << (tid & 63)) - 1ull;
         mask[(size_t)w * NT + tid] = bits;
       }
     }
     __syncthreads();
+    PROF_T(2);
     // ---- parallel fixed point == sequential greedy ----
     int status = (tid < S) ? 0 : 2;          // 0 undecided, 1 kept, 2 dead/absent
     for (int it = 0; it < NT + 1; ++it) {
@@ -254,9 +302,16 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
         else atomicOr(&deadb[tid >> 6], 1ull << (tid & 63));
       }
       const int any_open = __syncthreads_or(status == 0);
+#ifdef EFFDET_NMS_PROF
+      if (tid == 0 && b == 0) nms_prof[7] += 1;
+#endif
       if (!any_open) break;
       (void)nw;
     }
+    PROF_T(3);
+#ifdef EFFDET_NMS_PROF
+    if (tid == 0 && b == 0) { nms_prof[5] += S; nms_prof[6] += 1; }
+#endif
     // ---- append the kept survivors in order ----
     const bool k = status == 1;
     const unsigned long long kbal = __ballot(k);
@@ -275,6 +330,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
     kc += KT;
     __threadfence_block();
     __syncthreads();
+    PROF_T(4);
   }
   if (tid == 0) kept[b] = kc;
   (void)sh;
@@ -391,13 +447,14 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     return EFFDET_ELAUNCH;
   hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
   EFFDET_CHECK_LAUNCH();
-  const size_t lds = (size_t)16 * NT * 8 + (size_t)NT * 16 + (size_t)NT * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
+  const size_t lds = (size_t)16 * NT * 8 + (size_t)(NT + 8) * 16 + (size_t)(NT + 8) * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void*)nms_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
   const int rounds = (int)((A + ROUND - 1) / ROUND);
   for (int r = 0; r < rounds; ++r) {
     if (r > 0) {
-      hipLaunchKernelGGL(nms_cross_kernel, dim3(B, 8, 4), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, 4, iou_threshold);
+      constexpr int SPLITS = SUBS >= 8 ? 4 : (SUBS >= 4 ? 8 : 16);      // keep ~1000 workgroups per launch at B = 32
+      hipLaunchKernelGGL(nms_cross_kernel, dim3(B, SUBS, SPLITS), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, SPLITS, iou_threshold);
       EFFDET_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(nms_round_kernel, dim3(B), dim3(NT), lds, st, w.sbox, w.vals_out, w.kbox, w.nvalid, w.kept, w.dead, out_idx, A, r, iou_threshold);
@@ -406,6 +463,14 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
   return EFFDET_OK;
 }
+
+#ifdef EFFDET_NMS_PROF
+extern "C" int effdet_nms_prof(unsigned long long* out) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nms_prof), sizeof(z)) != hipSuccess) return -1;
+  return hipMemcpyToSymbol(HIP_SYMBOL(nms_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int effdet_gather_dets(const float* boxes, const float* score, const int* label, const int* idx, const int* count,
                                   float* out_scores, long long* out_labels, float* out_boxes, int B, long long A,
