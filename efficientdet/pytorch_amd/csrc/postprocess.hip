@@ -18,7 +18,7 @@
 //      sequential greedy result.  Kept boxes / indices are appended in order.
 //   All loops are bounded by device-side counts; the host launches ceil(A/8192) rounds blindly.
 #include "common.h"
-#include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -97,7 +97,7 @@ constexpr int SUBS = EFFDET_NMS_SUBS;
 constexpr int ROUND = SUBS * NT;  // candidates per round
 
 struct NmsWs {
-  unsigned* keys_in; unsigned* keys_out; unsigned* vals_in; unsigned* vals_out;
+  unsigned long long* keys_in; unsigned long long* keys_out; unsigned* vals_in; unsigned* vals_out;
   int* offsets; int* nvalid; int* kept; unsigned* dead; float4* sbox; float4* kbox;
   void* temp; size_t temp_bytes;
 };
@@ -131,7 +131,7 @@ __device__ __forceinline__ bool scan_kept(const float4& me, float ma, const floa
 // sentinel for the padding slots: empty box far away -> negative overlap width -> never suppresses
 __device__ __forceinline__ float4 no_box() { return make_float4(-3.0e30f, -3.0e30f, -3.0e30f, -3.0e30f); }
 
-__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals,
+__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned long long* keys, unsigned* vals,
                                                        int* nvalid, int* offsets, int* kept, unsigned* dead, long long A, int B) {
   // grid (x, B): one image per blockIdx.y, so the valid count is a ballot + one atomic per wave-leader block sum
   const int b = blockIdx.y;
@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__
       if (k == 0xffffffffu) k = 0xfffffffeu;
       ++mine;
     }
-    keys[i] = k; vals[i] = (unsigned)a; dead[i] = 0u;
+    // one GLOBAL stable radix sort over (image, descending score) instead of a segmented sort (3x faster for 32 segments
+    // of 49k keys): the image index rides in the upper key bits
+    keys[i] = ((unsigned long long)b << 32) | k; vals[i] = (unsigned)a; dead[i] = 0u;
   }
   mine = (int)wave_sum((float)mine);
   if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
@@ -352,11 +354,12 @@ __global__ void gather_dets_kernel(const float* __restrict__ boxes, const float*
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
+inline int key_bits(int B) { int bits = 32; while ((1LL << (bits - 32)) < B) ++bits; return bits; }
+
 size_t sort_temp_bytes(long long total, int B) {
   size_t bytes = 0;
-  unsigned* ku = nullptr; int* off = nullptr;
-  (void)rocprim::segmented_radix_sort_pairs<rocprim::default_config>(nullptr, bytes, ku, ku, ku, ku, (unsigned)total, (unsigned)B,
-                                                                     off, off, 0, 32, (hipStream_t)0, false);
+  unsigned long long* k = nullptr; unsigned* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)total, 0u, (unsigned)key_bits(B), (hipStream_t)0, false);
   return bytes;
 }
 
@@ -364,7 +367,7 @@ size_t carve(NmsWs& w, void* base, int B, long long A) {
   const size_t n = (size_t)B * A;
   size_t off = 0;
   auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += al(bytes); return p; };
-  w.keys_in = (unsigned*)take(n * 4); w.keys_out = (unsigned*)take(n * 4);
+  w.keys_in = (unsigned long long*)take(n * 8); w.keys_out = (unsigned long long*)take(n * 8);
   w.vals_in = (unsigned*)take(n * 4); w.vals_out = (unsigned*)take(n * 4);
   w.dead = (unsigned*)take(n * 4);
   w.sbox = (float4*)take(n * 16); w.kbox = (float4*)take(n * 16);
@@ -442,8 +445,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     hipLaunchKernelGGL(nms_keys_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B); }
   EFFDET_CHECK_LAUNCH();
   size_t tb = w.temp_bytes;
-  if (rocprim::segmented_radix_sort_pairs<rocprim::default_config>(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out,
-                                                                   (unsigned)n, (unsigned)B, w.offsets, w.offsets + 1, 0, 32, st, false) != hipSuccess)
+  if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, (unsigned)key_bits(B), st, false) != hipSuccess)
     return EFFDET_ELAUNCH;
   hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
   EFFDET_CHECK_LAUNCH();
