@@ -75,11 +75,44 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   const float s = scale ? scale[co] : 1.0f;
   const float* grow = g + (long long)co * np;
   float part = 0.f;
+  auto emit = [&](int pidx, const f32x4& gv) {          // 4 consecutive packed elements (same tap, 4 channels) -> OIHW
+    const int tap = pidx / Cin_pad, ci = pidx - tap * Cin_pad;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (ci + e >= Cin) continue;
+      const long long o = (long long)co * n + (ci + e) * taps + tap;
+      if (wsum || dgamma) part += w[o] * gv[e];
+      dw[o] = accumulate ? dw[o] + s * gv[e] : s * gv[e];
+    }
+  };
+  const int G = np >> 2;                                 // 16-byte groups per row (Cin_pad % 4 == 0)
+  if (G <= 128 && nslabs >= 8 && gridDim.y == 1) {
+    // Short rows with many split-K slabs (the high-resolution 1x1 convs: K = 16..144 against ~500 slabs): one thread
+    // per group summing every slab serially left 4..36 lanes of the workgroup walking a 500-long dependent chain
+    // (45 us for a few KiB).  Spread the slabs over 256/G thread slices and combine the slices through LDS.
+    __shared__ f32x4 sred[256];
+    const int SL = 256 / G, slice = threadIdx.x / G, grp = threadIdx.x - slice * G;
+    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    if (slice < SL) {
+      int sl = slice;
+      for (; sl + SL < nslabs; sl += 2 * SL) {
+        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride);
+        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride);
+      }
+      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride);
+    }
+    sred[threadIdx.x] = a0 + a1;
+    __syncthreads();
+    if ((int)threadIdx.x < G) {
+      f32x4 gv = sred[threadIdx.x];
+      for (int q = 1; q < SL; ++q) gv += sred[q * G + threadIdx.x];
+      emit((int)threadIdx.x * 4, gv);
+    }
+  } else {
   // 4 consecutive packed elements (same tap, 4 channels: Cin_pad % 4 == 0) per thread, 16-byte slab loads,
   // slab loop unrolled x4 so the loads of different slabs are in flight together
   for (int q4 = blockIdx.y * 256 + threadIdx.x; q4 * 4 < np; q4 += gridDim.y * 256) {
     const int pidx = q4 * 4;
-    const int tap = pidx / Cin_pad, ci = pidx - tap * Cin_pad;
     f32x4 a0 = *(const f32x4*)(grow + pidx), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     int sl = 1;
     for (; sl + 3 < nslabs; sl += 4) {
@@ -89,14 +122,8 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
       a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride);
     }
     for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride);
-    const f32x4 gv = (a0 + a1) + (a2 + a3);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (ci + e >= Cin) continue;
-      const long long o = (long long)co * n + (ci + e) * taps + tap;
-      if (wsum || dgamma) part += w[o] * gv[e];
-      dw[o] = accumulate ? dw[o] + s * gv[e] : s * gv[e];
-    }
+    emit(pidx, (a0 + a1) + (a2 + a3));
+  }
   }
   if (wsum || dgamma) {
     __shared__ float red[4];

@@ -166,6 +166,9 @@ def test_wgrad_shapes(dtype):
     _run_wgrad(dtype, 2, 8, 16, 64, 64, 3)
     _run_wgrad(dtype, 5, 4, 2, 64, 64, 3)
     _run_wgrad(dtype, 3, 24, 24, 24, 144, 1, pad=(0, 0, 0, 0))
+    # short rows x many split-K slabs: the sliced slab reduction of the unpack kernel
+    _run_wgrad(dtype, 8, 64, 64, 16, 96, 1, pad=(0, 0, 0, 0))
+    _run_wgrad(dtype, 4, 64, 64, 144, 24, 1, pad=(0, 0, 0, 0))
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
