@@ -44,6 +44,7 @@ __global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restri
     const float* row = w2 + (long long)c * Cse;
     float s0 = b2[c], s1 = 0.f;
     int j = 0;
+#pragma unroll 4                                   // 8 weight loads in flight: the loop is pure L2 latency otherwise
     for (; j + 1 < Cse; j += 2) { s0 = fmaf(row[j], sw[j], s0); s1 = fmaf(row[j + 1], sw[j + 1], s1); }
     if (j < Cse) s0 = fmaf(row[j], sw[j], s0);
     gate[(long long)b * C + c] = sigmoidf_(s0 + s1);
@@ -72,9 +73,12 @@ __global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __rest
   const int R = SE_T / Cse;
   const int r = tid / Cse, j = tid - r * Cse;
   if (r < R) {
-    float s = 0.f;
-    for (int c = r; c < C; c += R) s = fmaf(w2[(long long)c * Cse + j], du[c], s);
-    part[r * Cse + j] = s;
+    float s = 0.f, s2 = 0.f;
+    int c = r;
+#pragma unroll 4
+    for (; c + R < C; c += 2 * R) { s = fmaf(w2[(long long)c * Cse + j], du[c], s); s2 = fmaf(w2[(long long)(c + R) * Cse + j], du[c + R], s2); }
+    if (c < C) s = fmaf(w2[(long long)c * Cse + j], du[c], s);
+    part[r * Cse + j] = s + s2;
   }
   __syncthreads();
   if (tid < Cse) {
@@ -88,6 +92,7 @@ __global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __rest
   for (int c = tid; c < C; c += SE_T) {
     float s0 = 0.f, s1 = 0.f;
     int q = 0;
+#pragma unroll 4
     for (; q + 1 < Cse; q += 2) { s0 = fmaf(w1[(long long)q * C + c], dmid[q], s0); s1 = fmaf(w1[(long long)(q + 1) * C + c], dmid[q + 1], s1); }
     if (q < Cse) s0 = fmaf(w1[(long long)q * C + c], dmid[q], s0);
     dpool[(long long)b * C + c] = (s0 + s1) * inv_hw;
@@ -105,16 +110,30 @@ __global__ __launch_bounds__(256) void se_gate_bwd_b_kernel(const float* __restr
   int i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) {                                   // dw2[c][j]
     const int c = i / Cse, j = i - c * Cse;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s);
-    dw2[i] = s; return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: the batch loop is pure load latency
+    int b = 0;
+    for (; b + 3 < B; b += 4) {
+      s0 = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s0);
+      s1 = fmaf(ws_du[(long long)(b + 1) * C + c], ws_sw[(long long)(b + 1) * Cse + j], s1);
+      s2 = fmaf(ws_du[(long long)(b + 2) * C + c], ws_sw[(long long)(b + 2) * Cse + j], s2);
+      s3 = fmaf(ws_du[(long long)(b + 3) * C + c], ws_sw[(long long)(b + 3) * Cse + j], s3);
+    }
+    for (; b < B; ++b) s0 = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s0);
+    dw2[i] = (s0 + s1) + (s2 + s3); return;
   }
   i -= n;
   if (i < n) {                                   // dw1[j][c]
     const int j = i / C, c = i - j * C;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s);
-    dw1[i] = s * inv_hw; return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < B; b += 4) {
+      s0 = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s0);
+      s1 = fmaf(ws_dmid[(long long)(b + 1) * Cse + j], pool[(long long)(b + 1) * C + c], s1);
+      s2 = fmaf(ws_dmid[(long long)(b + 2) * Cse + j], pool[(long long)(b + 2) * C + c], s2);
+      s3 = fmaf(ws_dmid[(long long)(b + 3) * Cse + j], pool[(long long)(b + 3) * C + c], s3);
+    }
+    for (; b < B; ++b) s0 = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s0);
+    dw1[i] = ((s0 + s1) + (s2 + s3)) * inv_hw; return;
   }
   i -= n;
   if (i < C) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_du[(long long)b * C + i]; db2[i] = s; return; }
@@ -273,6 +292,7 @@ __global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const 
   if (c >= C) return;
   const float s = scale ? scale[c] : 1.f;
   float acc = 0.f;
+#pragma unroll 5
   for (int t = 0; t < kk; ++t) { const float gv = g[t * C + c]; dw[c * kk + t] = s * gv; acc = fmaf(w[c * kk + t], gv, acc); }
   if (wsum) wsum[c] = acc;
   if (dgamma) { dgamma[c] = invstd[c] * (acc - mean[c] * dsum[c]); dbeta[c] = dsum[c]; }     // = bn_param_grad_kernel
