@@ -159,6 +159,22 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__
   }
 }
 
+// The image path (C <= CE channels padded to exactly one 16-byte chunk): one thread per PIXEL -- the plane reads are
+// coalesced across threads (consecutive pixels) and every thread writes one whole chunk.  The generic kernel above
+// walks the output element-wise and reads 8 planes from 8 adjacent lanes (1.4 TB/s on the 512x512 batch).
+template <typename T>
+__global__ void nchw_to_nhwc_chunk_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int HW, int C) {
+  constexpr int CE = Elem<T>::CE;
+  const long long total = (long long)B * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / HW, p = i - b * HW;
+    float v[CE];
+#pragma unroll
+    for (int c = 0; c < CE; ++c) v[c] = c < C ? x[(b * C + c) * HW + p] : 0.f;
+    ((uint4*)y)[i] = Chunk<T>::pack(v);
+  }
+}
+
 // dst[b][pix][0..Cpad) = src[src_off + b*src_bs + pix*src_ld + c] (c < C), zeros beyond C
 template <typename T>
 __global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, long long src_off, long long src_bs, int src_ld,
@@ -235,6 +251,14 @@ extern "C" int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B
   if (Cpad < C) return EFFDET_EINVAL;
   const long long n = (long long)B * H * W * Cpad;
   hipStream_t st = (hipStream_t)stream;
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  if (Cpad == ce && C <= ce) {
+    const long long np = (long long)B * H * W;
+    if (dtype == EFFDET_F32) hipLaunchKernelGGL(nchw_to_nhwc_chunk_kernel<float>, dim3(grid_for(np)), dim3(256), 0, st, x, (float*)y, B, H * W, C);
+    else hipLaunchKernelGGL(nchw_to_nhwc_chunk_kernel<bf16_t>, dim3(grid_for(np)), dim3(256), 0, st, x, (bf16_t*)y, B, H * W, C);
+    EFFDET_CHECK_LAUNCH();
+    return EFFDET_OK;
+  }
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, x, (float*)y, B, H * W, C, Cpad);
   else hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, x, (bf16_t*)y, B, H * W, C, Cpad);
   EFFDET_CHECK_LAUNCH();
