@@ -26,6 +26,7 @@ struct LossK {
   float* losses; int* assign; float* stat;           // stat[b][SS]
   void* dcls; void* dreg;
   int B, nc, N; long long A;
+  int dld;           // channel pitch of the pixel-major dcls layout (0 = [B][A][nc])
 };
 
 __global__ __launch_bounds__(256) void loss_assign_kernel(const LossK p) {
@@ -191,6 +192,37 @@ __global__ __launch_bounds__(256) void loss_bwd_cls_kernel(const LossK p) {
   else for (int q = 0; q < cnt; ++q) Elem<T>::st(out + e0 + q, g[q]);
 }
 
+// The same gradient written PIXEL-major with a padded channel pitch: dcls[b][pixel][dld], channel = anchor*nc + class,
+// zeros in [9*nc, dld).  That is the layout the head's data-gradient conv reads as its input rows: with dld a multiple
+// of 64 every 128-byte K-slice of a row is one aligned cache line (the natural 720-channel pitch = 1440 B straddles two
+// lines for 3 pixels out of 4, and that conv is bound by its L2->LDS path).  Requires nc % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void loss_bwd_cls_pix_kernel(const LossK p) {
+  const int b = blockIdx.y;
+  const int apix = (int)(p.A / 9), perp = apix * p.dld, cmax = 9 * p.nc;
+  const int e0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= perp) return;
+  const int pix = e0 / p.dld, ch = e0 - pix * p.dld;
+  T* out = (T*)p.dcls + (long long)b * perp + e0;
+  f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* st = p.stat + b * SS;
+  if (ch < cmax && st[3] > 0.f) {
+    const int an = ch / p.nc, k = ch - an * p.nc, a = pix * 9 + an;
+    const int code = p.assign[(long long)b * p.A + a];
+    if (code != -2) {
+      const float gs = p.gscale[0] / ((float)p.B * fmaxf(st[2], 1.0f));
+      const int lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1;
+      const f32x4 v = *(const f32x4*)(p.cls + (long long)b * p.A * p.nc + (long long)pix * cmax + ch);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float d; (void)focal_elem(v[q], lab == k + q, d);
+        g[q] = gs * d * v[q] * (1.f - v[q]);                 // through the sigmoid
+      }
+    }
+  }
+  store4(out, g);
+}
+
 template <typename T>
 __global__ void loss_bwd_reg_kernel(const LossK p) {
   const long long total = (long long)p.B * p.A;
@@ -256,24 +288,41 @@ extern "C" int effdet_focal_loss_fwd(const float* cls, const float* reg, const f
   return EFFDET_OK;
 }
 
-extern "C" int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots,
-                                     const float* gscale, const void* workspace, void* dcls_logit, void* dreg, int dtype,
-                                     int B, long long A, int num_classes, int N, effdet_stream_t stream) {
+static int loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots, const float* gscale,
+                    const void* workspace, void* dcls_logit, int dld, void* dreg, int dtype, int B, long long A, int num_classes,
+                    int N, effdet_stream_t stream) {
   if (!cls || !reg || !anchors || !annots || !gscale || !workspace || !dcls_logit || !dreg) return EFFDET_EINVAL;
   if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  if (dld && (A % 9 || num_classes % 4 || dld % 4 || dld < 9 * num_classes)) return EFFDET_EINVAL;
+  if (dld && (A / 9) * dld >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
   LossK k{}; k.cls = cls; k.reg = reg; k.anchors = anchors; k.annots = annots; k.gscale = gscale;
-  k.dcls = dcls_logit; k.dreg = dreg; k.B = B; k.nc = num_classes; k.N = N; k.A = A;
+  k.dcls = dcls_logit; k.dreg = dreg; k.B = B; k.nc = num_classes; k.N = N; k.A = A; k.dld = dld;
   carve_loss(k, const_cast<void*>(workspace), B, A);
   hipStream_t st = (hipStream_t)stream;
-  const long long groups = (A * num_classes + 3) / 4;
+  const long long groups = dld ? (A / 9) * dld / 4 : (A * num_classes + 3) / 4;
   dim3 g1((unsigned)((groups + 255) / 256), B);
   if (dtype == EFFDET_F32) {
-    hipLaunchKernelGGL(loss_bwd_cls_kernel<float>, g1, dim3(256), 0, st, k);
+    if (dld) hipLaunchKernelGGL(loss_bwd_cls_pix_kernel<float>, g1, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(loss_bwd_cls_kernel<float>, g1, dim3(256), 0, st, k);
     hipLaunchKernelGGL(loss_bwd_reg_kernel<float>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
   } else {
-    hipLaunchKernelGGL(loss_bwd_cls_kernel<bf16_t>, g1, dim3(256), 0, st, k);
+    if (dld) hipLaunchKernelGGL(loss_bwd_cls_pix_kernel<bf16_t>, g1, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL(loss_bwd_cls_kernel<bf16_t>, g1, dim3(256), 0, st, k);
     hipLaunchKernelGGL(loss_bwd_reg_kernel<bf16_t>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
   }
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
+}
+
+extern "C" int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots,
+                                     const float* gscale, const void* workspace, void* dcls_logit, void* dreg, int dtype,
+                                     int B, long long A, int num_classes, int N, effdet_stream_t stream) {
+  return loss_bwd(cls, reg, anchors, annots, gscale, workspace, dcls_logit, 0, dreg, dtype, B, A, num_classes, N, stream);
+}
+
+extern "C" int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, const float* anchors, const float* annots,
+                                         const float* gscale, const void* workspace, void* dcls_pix, int dld, void* dreg,
+                                         int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream) {
+  if (dld <= 0) return EFFDET_EINVAL;
+  return loss_bwd(cls, reg, anchors, annots, gscale, workspace, dcls_pix, dld, dreg, dtype, B, A, num_classes, N, stream);
 }

@@ -230,8 +230,14 @@ class _HeadLossFn(torch.autograd.Function):
         ops.set_prep(ctx.prep)
         saved, cls, reg, anchors, annots, ws, dtype = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
-        dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
-        dp, g = Fn.head_bwd(saved, dcls, dreg, dtype)
+        nc = cls.shape[2]
+        if nc % 4 == 0:      # d(logits) straight into the pixel-major, 64-channel-padded rows the head's gradient convs read
+            dld = (9 * nc + 63) // 64 * 64
+            dcls, dreg = ops.focal_loss_bwd_pix(cls, reg, anchors, annots, gscale, ws, dtype, dld)
+        else:
+            dld = 0
+            dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
+        dp, g = Fn.head_bwd(saved, dcls, dreg, dtype, dcls_ld=dld)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(Fn.level_tensor(m) for m in dp) + tuple(g[k] for k in _HEAD_KEYS)
 

@@ -308,9 +308,9 @@ def head_fwd(p, HP, num_classes, dtype, train):
     return cls, reg, saved
 
 
-def head_bwd(saved, dcls_logit, dreg, dtype):
-    """dcls_logit [B,A,nc], dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.
-    -> (dp: 5 Maps, grads dict keyed like HP)."""
+def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0):
+    """dcls_logit [B,A,nc] (or, with dcls_ld, pixel-major and channel-padded [B,A/9,dcls_ld]: ops.focal_loss_bwd_pix),
+    dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.  -> (dp: 5 Maps, grads dict keyed like HP)."""
     p, acts, sizes, HP, nc = saved
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
@@ -320,12 +320,18 @@ def head_bwd(saved, dcls_logit, dreg, dtype):
     for tower, dout, per in (('cls', dcls_logit, nc), ('reg', dreg, 4)):
         fin = f'retina_{tower}'
         wf = HP[fin + '.weight']
-        dzmaps = head_out_maps(dout, B, sizes, per)
         Cf = wf.shape[0]
         ce = chunk_elems(dtype)
-        Cfp = (Cf + ce - 1) // ce * ce
-        if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
-            dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
+        if tower == 'cls' and dcls_ld:
+            # the loss kernel already wrote rows of dcls_ld channels per pixel (zeros past 9*nc): aligned 128-B K-slices
+            Cfp, apix, poff, dzmaps = dcls_ld, sum(h * w for (h, w) in sizes), 0, []
+            for (h, w) in sizes:
+                dzmaps.append(Map(dout, B, h, w, Cfp, ld=Cfp, bstride=apix * Cfp, off=poff * Cfp)); poff += h * w
+        else:
+            dzmaps = head_out_maps(dout, B, sizes, per)
+            Cfp = (Cf + ce - 1) // ce * ce
+            if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
+                dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
         db = ar.take(Cf)
         G = ops.conv2d_wgrad(acts[tower][3], dzmaps, None, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
         dw = torch.empty_like(wf); ops.unpack_wgrad(G, dw)

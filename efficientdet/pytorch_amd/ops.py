@@ -599,6 +599,17 @@ def focal_loss_bwd(cls, reg, anc, annots, gscale, ws, dtype):
     return dcls, dreg
 
 
+def focal_loss_bwd_pix(cls, reg, anc, annots, gscale, ws, dtype, dld):
+    """focal_loss_bwd with d(cls logits) pixel-major and channel-padded: -> (dcls_pix [B, A/9, dld], dreg [B, A, 4])."""
+    B, A, nc = cls.shape
+    dcls = torch.empty((B, A // 9, dld), dtype=dtype, device=cls.device)
+    dreg = torch.empty((B, A, 4), dtype=dtype, device=cls.device)
+    L.check(L.lib().effdet_focal_loss_bwd_pix(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(gscale), L.ptr(ws), L.ptr(dcls),
+                                              dld, L.ptr(dreg), L.dtype_code(dtype), B, C.c_longlong(A), nc, annots.shape[1],
+                                              L.stream_ptr()), 'effdet_focal_loss_bwd_pix')
+    return dcls, dreg
+
+
 def pad_rows(src_map, cpad):
     """Level map with unaligned channel count -> fresh contiguous [B,H,W,cpad] map, zero padded."""
     m = src_map

@@ -272,6 +272,12 @@ int effdet_focal_loss_fwd(const float* cls, const float* reg, const float* ancho
 int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* anchors, const float* annots,
                           const float* gscale, const void* workspace, void* dcls_logit, void* dreg, int dtype,
                           int B, long long A, int num_classes, int N, effdet_stream_t stream);
+/* The same, with d(cls logits) written PIXEL-major with a padded channel pitch: dcls_pix[b][pixel][dld], channel =
+ * anchor*num_classes + class, zeros in [9*num_classes, dld) -- directly the (cache-line aligned when dld % 64 == 0) input
+ * rows of the head's data-gradient / weight-gradient convs.  Requires num_classes % 4 == 0, dld % 4 == 0, A % 9 == 0. */
+int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, const float* anchors, const float* annots,
+                              const float* gscale, const void* workspace, void* dcls_pix, int dld, void* dreg, int dtype,
+                              int B, long long A, int num_classes, int N, effdet_stream_t stream);
 
 /* Row repack with zero channel padding: dst[b][pix][0..Cpad) = src[src_off + b*src_bstride + pix*src_ld + c]
  * for c < C, 0 beyond (makes an unaligned-channel gradient map consumable by effdet_conv2d). */

@@ -107,3 +107,9 @@ def test_focal_loss_fwd_bwd(dtype, nc):
     tol = 1e-3 if dtype == torch.float32 else 1e-2
     assert_close(dcls.float().cpu(), ref_dlogit, tol, 'dcls_logit')
     assert_close(dreg.float().cpu(), reg.grad, tol, 'dreg')
+    if nc % 4 == 0:      # the pixel-major, channel-padded variant that feeds the head's gradient convs: same values, zero padding
+        dld = (9 * nc + 63) // 64 * 64
+        dpix, dreg2 = ops.focal_loss_bwd_pix(cls.detach().cuda(), reg.detach().cuda(), anc.cuda(), ann.cuda(), gs.cuda(), ws, dtype, dld)
+        assert dpix.shape == (B, A // 9, dld)
+        assert torch.equal(dpix[:, :, :9 * nc].reshape(B, A, nc), dcls) and torch.equal(dreg2, dreg)
+        assert float(dpix[:, :, 9 * nc:].float().abs().max()) == 0.0
