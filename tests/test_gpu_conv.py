@@ -67,6 +67,12 @@ def test_conv3x3_head_shapes(dtype):
     _run(dtype, 1, 8, 8, 256, 36, 3, out_f32=True)                  # retina_reg
     _run(dtype, 2, 4, 4, 64, 64, 3)                                 # BiFPN conv on a tiny level
     _run(dtype, 1, 1, 1, 64, 64, 3)                                 # 1x1 map (D0@128: top level)
+    # more 3x3 'same' shapes: partial tiles, H != W, borders, fused epilogues
+    _run(dtype, 3, 32, 32, 64, 128, 3, act=1, res=True)
+    _run(dtype, 3, 4, 4, 256, 128, 3, act=2, bn=True, save_z=True)
+    _run(dtype, 1, 64, 64, 64, 192, 3)
+    _run(dtype, 2, 8, 16, 128, 144, 3, act=1)
+    _run(dtype, 1, 2, 128, 64, 128, 3)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])

@@ -19,7 +19,7 @@ ap.add_argument('--which', default='fwd,wgrad')
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
 dev = 'cuda'
-sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
+sizes = [(int(v), int(v)) for v in os.environ.get('KB_SIZES', '64,32,16,8,4').split(',')]
 _, x = Fn.pyramid_alloc(a.B, sizes, a.cin, dt, dev)
 _, y = Fn.pyramid_alloc(a.B, sizes, a.cout, dt, dev)
 x[0].t.copy_(torch.randn(x[0].t.numel(), device=dev).to(dt)); y[0].t.copy_(torch.randn(y[0].t.numel(), device=dev).to(dt))
