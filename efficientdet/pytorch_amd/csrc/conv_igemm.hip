@@ -3,12 +3,12 @@
 //   y[m][n] = epilogue( sum_{tap,c} x[pix(m)+tap][c] * w[n][tap][c] )      m = (b,ho,wo), NHWC
 //
 // Design (MI355X-first):
-//   * block tile 128 (m) x BN (n), 4 waves of 64 lanes; K is walked in steps of 128 BYTES per row
+//   * block tile 128 (m) x BN (n), 8 waves (BN = 128) or 4 waves of 64 lanes; K is walked in steps of 128 BYTES per row
 //     (64 bf16 or 32 fp32 channels) = two MFMA "slices" of 4 x 16-byte chunks.
 //   * both operands are staged through LDS as [row][8 chunks of 16 B] with the chunk index XORed
-//     by (row>>1)&7: ds_write_b128 of one 128-B row by 8 consecutive lanes and the fragment
-//     ds_read_b128 (lane l reads row l&15, chunk l>>4) are both bank-conflict free for the
-//     16-lane service groups of gfx950's 64-bank LDS.
+//     by (row>>1)&7 (applied at the DMA source, the LDS image of a DMA being lane-linear): the fragment
+//     ds_read_b128 (lane l reads row l&15, chunk l>>4) is bank-conflict free for the 16-lane service
+//     groups of gfx950's 64-bank LDS.
 //   * the weight tile is the MFMA A operand and the activation tile the B operand, so every lane
 //     ends up with 4 CONSECUTIVE OUTPUT CHANNELS of one pixel -> 8/16-byte NHWC stores and float4
 //     scale/shift loads in the fused epilogue (bias / frozen-BN affine / ReLU / Swish / sigmoid /

@@ -124,7 +124,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
   // the staging role is wave-uniform; readfirstlane makes that PROVABLE, so the role branch is a scalar branch and
   // each SRD stays in SGPRs (a per-lane `do_a ? rz : rx` select costs a waterfall loop around every buffer load)
   const bool do_a = SPLIT ? (__builtin_amdgcn_readfirstlane(tid) < 128) : true;
-  const bool do_b = SPLIT ? !do_a : true;
   const int g = task / NCH, c = task - g * NCH;      // pixel group (CE pixels), chunk column
 
   // dz side: channels n0..n0+CE-1

@@ -1,13 +1,12 @@
 // Depthwise k x k convolution (k = 3 / 5, stride 1 / 2, asymmetric TF-"same" zero pad), NHWC,
-// im2col-free, fused with the frozen-BN affine + Swish epilogue and the squeeze-excite pooling.
+// im2col-free, fused with the frozen-BN affine + Swish epilogue and the squeeze-excite pooling; its data gradient
+// (with the expand conv's Swish' fused) and its weight gradient (+ the BN sum of dz).
 //
-// HBM-bound (1.6-4 FLOP/B): the design goal is coalesced 16-byte channel-chunk accesses and no
-// extra passes -- BN, Swish, the pre-activation copy needed by backward and the SE global sum all
-// happen in the epilogue of the one kernel that reads the input.
-//   thread = (pixel, 16-byte channel chunk); lanes run along channels first, so a wave touches
-//   whole NHWC pixel rows (coalesced); the k*k re-reads of a pixel by neighbouring outputs hit
-//   L1/L2 (blocks walk pixels in raster order).  Pool sums are reduced across the block's pixel
-//   lanes with wave shuffles / LDS before ONE fp32 atomic per (image, channel) per block.
+// HBM-bound (1.6-4 FLOP/B): the design goal is ONE pass over each tensor in 16-byte channel chunks -- BN, Swish, the
+// pre-activation copy needed by backward and the SE global sum all happen in the epilogue of the kernel that reads
+// the input -- and no k*k re-reads through L1: every kernel stages a halo'd tile in LDS by direct-to-LDS DMA and reads
+// its taps from there (the first, direct version issued k*k bounds-checked 8/16-byte global loads per output and ran
+// at ~1-2 TB/s of algorithmic bytes).  Only weight gradients of <= 8x8 maps still use the direct kernel.
 #include "common.h"
 
 namespace {
@@ -23,154 +22,6 @@ struct DwK {
   int tx;         // chunk lanes per block (power of two <= 64)
   int ppt;        // pixels per thread
 };
-
-// ---------------------------------------------------------------- forward
-// K is a template parameter so the k*k taps are fully unrolled: all tap loads are bounds-checked SRD buffer loads
-// (halo taps pass EFFDET_OOB and read zeros), issued back to back with no per-tap branch / s_waitcnt.
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(const DwK p) {
-  constexpr int CE = Elem<T>::CE;
-  constexpr unsigned ES = sizeof(T);
-  const int tx = threadIdx.x & (p.tx - 1), ty = threadIdx.x / p.tx, TY = 256 / p.tx;
-  const int chunk = blockIdx.y * p.tx + tx;
-  const bool cok = chunk < p.nch;
-  const int c0 = chunk * CE;
-  const int HoWo = p.Ho * p.Wo;
-  const int pixb = TY * p.ppt;                       // pixels per block (within ONE image)
-  const int tiles_per_img = (HoWo + pixb - 1) / pixb;
-  const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
-  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
-
-  float sc[CE], sh[CE], psum[CE];
-#pragma unroll
-  for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; psum[e] = 0.f; }
-  if (cok) {
-#pragma unroll
-    for (int e = 0; e < CE; ++e) if (c0 + e < p.C) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
-  }
-  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES) + (unsigned)c0 * ES;
-  for (int i = 0; i < p.ppt; ++i) {
-    const int pix = tile * pixb + i * TY + ty;
-    if (pix >= HoWo || !cok) continue;
-    const int ho = pix / p.Wo, wo = pix - ho * p.Wo;
-    const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
-    float acc[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-      const int hi = hi0 + kh;
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int wi = wi0 + kw;
-        const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        float xv[CE], wv[CE];
-        Chunk<T>::unpack(srd_load16(rx, ok ? img_off + (unsigned)((hi * p.W + wi) * p.C) * ES : EFFDET_OOB), xv);
-        const float* wp = p.w + (kh * K + kw) * p.C + c0;
-#pragma unroll
-        for (int q = 0; q < CE; q += 4) { f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
-#pragma unroll
-        for (int e = 0; e < CE; ++e) acc[e] = fmaf(xv[e], wv[e], acc[e]);
-      }
-    }
-    const long long o = ((long long)b * HoWo + pix) * p.C + c0;
-    float zv[CE], yv[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) { zv[e] = acc[e] * sc[e] + sh[e]; yv[e] = swishf_(zv[e]); }
-    if (p.z) *(uint4*)((T*)p.z + o) = Chunk<T>::pack(zv);
-    const uint4 packed = Chunk<T>::pack(yv);
-    *(uint4*)((T*)p.y + o) = packed;
-    if (p.pool) {
-      // pool what the next kernel will READ (the rounded value) so fp32 and bf16 paths stay self-consistent
-      float yr[CE];
-      Chunk<T>::unpack(packed, yr);
-#pragma unroll
-      for (int e = 0; e < CE; ++e) psum[e] += yr[e];
-    }
-  }
-  if (p.pool) {
-    // reduce over the block's pixel lanes (same tx): shuffles inside the wave, then LDS across waves
-    __shared__ float red[4][64 * CE];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int e = 0; e < CE; ++e) {
-      float v = psum[e];
-      for (int o = 32; o >= p.tx; o >>= 1) v += __shfl_xor(v, o, 64);
-      psum[e] = v;
-    }
-    const int wtx = (p.tx < 64) ? p.tx : 64;
-    if (lane < wtx) {
-#pragma unroll
-      for (int e = 0; e < CE; ++e) red[wave][lane * CE + e] = psum[e];
-    }
-    __syncthreads();
-    // when tx == 64 each wave holds one ty; when tx < 64 every wave holds all tx -> sum the 4 waves
-    for (int i = threadIdx.x; i < wtx * CE; i += 256) {
-      const int l = i / CE, e = i - l * CE;
-      const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-      const int cch = (blockIdx.y * p.tx + l) * CE + e;
-      if (cch < p.C) atomicAdd(p.pool + (long long)b * p.C + cch, v);
-    }
-  }
-}
-
-// ---------------------------------------------------------------- data gradient
-// dx[b,h,w,c] = sum_{kh,kw} dz[b,(h+pt-kh)/s,(w+pl-kw)/s,c] * w[kh,kw,c] * scale[c]   [* swish'(aux)]
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dw_dgrad_kernel(const DwK p) {
-  constexpr int CE = Elem<T>::CE;
-  constexpr unsigned ES = sizeof(T);
-  const int tx = threadIdx.x & (p.tx - 1), ty = threadIdx.x / p.tx, TY = 256 / p.tx;
-  const int chunk = blockIdx.y * p.tx + tx;
-  if (chunk >= p.nch) return;
-  const int c0 = chunk * CE;
-  const int HW = p.H * p.W, HoWo = p.Ho * p.Wo;
-  const int pixb = TY * p.ppt;
-  const int tiles_per_img = (HW + pixb - 1) / pixb;
-  const int b = blockIdx.x / tiles_per_img, tile = blockIdx.x - b * tiles_per_img;
-  const __amdgpu_buffer_rsrc_t rz = make_srd(p.x, p.x_bytes);       // p.x carries dz here
-  float sc[CE];
-#pragma unroll
-  for (int e = 0; e < CE; ++e) sc[e] = p.scale ? p.scale[c0 + e] : 1.f;
-  const unsigned img_off = (unsigned)((long long)b * HoWo * p.C * ES) + (unsigned)c0 * ES;
-  for (int i = 0; i < p.ppt; ++i) {
-    const int pix = tile * pixb + i * TY + ty;
-    if (pix >= HW) continue;
-    const int h = pix / p.W, w = pix - h * p.W;
-    float acc[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-      const int hn = h + p.pad_t - kh;
-      const int ho = p.stride == 2 ? (hn >> 1) : hn;
-      const bool hok = hn >= 0 && (p.stride == 1 || (hn & 1) == 0) && ho < p.Ho;
-#pragma unroll
-      for (int kw = 0; kw < K; ++kw) {
-        const int wn = w + p.pad_l - kw;
-        const int wo = p.stride == 2 ? (wn >> 1) : wn;
-        const bool ok = hok && wn >= 0 && (p.stride == 1 || (wn & 1) == 0) && wo < p.Wo;
-        float dv[CE], wv[CE];
-        Chunk<T>::unpack(srd_load16(rz, ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C) * ES : EFFDET_OOB), dv);
-        const float* wp = p.w + (kh * K + kw) * p.C + c0;
-#pragma unroll
-        for (int q = 0; q < CE; q += 4) { f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
-#pragma unroll
-        for (int e = 0; e < CE; ++e) acc[e] = fmaf(dv[e], wv[e], acc[e]);
-      }
-    }
-    const long long o = ((long long)b * HW + pix) * p.C + c0;
-#pragma unroll
-    for (int e = 0; e < CE; ++e) acc[e] *= sc[e];
-    if (p.aux) {
-      float av[CE];
-      Chunk<T>::unpack(*(const uint4*)((const T*)p.aux + o), av);
-#pragma unroll
-      for (int e = 0; e < CE; ++e) acc[e] *= swish_gradf_(av[e]);
-    }
-    *(uint4*)((T*)p.y + o) = Chunk<T>::pack(acc);
-  }
-}
 
 // ---------------------------------------------------------------- LDS-tiled forward / data gradient
 // One workgroup = one image x one TH x TW output tile x one slab of 8 channel chunks (64 bf16 / 32 fp32 channels).
