@@ -1,0 +1,103 @@
+"""Fused train-step tail: global-norm gradient clipping + AdamW in three HIP launches.
+
+Replaces the pair of the reference's train step (train.py:115-118)
+
+    torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+    optimizer.step()                      # torch.optim.AdamW(lr=1e-4), train.py:268
+
+with `ClipAdamW(params, lr=..., max_norm=0.1).step()`: same arithmetic (clip coefficient max_norm / (norm + 1e-6)
+clamped to 1; decoupled weight decay; bias-corrected moments), one pass for the norm and one for the update over a
+device-resident pointer table instead of ~17 foreach / multi-tensor launches.  Only the gradient pointers change from
+step to step (fresh tensors after zero_grad(set_to_none=True)); they are refreshed through a pinned staging buffer.
+fp32 parameters on one GPU; moments live in two flat arenas.  There is no CPU fallback."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class ClipAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_norm=0.0, write_clipped_grads=False):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, max_norm=max_norm)
+        super().__init__(params, defaults)
+        if len(self.param_groups) != 1:
+            raise ValueError('ClipAdamW supports a single parameter group (the reference uses one, train.py:268)')
+        self.write_clipped_grads = bool(write_clipped_grads)
+        self._table = None
+        self._step = 0
+
+    # ---- the device tables (built once; parameter and moment storage is stable) ----
+    def _build(self):
+        ps = [p for p in self.param_groups[0]['params'] if p.requires_grad]
+        if not ps:
+            raise ValueError('no trainable parameters')
+        dev = ps[0].device
+        for p in ps:
+            if p.dtype != torch.float32 or p.device != dev or not p.is_contiguous() or not p.is_cuda:
+                raise ValueError('ClipAdamW needs contiguous fp32 parameters on one GPU')
+        chunk = int(L.lib().effdet_opt_chunk())
+        n = len(ps)
+        numel = [p.numel() for p in ps]
+        offs = np.concatenate([[0], np.cumsum([(k + 63) // 64 * 64 for k in numel])]).astype(np.int64)
+        self.exp_avg = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(int(offs[-1]), dtype=torch.float32, device=dev)
+        block_tensor, block_first, nb = [], [], 0
+        for i, k in enumerate(numel):
+            b = (k + chunk - 1) // chunk
+            block_first.append(nb); block_tensor += [i] * b; nb += b
+        i64 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int64)).to(dev)
+        i32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int32)).to(dev)
+        t = {
+            'params': ps, 'n': n, 'nblocks': nb,
+            'p_ptr': i64([p.data_ptr() for p in ps]),
+            'm_ptr': i64([self.exp_avg.data_ptr() + 4 * int(o) for o in offs[:-1]]),
+            'v_ptr': i64([self.exp_avg_sq.data_ptr() + 4 * int(o) for o in offs[:-1]]),
+            'numel': i64(numel), 'block_tensor': i32(block_tensor), 'block_first': i32(block_first),
+            'g_ptr': torch.zeros(n, dtype=torch.int64, device=dev),
+            'g_host': torch.zeros(n, dtype=torch.int64).pin_memory(), 'g_last': None,
+            'scratch': torch.zeros(64 + nb, dtype=torch.float32, device=dev), 'offs': offs,
+            'steps': torch.zeros(n, dtype=torch.int32, device=dev), 'p_sig': [p.data_ptr() for p in ps],
+        }
+        for i, p in enumerate(ps):                                     # per-parameter views for state_dict()
+            self.state[p] = {'step': torch.tensor(float(self._step)),
+                             'exp_avg': self.exp_avg[int(offs[i]):int(offs[i]) + numel[i]].view_as(p),
+                             'exp_avg_sq': self.exp_avg_sq[int(offs[i]):int(offs[i]) + numel[i]].view_as(p)}
+        self._table = t
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if self._table is None or self._table['p_sig'] != [p.data_ptr() for p in self._table['params']]:
+            self._build()
+        t, g = self._table, self.param_groups[0]
+        ptrs = []
+        for p in t['params']:
+            gr = p.grad
+            if gr is None:
+                ptrs.append(0)
+                continue
+            if gr.dtype != torch.float32 or not gr.is_contiguous():
+                gr = gr.float().contiguous(); p.grad = gr
+            ptrs.append(gr.data_ptr())
+        if ptrs != t['g_last']:                                        # (DDP bucket views keep their addresses: no upload)
+            t['g_host'].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            t['g_ptr'].copy_(t['g_host'], non_blocking=True)
+            t['g_last'] = ptrs
+        self._step += 1
+        b1, b2 = g['betas']
+        L.check(L.lib().effdet_clip_adamw_step(L.ptr(t['p_ptr']), L.ptr(t['g_ptr']), L.ptr(t['m_ptr']), L.ptr(t['v_ptr']), L.ptr(t['numel']),
+                                               L.ptr(t['block_tensor']), L.ptr(t['block_first']), t['n'], t['nblocks'],
+                                               L.ptr(t['scratch']), L.ptr(t['steps']), C.c_float(g['max_norm'] or 0.0),
+                                               C.c_float(g['lr']), C.c_float(b1), C.c_float(b2), C.c_float(g['eps']),
+                                               C.c_float(g['weight_decay']), int(self.write_clipped_grads), L.stream_ptr()),
+                'effdet_clip_adamw_step')
+        return loss
+
+    def grad_norm(self):
+        """Total gradient norm measured by the last step() (device scalar; clipping enabled only)."""
+        return self._table['scratch'][0] if self._table is not None else None

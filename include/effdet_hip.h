@@ -279,6 +279,27 @@ int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, const float* a
                               const float* gscale, const void* workspace, void* dcls_pix, int dld, void* dreg, int dtype,
                               int B, long long A, int num_classes, int N, effdet_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Train-step tail: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by
+ * torch.optim.AdamW.step() (reference train.py:115-118) as three launches over a device-resident pointer table.
+ *   params / grads / exp_avg / exp_avg_sq : device arrays of ntensors DEVICE POINTERS (as 64-bit integers) to fp32
+ *                                           tensors; grads[i] == 0 skips tensor i (parameter without gradient)
+ *   numel[i]                              : elements of tensor i
+ *   block_tensor / block_first            : workgroup i handles elements [(i - block_first[t]) * effdet_opt_chunk(), +chunk)
+ *                                           of tensor t = block_tensor[i]      (device arrays, nblocks / ntensors ints)
+ *   scratch                               : 64 + nblocks floats; scratch[0] receives the total gradient norm
+ *   steps                                 : ntensors ints, zero before the first call: per-tensor AdamW step counters
+ *                                           (advanced on device for every tensor that has a gradient, as torch does)
+ * max_norm <= 0 disables clipping.  write_grad != 0 writes the clipped gradients back like clip_grad_norm_ does (costs
+ * one more store per element).
+ * ------------------------------------------------------------------------------------------- */
+int effdet_opt_chunk(void);
+int effdet_clip_adamw_step(const unsigned long long* params, const unsigned long long* grads,
+                           const unsigned long long* exp_avg, const unsigned long long* exp_avg_sq, const long long* numel,
+                           const int* block_tensor, const int* block_first, int ntensors, int nblocks, float* scratch,
+                           int* steps, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                           int write_grad, effdet_stream_t stream);
+
 /* Row repack with zero channel padding: dst[b][pix][0..Cpad) = src[src_off + b*src_bstride + pix*src_ld + c]
  * for c < C, 0 beyond (makes an unaligned-channel gradient map consumable by effdet_conv2d). */
 int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, long long src_bstride, int src_ld,

@@ -113,3 +113,38 @@ def test_focal_loss_fwd_bwd(dtype, nc):
         assert dpix.shape == (B, A // 9, dld)
         assert torch.equal(dpix[:, :, :9 * nc].reshape(B, A, nc), dcls) and torch.equal(dreg2, dreg)
         assert float(dpix[:, :, 9 * nc:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('max_norm', [0.1, 0.0])
+def test_clip_adamw_matches_torch(max_norm):
+    """effdet_clip_adamw_step vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW on the same GPU tensors
+    (ragged sizes, an unaligned gradient view, a parameter without gradient), three steps."""
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    g = torch.Generator().manual_seed(21)
+    shapes = [(256, 256, 3, 3), (17,), (4097,), (3, 5, 7), (1,), (720, 256, 3, 3), (64,), (8193,)]
+    pa = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = ClipAdamW(pa, lr=1e-2, weight_decay=0.01, max_norm=max_norm)
+    ob = torch.optim.AdamW(pb, lr=1e-2, weight_decay=0.01)
+    for it in range(3):
+        big = torch.randn(20000, generator=g).cuda() * (3.0 if it else 0.01)      # first step: norm below max_norm*...
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if i == 4 and it == 1:
+                a.grad = None; b.grad = None                                        # parameter skipped this step
+                continue
+            gr = torch.randn(a.shape, generator=g).cuda() * (0.02 if it == 0 else 1.0)
+            if i == 1:
+                a.grad = big[3:3 + 17].view(17)                                     # 12-byte-offset view: unaligned path
+                b.grad = a.grad.clone()
+            else:
+                a.grad = gr; b.grad = gr.clone()
+        if max_norm:
+            ref_norm = torch.nn.utils.clip_grad_norm_(pb, max_norm)
+        oa.step(); ob.step()
+        torch.cuda.synchronize()
+        if max_norm:
+            assert abs(float(oa.grad_norm()) - float(ref_norm)) <= 2e-6 * float(ref_norm)
+        for a, b in zip(pa, pb):
+            assert_close(a.detach().cpu(), b.detach().cpu(), 1e-5, 'param step %d' % it)
+    st = oa.state_dict()
+    assert len(st['state']) == len(shapes)
