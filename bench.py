@@ -143,10 +143,14 @@ def main():
         'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / ms_step, 2) if a.network == 'efficientdet-d0' and a.size == 512 else None,
     }
 
-    if rank == 0 and not a.no_roofline:
-        # live per-launch timing of the MFMA kernels with HIP events on the launch stream (one instrumented step)
-        ops.PROFILE = ops.LaunchProfile()
+    if not a.no_roofline:
+        # live per-launch timing of the MFMA kernels with HIP events on the launch stream (one instrumented step).
+        # EVERY rank runs the step (under DDP its gradient all-reduce is collective); only rank 0 instruments it.
+        if rank == 0:
+            ops.PROFILE = ops.LaunchProfile()
         step()
+        torch.cuda.synchronize()
+    if rank == 0 and not a.no_roofline:
         summ = ops.PROFILE.summary(); ops.PROFILE = None
         peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
         hbm = {k: v for k, v in summ.items() if not k.startswith('conv_')}       # byte-counted (HBM-bound) kernels
