@@ -75,12 +75,16 @@ def main():
     a = parse()
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
     assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    ndev = torch.cuda.device_count()
+    if local >= ndev:      # debug only (EFFDET_BENCH_BACKEND=gloo): several ranks sharing one GPU to exercise the N>1 control flow
+        assert os.environ.get('EFFDET_BENCH_BACKEND') == 'gloo', 'rank %d has no GPU of its own (%d visible)' % (local, ndev)
+        local %= ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, ops, ddp
     import torch.distributed as dist
     if world > 1:
-        ddp.init_process_group_from_env('nccl')
+        ddp.init_process_group_from_env(os.environ.get('EFFDET_BENCH_BACKEND', 'nccl'))     # 'nccl' IS RCCL on ROCm
     dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
     cfg = EFFICIENTDET[a.network]
     torch.manual_seed(0)
