@@ -138,11 +138,6 @@ __device__ __forceinline__ void dma16_async(u32x4_t rsrc, unsigned lds_byte_addr
                :: "s"(lds_byte_addr), "v"(byte_off), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// wait until at most N of this wave's DMA instructions are still in flight (they complete in issue order)
-template <int N> __device__ __forceinline__ void dma_wait_keep() {
-  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 
 // 4 consecutive elements (16 B fp32 / 8 B bf16) through an SRD -> 4 floats
 template <typename T> __device__ __forceinline__ f32x4 srd_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off);

@@ -40,7 +40,7 @@ struct ConvK {
   int ldx, ldy;
   int Kc;    // K in 16-byte chunks (= KH*KW*Cin/CE)
   int cpt;   // chunks per tap (= Cin/CE)
-  int act, res_mode, out_f32, vec_ok, vec16_ok;
+  int act, res_mode, out_f32, vec_ok;
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   SegD seg[EFFDET_MAX_SEG];
@@ -327,9 +327,6 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   k.nseg = p->nseg;
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
-  // 16-byte row stores of the LDS-transposed epilogue: rows / level offsets aligned to 8 elements (bf16) or 4 (fp32)
-  const int al16 = (p->dtype == EFFDET_F32 || p->out_f32) ? 4 : 8;
-  bool vec16 = (p->ldy % al16 == 0);
   for (int s = 0; s < p->nseg; ++s) {
     const effdet_seg_t& g = p->seg[s];
     SegD& d = k.seg[s];
@@ -340,11 +337,10 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     if (d.M <= 0) return EFFDET_EINVAL;
     if (g.in_off % ce || g.in_bstride % ce) return EFFDET_EUNSUPPORTED;
     if (g.out_off % 4 || g.out_bstride % 4) vec = false;
-    if (g.out_off % al16 || g.out_bstride % al16) vec16 = false;
     tiles += (d.M + BM - 1) / BM;
   }
   for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
-  k.mtiles = tiles; k.vec_ok = vec ? 1 : 0; k.vec16_ok = (vec && vec16) ? 1 : 0;
+  k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
   // byte extents actually addressed through each segment's SRD (32-bit offsets): refuse tensors beyond 4 GiB - 64 KiB
   const long long es = p->dtype == EFFDET_F32 ? 4 : 2;
   for (int s = 0; s < p->nseg; ++s) {

@@ -7,6 +7,7 @@
 // the input -- and no k*k re-reads through L1: every kernel stages a halo'd tile in LDS by direct-to-LDS DMA and reads
 // its taps from there (the first, direct version issued k*k bounds-checked 8/16-byte global loads per output and ran
 // at ~1-2 TB/s of algorithmic bytes).  Only weight gradients of <= 8x8 maps still use the direct kernel.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -35,50 +36,52 @@ template <int K, int S> struct DwTile {
   static constexpr int TH = (S == 1) ? 16 : 8, TW = 8;                        // forward OUTPUT tile (4 / 2 outputs per thread)
   static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;         // staged input tile
   static constexpr int IWH = (IW + 1) / 2, IWP = (S == 1) ? IW : 2 * IWH;    // padded row length of the LDS image
-  static constexpr int NPIX = IH * IWP, NPIECE = (NPIX + 7) / 8;
+  static constexpr int NPIX = IH * IWP;
+  static constexpr int npiece(int px) { return (NPIX + px - 1) / px; }     // DMA pieces of px pixel slots (1 KiB each)
   static __device__ __forceinline__ int slot(int ih, int iw) {
     return (S == 1) ? ih * IWP + iw : ih * IWP + (iw & 1) * IWH + (iw >> 1);
   }
 };
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, int CQ>
 __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
   typedef DwTile<K, S> TL;
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
+  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX);  // pixel slots per 1-KiB DMA piece (CQ chunks each)
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
-  uint4* xt = sm;                                       // [NPIECE*8][8] chunks
-  float* wt = (float*)(sm + TL::NPIECE * 64);           // [K*K][8*CE] weights of this slab
+  uint4* xt = sm;                                       // [NPIECE*PX][CQ] chunks
+  float* wt = (float*)(sm + NPIECE * 64);               // [K*K][CQ*CE] weights of this slab
   __shared__ float red[4][8 * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
   const int oh0 = (tr / tiles_x) * TL::TH, ow0 = (tr % tiles_x) * TL::TW;
-  const int chunk0 = blockIdx.y * 8;                    // first channel chunk of the slab
+  const int chunk0 = blockIdx.y * CQ;                   // first channel chunk of the slab
   const int hi_org = oh0 * S - p.pad_t, wi_org = ow0 * S - p.pad_l;
   const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
   const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
   // ---- stage the input tile ----
   {
-    const int pl = lane >> 3, cq = lane & 7;
+    const int pl = lane / CQ, cq = lane % CQ;
     const bool cok = chunk0 + cq < p.nch;
-    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
-      const int q = piece * 8 + pl;                     // LDS pixel slot
+    for (int piece = wave; piece < NPIECE; piece += 4) {
+      const int q = piece * PX + pl;                    // LDS pixel slot
       int ih = q / TL::IWP, r = q - ih * TL::IWP, iw;
       if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
       const int hi = hi_org + ih, wi = wi_org + iw;
       const bool ok = cok && q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
       srd_dma16(rx, (void*)(xt + piece * 64), ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
     }
-    for (int i = tid; i < K * K * 8 * CE; i += 256) {
-      const int t = i / (8 * CE), c = chunk0 * CE + (i - t * 8 * CE);
+    for (int i = tid; i < K * K * CQ * CE; i += 256) {
+      const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
       wt[i] = c < p.C ? p.w[t * p.C + c] : 0.f;
     }
   }
   __syncthreads();
   // ---- compute: thread = (chunk cq, pixel slot ps); NOUT outputs per thread ----
-  constexpr int NOUT = TL::TH * TL::TW / 32;
-  const int cq = tid & 7, ps = tid >> 3;
+  constexpr int NPS = 256 / CQ, NOUT = TL::TH * TL::TW / NPS;
+  const int cq = tid % CQ, ps = tid / CQ;
   const int c0 = (chunk0 + cq) * CE;
   const bool cok = chunk0 + cq < p.nch;
   float acc[NOUT][CE];
@@ -91,14 +94,14 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
 #pragma unroll
     for (int kw = 0; kw < K; ++kw) {
       float wv[CE];
-      const float* wp = wt + (kh * K + kw) * 8 * CE + cq * CE;
+      const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
 #pragma unroll
       for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) {
-        const int op = ps + 32 * o, oh = op / TL::TW, ow = op - oh * TL::TW;
+        const int op = ps + NPS * o, oh = op / TL::TW, ow = op - oh * TL::TW;
         float xv[CE];
-        Chunk<T>::unpack(xt[TL::slot(oh * S + kh, ow * S + kw) * 8 + cq], xv);
+        Chunk<T>::unpack(xt[TL::slot(oh * S + kh, ow * S + kw) * CQ + cq], xv);
 #pragma unroll
         for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(xv[e], wv[e], acc[o][e]);
       }
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
-    const int op = ps + 32 * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
+    const int op = ps + NPS * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
     if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
     const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
     float zv[CE], yv[CE];
@@ -129,15 +132,20 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     for (int e = 0; e < CE; ++e) psum[e] += yr[e];
   }
   if (p.pool) {
-    // sum over the 32 pixel slots: lanes with equal (lane & 7) inside the wave, then the 4 waves through LDS
+    // sum over the pixel slots: lanes with equal (lane % CQ) inside the wave, then the 4 waves through LDS
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { float v = psum[e]; v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); psum[e] = v; }
-    if (lane < 8) {
+    for (int e = 0; e < CE; ++e) {
+      float v = psum[e];
+#pragma unroll
+      for (int o = 32; o >= CQ; o >>= 1) v += __shfl_xor(v, o, 64);
+      psum[e] = v;
+    }
+    if (lane < CQ) {
 #pragma unroll
       for (int e = 0; e < CE; ++e) red[wave][lane * 8 + e] = psum[e];
     }
     __syncthreads();
-    if (tid < 8 * CE) {
+    if (tid < CQ * CE) {
       const int l = tid / CE, e = tid - l * CE;
       const float v = red[0][l * 8 + e] + red[1][l * 8 + e] + red[2][l * 8 + e] + red[3][l * 8 + e];
       const int cch = (chunk0 + l) * CE + e;
@@ -150,52 +158,55 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
 template <int K, int S> struct DgTile {
   static constexpr int TH = 16, TW = (S == 1) ? 8 : 16;                       // 4 / 8 (= 4 classes x 2) outputs per thread
   static constexpr int IH = (S == 1) ? TH + K - 1 : TH / 2 + (K + 1) / 2, IW = (S == 1) ? TW + K - 1 : TW / 2 + (K + 1) / 2;
-  static constexpr int NPIX = IH * IW, NPIECE = (NPIX + 7) / 8;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int npiece(int px) { return (NPIX + px - 1) / px; }
 };
 __device__ __forceinline__ int floordiv2(int v) { return v >> 1; }       // arithmetic shift = floor for negatives
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, int CQ>
 __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
   typedef DgTile<K, S> TL;
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
+  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX);
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
   uint4* zt = sm;
-  float* wt = (float*)(sm + TL::NPIECE * 64);           // [K*K][8*CE], scale folded in
+  float* wt = (float*)(sm + NPIECE * 64);               // [K*K][CQ*CE], scale folded in
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.W + TL::TW - 1) / TL::TW, tiles_y = (p.H + TL::TH - 1) / TL::TH;
   const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
   const int h0 = (tr / tiles_x) * TL::TH, w0 = (tr % tiles_x) * TL::TW;
-  const int chunk0 = blockIdx.y * 8;
+  const int chunk0 = blockIdx.y * CQ;
   // first dz row / column the tile can touch
   const int ro0 = (S == 1) ? h0 + p.pad_t - (K - 1) : floordiv2(h0 + p.pad_t - (K - 1) + 1);
   const int co0 = (S == 1) ? w0 + p.pad_l - (K - 1) : floordiv2(w0 + p.pad_l - (K - 1) + 1);
   const __amdgpu_buffer_rsrc_t rz = make_srd(p.x, p.x_bytes);          // p.x carries dz
   const unsigned img_off = (unsigned)((long long)b * p.Ho * p.Wo * p.C * ES);
   {
-    const int pl = lane >> 3, cq = lane & 7;
+    const int pl = lane / CQ, cq = lane % CQ;
     const bool cok = chunk0 + cq < p.nch;
-    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
-      const int q = piece * 8 + pl;
+    for (int piece = wave; piece < NPIECE; piece += 4) {
+      const int q = piece * PX + pl;
       const int ih = q / TL::IW, iw = q - ih * TL::IW;
       const int ho = ro0 + ih, wo = co0 + iw;
       const bool ok = cok && q < TL::NPIX && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
       srd_dma16(rz, (void*)(zt + piece * 64), ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
     }
-    for (int i = tid; i < K * K * 8 * CE; i += 256) {
-      const int t = i / (8 * CE), c = chunk0 * CE + (i - t * 8 * CE);
+    for (int i = tid; i < K * K * CQ * CE; i += 256) {
+      const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
       wt[i] = c < p.C ? p.w[t * p.C + c] * (p.scale ? p.scale[c] : 1.f) : 0.f;
     }
   }
   __syncthreads();
-  const int cq = tid & 7, ps = tid >> 3;
+  constexpr int NPS = 256 / CQ;
+  const int cq = tid % CQ, ps = tid / CQ;
   const int c0 = (chunk0 + cq) * CE;
   const bool cok = chunk0 + cq < p.nch;
   const int HW = p.H * p.W;
   // S == 1: 8 outputs per thread, all taps valid.  S == 2: 4 parity classes x 2 outputs per thread; in class (ph, pw)
   // only taps with (h + pad_t - kh) even, i.e. kh = (h + pad_t) & 1, +2, ... are valid (same for columns).
   constexpr int NCLS = (S == 1) ? 1 : 4;
-  constexpr int NOUT = TL::TH * TL::TW / 32 / NCLS;
+  constexpr int NOUT = TL::TH * TL::TW / NPS / NCLS;
 #pragma unroll
   for (int cls = 0; cls < NCLS; ++cls) {
     const int ph = cls >> 1, pw = cls & 1;
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
     int lh[NOUT], lw[NOUT];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-      const int op = ps + 32 * o;
+      const int op = ps + NPS * o;
       if (S == 1) { lh[o] = op / TL::TW; lw[o] = op - lh[o] * TL::TW; }
       else { const int hh = op / (TL::TW / 2), ww = op - hh * (TL::TW / 2); lh[o] = 2 * hh + ph; lw[o] = 2 * ww + pw; }   // TW = 16 here
 #pragma unroll
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
         const int kw = (S == 1) ? c : kw0 + 2 * c;
         if (kw >= K) continue;
         float wv[CE];
-        const float* wp = wt + (kh * K + kw) * 8 * CE + cq * CE;
+        const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
 #pragma unroll
         for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
 #pragma unroll
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
           const int hn = h0 + lh[o] + p.pad_t - kh, wn = w0 + lw[o] + p.pad_l - kw;
           const int ih = ((S == 1) ? hn : (hn >> 1)) - ro0, iw = ((S == 1) ? wn : (wn >> 1)) - co0;
           float dv[CE];
-          Chunk<T>::unpack(zt[(ih * TL::IW + iw) * 8 + cq], dv);
+          Chunk<T>::unpack(zt[(ih * TL::IW + iw) * CQ + cq], dv);
 #pragma unroll
           for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(dv[e], wv[e], acc[o][e]);
         }
@@ -320,23 +331,24 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
 // run of consecutive output pixels of one tile row, so that for stride 1 a tap row is a sliding window over
 // NOUT + K - 1 LDS values instead of NOUT * K.  The k*k*CPT accumulators stay in registers across all tiles; one
 // shuffle + LDS reduction per workgroup writes its slab row (summed by dw_wgrad_reduce_kernel).
-template <typename T, int K, int S>
+template <typename T, int K, int S, int CQ>
 __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   typedef DwTile<K, S> TL;
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
   constexpr int CPT = (K == 5 && CE == 8) ? 4 : CE;       // channels per thread: K*K*CPT accumulators must fit in registers
-  constexpr int NCG = 8 * CE / CPT, NPS = 256 / NCG;      // channel groups per 8-chunk slab, pixel slots
+  constexpr int NCG = CQ * CE / CPT, NPS = 256 / NCG;     // channel groups per CQ-chunk slab, pixel slots
   constexpr int NPIX = TL::TH * TL::TW, NOUT = NPIX / NPS;
   constexpr int ROWS = K * K + 1;
+  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX), SLABC = CQ * CE;   // DMA piece geometry; channels per slab
   static_assert(S == 2 || NOUT <= TL::TW, "stride 1: a thread's pixels are one run inside a tile row");
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
-  uint4* xt = sm;                                        // [NPIECE*8 pixel slots][8 chunks]; reused for the final reduction
+  uint4* xt = sm;                                        // [NPIECE*PX pixel slots][CQ chunks]; reused for the final reduction
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
   const int groups = (tpi + p.ppt - 1) / p.ppt;
   const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
-  const int chunk0 = blockIdx.y * 8;
+  const int chunk0 = blockIdx.y * CQ;
   const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t rz = make_srd(p.aux, (unsigned)((long long)p.B * p.Ho * p.Wo * p.C * ES));   // dz (host checks < 4 GiB)
   const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
@@ -344,8 +356,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   const int cg = tid % NCG, ps = tid / NCG;
   const int c0 = chunk0 * CE + cg * CPT;                  // first channel of this thread
   const bool cok = c0 < p.C;
-  const unsigned lds_c = (unsigned)(cg * CPT) * ES;       // byte offset of the thread's channels inside a pixel's 128-B row
-  const int st_pl = lane >> 3, st_cq = lane & 7;
+  const unsigned lds_c = (unsigned)(cg * CPT) * ES;       // byte offset of the thread's channels inside a pixel's CQ*16-B row
+  const int st_pl = lane / CQ, st_cq = lane % CQ;
   const bool st_cok = chunk0 + st_cq < p.nch;
 
   float g[K * K][CPT], ds[CPT];
@@ -357,7 +369,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   for (int e = 0; e < CPT; ++e) ds[e] = 0.f;
 
   auto ldx = [&](int slot, float* v) {                   // CPT channels of one staged pixel
-    const char* q = (const char*)xt + (unsigned)slot * 128u + lds_c;
+    const char* q = (const char*)xt + (unsigned)slot * (CQ * 16u) + lds_c;
     if constexpr (CPT * ES == 16) {
       Chunk<T>::unpack(*(const uint4*)q, v);
     } else {                                              // bf16, 4 channels = 8 bytes
@@ -371,8 +383,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
     const int oh0 = (tile / tiles_x) * TL::TH, ow0 = (tile % tiles_x) * TL::TW;
     const int hi_org = oh0 * S - p.pad_t, wi_org = ow0 * S - p.pad_l;
     __syncthreads();                                      // every wave is done reading the previous tile
-    for (int piece = wave; piece < TL::NPIECE; piece += 4) {
-      const int q = piece * 8 + st_pl;
+    for (int piece = wave; piece < NPIECE; piece += 4) {
+      const int q = piece * PX + st_pl;
       int ih = q / TL::IWP, r = q - ih * TL::IWP, iw;
       if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
       const int hi = hi_org + ih, wi = wi_org + iw;
@@ -433,7 +445,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   }
   // ---- reduce over the pixel slots: shuffles inside the wave, then the 4 waves through LDS (tile memory reused) ----
   __syncthreads();
-  float* red = (float*)sm;                                // [4 waves][ROWS][8*CE]
+  float* red = (float*)sm;                                // [4 waves][ROWS][SLABC]
   auto wred = [&](float v) {
 #pragma unroll
     for (int o = 32; o >= NCG; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -444,7 +456,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
 #pragma unroll
     for (int e = 0; e < CPT; ++e) {
       const float v = wred(t < K * K ? g[t < K * K ? t : 0][e] : ds[e]);
-      if (lane < NCG) red[(wave * ROWS + t) * (8 * CE) + cg * CPT + e] = v;
+      if (lane < NCG) red[(wave * ROWS + t) * SLABC + cg * CPT + e] = v;
     }
   }
   __syncthreads();
@@ -452,10 +464,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   // hundred per line over the whole launch (the same-line serialisation that hurts is ONE lane per instruction onto a
   // shared line).  g / dsum are zeroed by the caller; this replaces the per-workgroup slabs + reduce launch.
   float* gout = (float*)p.y;                              // [K*K][C]
-  for (int i = tid; i < ROWS * 8 * CE; i += 256) {
-    const int t = i / (8 * CE), c = i - t * (8 * CE);
+  for (int i = tid; i < ROWS * SLABC; i += 256) {
+    const int t = i / SLABC, c = i - t * SLABC;
     const int ch = chunk0 * CE + c;
-    const float v = red[i] + red[ROWS * 8 * CE + i] + red[2 * ROWS * 8 * CE + i] + red[3 * ROWS * 8 * CE + i];
+    const float v = red[i] + red[ROWS * SLABC + i] + red[2 * ROWS * SLABC + i] + red[3 * ROWS * SLABC + i];
     if (ch < p.C) atomicAdd(t < K * K ? gout + (long long)t * p.C + ch : p.pool + ch, v);     // p.pool carries dsum here
   }
 }
@@ -514,49 +526,62 @@ int fill(DwK& k, int dtype, int B, int H, int W, int C, int kk, int stride, int 
 }  // namespace
 
 namespace {
-template <template <typename, int, int> class Kern> struct LdsLaunch {};
-template <typename T, int K, int S>
+// Slab width: 8 channel chunks (128-B pixel rows) unless that leaves >= 15 % of the lanes on channel padding, in which
+// case 4 chunks (C = 32: 4 of 8 chunk lanes live, C = 96: 12 of 16, C = 144: 18 of 24 -- the three largest maps of
+// EfficientNet-B0..B2).  Half-width slabs read 64-B pixel rows, so they are not the default.
+inline int slab_chunks(int nch) {
+  const int p8 = (nch + 7) / 8 * 8, p4 = (nch + 3) / 4 * 4;
+  static const int force = getenv("EFFDET_DW_SLAB") ? atoi(getenv("EFFDET_DW_SLAB")) : 0;     // A/B switch: 4 or 8
+  if (force == 4 || force == 8) return force;
+  return (p8 - p4) * 100 >= 15 * p8 ? 4 : 8;
+}
+template <typename T, int K, int S, int CQ>
 int launch_fwd_lds(const DwK& a, hipStream_t st) {
   typedef DwTile<K, S> TL;
-  const size_t lds = (size_t)TL::NPIECE * 1024 + (size_t)K * K * 8 * Elem<T>::CE * 4;
-  dim3 grid(a.B * ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), (a.nch + 7) / 8);
+  const size_t lds = (size_t)TL::npiece(64 / CQ) * 1024 + (size_t)K * K * CQ * Elem<T>::CE * 4;
+  dim3 grid(a.B * ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), (a.nch + CQ - 1) / CQ);
   static bool once = false;   // per instantiation; idempotent, benign race
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-  hipLaunchKernelGGL((dw_fwd_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_fwd_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
-template <typename T, int K, int S>
+template <typename T, int K, int S, int CQ>
 int launch_dgrad_lds(const DwK& a, hipStream_t st) {
   typedef DgTile<K, S> TL;
-  const size_t lds = (size_t)TL::NPIECE * 1024 + (size_t)K * K * 8 * Elem<T>::CE * 4;
-  dim3 grid(a.B * ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), (a.nch + 7) / 8);
+  const size_t lds = (size_t)TL::npiece(64 / CQ) * 1024 + (size_t)K * K * CQ * Elem<T>::CE * 4;
+  dim3 grid(a.B * ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), (a.nch + CQ - 1) / CQ);
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-  hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
-template <typename T, int K, int S>
+template <typename T, int K, int S, int CQ>
 int launch_wgrad_lds(const DwK& a, hipStream_t st) {
   typedef DwTile<K, S> TL;
-  size_t lds = (size_t)TL::NPIECE * 1024;
-  const size_t red = (size_t)4 * (K * K + 1) * 8 * Elem<T>::CE * 4;
+  size_t lds = (size_t)TL::npiece(64 / CQ) * 1024;
+  const size_t red = (size_t)4 * (K * K + 1) * CQ * Elem<T>::CE * 4;
   if (red > lds) lds = red;
   const int tpi = ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW);
-  dim3 grid(a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + 7) / 8);
+  dim3 grid(a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + CQ - 1) / CQ);
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_lds_kernel<T, K, S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
-  hipLaunchKernelGGL((dw_wgrad_lds_kernel<T, K, S>), grid, dim3(256), lds, st, a);
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  hipLaunchKernelGGL((dw_wgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
+#define DW_DISPATCH_Q(FN, T, k, s, a, st)                                                               \
+  do {                                                                                                  \
+    if (slab_chunks((a).nch) == 4) {                                                                    \
+      if ((k) == 3) { if ((s) == 1) FN<T, 3, 1, 4>(a, st); else FN<T, 3, 2, 4>(a, st); }                \
+      else { if ((s) == 1) FN<T, 5, 1, 4>(a, st); else FN<T, 5, 2, 4>(a, st); }                         \
+    } else {                                                                                            \
+      if ((k) == 3) { if ((s) == 1) FN<T, 3, 1, 8>(a, st); else FN<T, 3, 2, 8>(a, st); }                \
+      else { if ((s) == 1) FN<T, 5, 1, 8>(a, st); else FN<T, 5, 2, 8>(a, st); }                         \
+    }                                                                                                   \
+  } while (0)
 #define DW_DISPATCH(FN, dtype, k, s, a, st)                                                    \
   do {                                                                                         \
-    if ((dtype) == EFFDET_F32) {                                                               \
-      if ((k) == 3) { if ((s) == 1) FN<float, 3, 1>(a, st); else FN<float, 3, 2>(a, st); }     \
-      else { if ((s) == 1) FN<float, 5, 1>(a, st); else FN<float, 5, 2>(a, st); }              \
-    } else {                                                                                   \
-      if ((k) == 3) { if ((s) == 1) FN<bf16_t, 3, 1>(a, st); else FN<bf16_t, 3, 2>(a, st); }   \
-      else { if ((s) == 1) FN<bf16_t, 5, 1>(a, st); else FN<bf16_t, 5, 2>(a, st); }            \
-    }                                                                                          \
+    if ((dtype) == EFFDET_F32) DW_DISPATCH_Q(FN, float, k, s, a, st);                          \
+    else DW_DISPATCH_Q(FN, bf16_t, k, s, a, st);                                               \
   } while (0)
 }  // namespace
 
@@ -613,7 +638,7 @@ int wgrad_plan(DwK& a, dim3& grid, int dtype, int B, int H, int W, int C, int k,
   // forward tiles (16x8 at stride 1, 8x8 at stride 2) walked `ppt` at a time by one workgroup: fat workgroups (each
   // ends in a reduction + a slab row that the reduce kernel has to sum), but at least ~768 of them
   const int th = stride == 1 ? 16 : 8, tw = 8;
-  const int tpi = ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw), nslab = (a.nch + 7) / 8;
+  const int tpi = ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw), cq = slab_chunks(a.nch), nslab = (a.nch + cq - 1) / cq;
   long long ppt = (long long)tpi * B * nslab / 768;
   if (ppt < 1) ppt = 1;
   if (ppt > 16) ppt = 16;
