@@ -21,14 +21,29 @@ struct DwK {
   unsigned x_bytes;  // byte extent of the tensor read through the SRD (x, or dz for the data gradient)
   int nch;        // channel chunks (C / CE, rounded up)
   int tx;         // chunk lanes per block (power of two <= 64)
-  int ppt;        // pixels per thread
+  int ppt;        // pixels per thread (direct kernels) / tiles per workgroup (LDS kernels)
+  int nbuf;       // LDS tile buffers of the forward / data-gradient kernels: 2 = prefetch the next tile under the taps
+  int nslab;      // channel slabs (LDS kernels, 1-D grid of tile groups x slabs); 0 = legacy 2-D grid (x = groups, y = slabs)
 };
 
+// (tile group, slab) of this workgroup.  A pixel row of C channels is cut into slabs of 64 / 128 B, and unless C * 2 B is
+// a multiple of 128 B a slab's segments do not cover whole cache lines: with the slab as the SLOW grid dimension every
+// line was fetched twice and written back in pieces by workgroups that ran far apart in time (C = 144, 128^2, batch 32:
+// 215 us with the pre-activation copy, 119 us without -- the extra 151 MB cost 1.6 TB/s).  Here the slabs of one tile
+// group are CONSECUTIVE logical ids on the SAME XCD (xcd_remap), so the partial lines meet in that XCD's L2.
+__device__ __forceinline__ int2 slab_block(const DwK& p) {
+  if (p.nslab == 0) return make_int2((int)blockIdx.x, (int)blockIdx.y);
+  const int L = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+  const int g = L / p.nslab;
+  return make_int2(g, L - g * p.nslab);
+}
+
 // ---------------------------------------------------------------- LDS-tiled forward / data gradient
-// One workgroup = one image x one TH x TW output tile x one slab of 8 channel chunks (64 bf16 / 32 fp32 channels).
-// The halo'd source tile is staged ONCE by direct-to-LDS DMA (srd_dma16: 8 pixels x 8 chunks = 1 KiB per wave
-// instruction, lane-linear; out-of-image / out-of-slab lanes pass EFFDET_OOB = the zero padding of TF-"same"),
-// then every tap is a ds_read_b128.  This replaces k*k L1/TA round trips per output by one HBM/L2 read per input
+// One workgroup = one image x a run of `ppt` TH x TW output tiles x one slab of CQ = 8 (or 4) channel chunks (64 / 32
+// bf16 channels).  Each halo'd source tile is staged ONCE by direct-to-LDS DMA (64 / CQ pixels x CQ chunks = 1 KiB per
+// wave instruction, lane-linear; out-of-image / out-of-slab lanes pass EFFDET_OOB = the zero padding of TF-"same"), the
+// next tile of the run is prefetched into a second LDS buffer while the taps of the current one run (asm DMA), and
+// every tap is a ds_read_b128.  The slabs of one tile run are neighbouring workgroups on one XCD (slab_block below).  This replaces k*k L1/TA round trips per output by one HBM/L2 read per input
 // element (x ~1.3-1.6 halo overhead).  Stride 2: the LDS pixel order de-interleaves even / odd columns so that the
 // 8 pixels a wave reads together are contiguous (no bank conflicts); the stride-2 data gradient walks the four
 // (row, column) parity classes one after the other so that the valid-tap set is uniform across the wave.
@@ -49,64 +64,49 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
   constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX);  // pixel slots per 1-KiB DMA piece (CQ chunks each)
+  constexpr int TILE = NPIECE * 64;                     // uint4 per staged tile
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
-  uint4* xt = sm;                                       // [NPIECE*PX][CQ] chunks
-  float* wt = (float*)(sm + NPIECE * 64);               // [K*K][CQ*CE] weights of this slab
+  uint4* xt = sm;                                       // [nbuf][NPIECE*PX][CQ] chunks
+  float* wt = (float*)(sm + p.nbuf * TILE);             // [K*K][CQ*CE] weights of this slab
   __shared__ float red[4][8 * 8];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH;
-  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
-  const int oh0 = (tr / tiles_x) * TL::TH, ow0 = (tr % tiles_x) * TL::TW;
-  const int chunk0 = blockIdx.y * CQ;                   // first channel chunk of the slab
-  const int hi_org = oh0 * S - p.pad_t, wi_org = ow0 * S - p.pad_l;
-  const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
+  const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
+  // a workgroup walks `ppt` consecutive tiles of ONE image (so the squeeze-excite partial sums stay in registers)
+  const int groups = (tpi + p.ppt - 1) / p.ppt;
+  const int2 bs = slab_block(p);
+  const int b = bs.x / groups, t0 = (bs.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = bs.y * CQ;                         // first channel chunk of the slab
+  const u32x4_t rx = make_srd_raw(p.x, p.x_bytes);
   const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
-  // ---- stage the input tile ----
-  {
-    const int pl = lane / CQ, cq = lane % CQ;
-    const bool cok = chunk0 + cq < p.nch;
+  const unsigned xt_a = lds_addr(xt);
+  const int st_pl = lane / CQ, st_cq = lane % CQ;
+  const bool st_cok = chunk0 + st_cq < p.nch;
+  // Stage one halo'd input tile: asm DMA (invisible to hipcc's waitcnt pass), so that tile t+1 lands UNDER the taps of
+  // tile t.  With the builtin the prefetch was drained before the first ds_read of the current tile, i.e. a workgroup
+  // alternated "wait for HBM" and "compute" phases and the kernel ran at ~2.3 TB/s with 4-6 workgroups per CU.
+  auto stage = [&](int tile, int buf) {
+    const int ty = tile / tiles_x, tx_ = tile - ty * tiles_x;
+    const int hi_org = ty * TL::TH * S - p.pad_t, wi_org = tx_ * TL::TW * S - p.pad_l;
     for (int piece = wave; piece < NPIECE; piece += 4) {
-      const int q = piece * PX + pl;                    // LDS pixel slot
+      const int q = piece * PX + st_pl;                 // LDS pixel slot
       int ih = q / TL::IWP, r = q - ih * TL::IWP, iw;
       if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
       const int hi = hi_org + ih, wi = wi_org + iw;
-      const bool ok = cok && q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-      srd_dma16(rx, (void*)(xt + piece * 64), ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
+      const bool ok = st_cok && q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+      dma16_async(rx, (unsigned)__builtin_amdgcn_readfirstlane((int)(xt_a + (unsigned)(buf * TILE + piece * 64) * 16u)),
+                  ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + st_cq) * CE) * ES : EFFDET_OOB);
     }
-    for (int i = tid; i < K * K * CQ * CE; i += 256) {
-      const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
-      wt[i] = c < p.C ? p.w[t * p.C + c] : 0.f;
-    }
+  };
+  stage(t0, 0);
+  for (int i = tid; i < K * K * CQ * CE; i += 256) {
+    const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
+    wt[i] = c < p.C ? p.w[t * p.C + c] : 0.f;
   }
-  __syncthreads();
-  // ---- compute: thread = (chunk cq, pixel slot ps); NOUT outputs per thread ----
+  // ---- thread = (chunk cq, pixel slot ps); NOUT outputs per thread and tile ----
   constexpr int NPS = 256 / CQ, NOUT = TL::TH * TL::TW / NPS;
   const int cq = tid % CQ, ps = tid / CQ;
   const int c0 = (chunk0 + cq) * CE;
   const bool cok = chunk0 + cq < p.nch;
-  float acc[NOUT][CE];
-#pragma unroll
-  for (int o = 0; o < NOUT; ++o)
-#pragma unroll
-    for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
-#pragma unroll 1
-  for (int kh = 0; kh < K; ++kh) {           // NOT unrolled: the full K*K*NOUT unroll spilled to scratch (occupancy 1)
-#pragma unroll
-    for (int kw = 0; kw < K; ++kw) {
-      float wv[CE];
-      const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
-#pragma unroll
-      for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) {
-        const int op = ps + NPS * o, oh = op / TL::TW, ow = op - oh * TL::TW;
-        float xv[CE];
-        Chunk<T>::unpack(xt[TL::slot(oh * S + kh, ow * S + kw) * CQ + cq], xv);
-#pragma unroll
-        for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(xv[e], wv[e], acc[o][e]);
-      }
-    }
-  }
   float sc[CE], sh[CE], psum[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; psum[e] = 0.f; }
@@ -115,21 +115,64 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     for (int e = 0; e < CE; ++e) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
   }
   const int HoWo = p.Ho * p.Wo;
+  dma_wait_all();
+  for (int tile = t0; tile < t1; ++tile) {
+    const int cur = (p.nbuf == 2) ? ((tile - t0) & 1) : 0;
+    __syncthreads();                                    // tile `tile` is in LDS for every wave; the other buffer is free
+    if (p.nbuf == 2 && tile + 1 < t1) stage(tile + 1, cur ^ 1);
+    const uint4* xb = xt + cur * TILE;
+    float acc[NOUT][CE];
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
-    const int op = ps + NPS * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
-    if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
-    const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
-    float zv[CE], yv[CE];
+    for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { zv[e] = acc[o][e] * sc[e] + sh[e]; yv[e] = swishf_(zv[e]); }
-    if (p.z) *(uint4*)((T*)p.z + off) = Chunk<T>::pack(zv);
-    const uint4 packed = Chunk<T>::pack(yv);
-    *(uint4*)((T*)p.y + off) = packed;
-    float yr[CE];
-    Chunk<T>::unpack(packed, yr);
+      for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {           // NOT unrolled: the full K*K*NOUT unroll spilled to scratch (occupancy 1)
 #pragma unroll
-    for (int e = 0; e < CE; ++e) psum[e] += yr[e];
+      for (int kw = 0; kw < K; ++kw) {
+        float wv[CE];
+        const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
+#pragma unroll
+        for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          const int op = ps + NPS * o, oh = op / TL::TW, ow = op - oh * TL::TW;
+          float xv[CE];
+          Chunk<T>::unpack(xb[TL::slot(oh * S + kh, ow * S + kw) * CQ + cq], xv);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(xv[e], wv[e], acc[o][e]);
+        }
+      }
+    }
+    const int oh0 = (tile / tiles_x) * TL::TH, ow0 = (tile % tiles_x) * TL::TW;
+    uint4 zq[NOUT], yq[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      float zv[CE], yv[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) { zv[e] = acc[o][e] * sc[e] + sh[e]; yv[e] = swishf_(zv[e]); }
+      zq[o] = Chunk<T>::pack(zv); yq[o] = Chunk<T>::pack(yv);
+    }
+    // this wave's pieces of the NEXT tile have landed (they had the whole tap loop); waiting here, ahead of the stores,
+    // keeps the stores of this tile in flight across the barrier and the next tile's taps
+    dma_wait_all();
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const int op = ps + NPS * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
+      if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
+      const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
+      if (p.z) *(uint4*)((T*)p.z + off) = zq[o];
+      *(uint4*)((T*)p.y + off) = yq[o];
+      float yr[CE];
+      Chunk<T>::unpack(yq[o], yr);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) psum[e] += yr[e];
+    }
+    if (p.nbuf == 1 && tile + 1 < t1) {                 // single buffer (tile too large to double): restage after the reads
+      __syncthreads();
+      stage(tile + 1, 0);
+      dma_wait_all();
+    }
   }
   if (p.pool) {
     // sum over the pixel slots: lanes with equal (lane % CQ) inside the wave, then the 4 waves through LDS
@@ -168,95 +211,123 @@ __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
   typedef DgTile<K, S> TL;
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
-  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX);
+  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX), TILE = NPIECE * 64;
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
-  uint4* zt = sm;
-  float* wt = (float*)(sm + NPIECE * 64);               // [K*K][CQ*CE], scale folded in
+  uint4* zt = sm;                                       // [nbuf][TILE]
+  float* wt = (float*)(sm + p.nbuf * TILE);             // [K*K][CQ*CE], scale folded in
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_x = (p.W + TL::TW - 1) / TL::TW, tiles_y = (p.H + TL::TH - 1) / TL::TH;
-  const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x - b * tiles_x * tiles_y;
-  const int h0 = (tr / tiles_x) * TL::TH, w0 = (tr % tiles_x) * TL::TW;
-  const int chunk0 = blockIdx.y * CQ;
-  // first dz row / column the tile can touch
-  const int ro0 = (S == 1) ? h0 + p.pad_t - (K - 1) : floordiv2(h0 + p.pad_t - (K - 1) + 1);
-  const int co0 = (S == 1) ? w0 + p.pad_l - (K - 1) : floordiv2(w0 + p.pad_l - (K - 1) + 1);
-  const __amdgpu_buffer_rsrc_t rz = make_srd(p.x, p.x_bytes);          // p.x carries dz
+  const int tiles_x = (p.W + TL::TW - 1) / TL::TW, tiles_y = (p.H + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
+  const int groups = (tpi + p.ppt - 1) / p.ppt;         // same tile walk / prefetch scheme as the forward kernel
+  const int2 bs = slab_block(p);
+  const int b = bs.x / groups, t0 = (bs.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = bs.y * CQ;
+  const u32x4_t rz = make_srd_raw(p.x, p.x_bytes);      // p.x carries dz
   const unsigned img_off = (unsigned)((long long)b * p.Ho * p.Wo * p.C * ES);
-  {
-    const int pl = lane / CQ, cq = lane % CQ;
-    const bool cok = chunk0 + cq < p.nch;
+  const unsigned zt_a = lds_addr(zt);
+  const int st_pl = lane / CQ, st_cq = lane % CQ;
+  const bool st_cok = chunk0 + st_cq < p.nch;
+  // first dz row / column a tile with origin (h0, w0) can touch
+  auto row0 = [&](int h0) { return (S == 1) ? h0 + p.pad_t - (K - 1) : floordiv2(h0 + p.pad_t - (K - 1) + 1); };
+  auto col0 = [&](int w0) { return (S == 1) ? w0 + p.pad_l - (K - 1) : floordiv2(w0 + p.pad_l - (K - 1) + 1); };
+  auto stage = [&](int tile, int buf) {
+    const int ty = tile / tiles_x, tx_ = tile - ty * tiles_x;
+    const int ro0 = row0(ty * TL::TH), co0 = col0(tx_ * TL::TW);
     for (int piece = wave; piece < NPIECE; piece += 4) {
-      const int q = piece * PX + pl;
+      const int q = piece * PX + st_pl;
       const int ih = q / TL::IW, iw = q - ih * TL::IW;
       const int ho = ro0 + ih, wo = co0 + iw;
-      const bool ok = cok && q < TL::NPIX && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
-      srd_dma16(rz, (void*)(zt + piece * 64), ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C + (chunk0 + cq) * CE) * ES : EFFDET_OOB);
+      const bool ok = st_cok && q < TL::NPIX && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
+      dma16_async(rz, (unsigned)__builtin_amdgcn_readfirstlane((int)(zt_a + (unsigned)(buf * TILE + piece * 64) * 16u)),
+                  ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C + (chunk0 + st_cq) * CE) * ES : EFFDET_OOB);
     }
-    for (int i = tid; i < K * K * CQ * CE; i += 256) {
-      const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
-      wt[i] = c < p.C ? p.w[t * p.C + c] * (p.scale ? p.scale[c] : 1.f) : 0.f;
-    }
+  };
+  stage(t0, 0);
+  for (int i = tid; i < K * K * CQ * CE; i += 256) {
+    const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
+    wt[i] = c < p.C ? p.w[t * p.C + c] * (p.scale ? p.scale[c] : 1.f) : 0.f;
   }
-  __syncthreads();
   constexpr int NPS = 256 / CQ;
   const int cq = tid % CQ, ps = tid / CQ;
   const int c0 = (chunk0 + cq) * CE;
   const bool cok = chunk0 + cq < p.nch;
   const int HW = p.H * p.W;
-  // S == 1: 8 outputs per thread, all taps valid.  S == 2: 4 parity classes x 2 outputs per thread; in class (ph, pw)
+  // S == 1: 4 outputs per thread, all taps valid.  S == 2: 4 parity classes x 2 outputs per thread; in class (ph, pw)
   // only taps with (h + pad_t - kh) even, i.e. kh = (h + pad_t) & 1, +2, ... are valid (same for columns).
   constexpr int NCLS = (S == 1) ? 1 : 4;
   constexpr int NOUT = TL::TH * TL::TW / NPS / NCLS;
+  dma_wait_all();
+  for (int tile = t0; tile < t1; ++tile) {
+    const int cur = (p.nbuf == 2) ? ((tile - t0) & 1) : 0;
+    __syncthreads();
+    if (p.nbuf == 2 && tile + 1 < t1) stage(tile + 1, cur ^ 1);
+    const uint4* zb = zt + cur * TILE;
+    const int h0 = (tile / tiles_x) * TL::TH, w0 = (tile % tiles_x) * TL::TW;
+    const int ro0 = row0(h0), co0 = col0(w0);
 #pragma unroll
-  for (int cls = 0; cls < NCLS; ++cls) {
-    const int ph = cls >> 1, pw = cls & 1;
-    float acc[NOUT][CE];
-    int lh[NOUT], lw[NOUT];
+    for (int cls = 0; cls < NCLS; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      float acc[NOUT][CE];
+      int lh[NOUT], lw[NOUT];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      const int op = ps + NPS * o;
-      if (S == 1) { lh[o] = op / TL::TW; lw[o] = op - lh[o] * TL::TW; }
-      else { const int hh = op / (TL::TW / 2), ww = op - hh * (TL::TW / 2); lh[o] = 2 * hh + ph; lw[o] = 2 * ww + pw; }   // TW = 16 here
+      for (int o = 0; o < NOUT; ++o) {
+        const int op = ps + NPS * o;
+        if (S == 1) { lh[o] = op / TL::TW; lw[o] = op - lh[o] * TL::TW; }
+        else { const int hh = op / (TL::TW / 2), ww = op - hh * (TL::TW / 2); lh[o] = 2 * hh + ph; lw[o] = 2 * ww + pw; }   // TW = 16 here
 #pragma unroll
-      for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
-    }
-    // tile origin h0, w0 are multiples of 16, so the parity of (h + pad) is that of (lh + pad)
-    const int kh0 = (S == 1) ? 0 : ((ph + p.pad_t) & 1), kw0 = (S == 1) ? 0 : ((pw + p.pad_l) & 1);
+        for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+      }
+      // tile origin h0, w0 are multiples of 16, so the parity of (h + pad) is that of (lh + pad)
+      const int kh0 = (S == 1) ? 0 : ((ph + p.pad_t) & 1), kw0 = (S == 1) ? 0 : ((pw + p.pad_l) & 1);
 #pragma unroll 1
-    for (int a = 0; a < (S == 1 ? K : (K + 1) / 2); ++a) {
-      const int kh = (S == 1) ? a : kh0 + 2 * a;
-      if (kh >= K) continue;
+      for (int a = 0; a < (S == 1 ? K : (K + 1) / 2); ++a) {
+        const int kh = (S == 1) ? a : kh0 + 2 * a;
+        if (kh >= K) continue;
 #pragma unroll
-      for (int c = 0; c < (S == 1 ? K : (K + 1) / 2); ++c) {
-        const int kw = (S == 1) ? c : kw0 + 2 * c;
-        if (kw >= K) continue;
-        float wv[CE];
-        const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
+        for (int c = 0; c < (S == 1 ? K : (K + 1) / 2); ++c) {
+          const int kw = (S == 1) ? c : kw0 + 2 * c;
+          if (kw >= K) continue;
+          float wv[CE];
+          const float* wp = wt + (kh * K + kw) * CQ * CE + cq * CE;
 #pragma unroll
-        for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
+          for (int q = 0; q < CE; q += 4) { const f32x4 t = *(const f32x4*)(wp + q); wv[q] = t[0]; wv[q + 1] = t[1]; wv[q + 2] = t[2]; wv[q + 3] = t[3]; }
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-          const int hn = h0 + lh[o] + p.pad_t - kh, wn = w0 + lw[o] + p.pad_l - kw;
-          const int ih = ((S == 1) ? hn : (hn >> 1)) - ro0, iw = ((S == 1) ? wn : (wn >> 1)) - co0;
-          float dv[CE];
-          Chunk<T>::unpack(zt[(ih * TL::IW + iw) * CQ + cq], dv);
+          for (int o = 0; o < NOUT; ++o) {
+            const int hn = h0 + lh[o] + p.pad_t - kh, wn = w0 + lw[o] + p.pad_l - kw;
+            const int ih = ((S == 1) ? hn : (hn >> 1)) - ro0, iw = ((S == 1) ? wn : (wn >> 1)) - co0;
+            float dv[CE];
+            Chunk<T>::unpack(zb[(ih * TL::IW + iw) * CQ + cq], dv);
 #pragma unroll
-          for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(dv[e], wv[e], acc[o][e]);
+            for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(dv[e], wv[e], acc[o][e]);
+          }
         }
       }
-    }
+      uint4 outq[NOUT];
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) {
-      const int h = h0 + lh[o], w = w0 + lw[o];
-      if (!cok || h >= p.H || w >= p.W) continue;
-      const long long off = ((long long)b * HW + (long long)h * p.W + w) * p.C + c0;
-      if (p.aux) {
-        float av[CE];
-        Chunk<T>::unpack(*(const uint4*)((const T*)p.aux + off), av);
+      for (int o = 0; o < NOUT; ++o) {
+        const int h = h0 + lh[o], w = w0 + lw[o];
+        if (p.aux && cok && h < p.H && w < p.W) {
+          const long long off = ((long long)b * HW + (long long)h * p.W + w) * p.C + c0;
+          float av[CE];
+          Chunk<T>::unpack(*(const uint4*)((const T*)p.aux + off), av);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) acc[o][e] *= swish_gradf_(av[e]);
+          for (int e = 0; e < CE; ++e) acc[o][e] *= swish_gradf_(av[e]);
+        }
+        outq[o] = Chunk<T>::pack(acc[o]);
       }
-      *(uint4*)((T*)p.y + off) = Chunk<T>::pack(acc[o]);
+      // the next tile's pieces have landed; the stores of the last class stay in flight across the barrier
+      if (cls == NCLS - 1) dma_wait_all();
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        const int h = h0 + lh[o], w = w0 + lw[o];
+        if (!cok || h >= p.H || w >= p.W) continue;
+        const long long off = ((long long)b * HW + (long long)h * p.W + w) * p.C + c0;
+        *(uint4*)((T*)p.y + off) = outq[o];
+      }
+    }
+    if (p.nbuf == 1 && tile + 1 < t1) {
+      __syncthreads();
+      stage(tile + 1, 0);
+      dma_wait_all();
     }
   }
 }
@@ -347,8 +418,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
   const int groups = (tpi + p.ppt - 1) / p.ppt;
-  const int b = blockIdx.x / groups, t0 = (blockIdx.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
-  const int chunk0 = blockIdx.y * CQ;
+  const int2 bs = slab_block(p);
+  const int b = bs.x / groups, t0 = (bs.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = bs.y * CQ;
   const __amdgpu_buffer_rsrc_t rx = make_srd(p.x, p.x_bytes);
   const __amdgpu_buffer_rsrc_t rz = make_srd(p.aux, (unsigned)((long long)p.B * p.Ho * p.Wo * p.C * ES));   // dz (host checks < 4 GiB)
   const unsigned img_off = (unsigned)((long long)b * p.H * p.W * p.C * ES);
@@ -535,34 +607,61 @@ inline int slab_chunks(int nch) {
   if (force == 4 || force == 8) return force;
   return (p8 - p4) * 100 >= 15 * p8 ? 4 : 8;
 }
+// 1-D grid of (tile groups x slabs) with the slab fastest (see slab_block); EFFDET_DW_ORDER=0 restores the 2-D grid for A/B
+inline dim3 slab_grid(DwK& a, int groups, int nslab) {
+  static const int legacy = getenv("EFFDET_DW_ORDER") ? atoi(getenv("EFFDET_DW_ORDER")) == 0 : 0;
+  if (legacy || nslab == 1) { a.nslab = 0; return dim3(groups, nslab); }
+  a.nslab = nslab;
+  return dim3((unsigned)groups * nslab);
+}
+// tiles per workgroup of the pipelined forward / data-gradient kernels: >= ~2048 workgroups first, then up to 16 tiles each
+inline int tiles_per_wg(long long total_tiles) {
+  long long ppt = total_tiles / 2048;
+  return ppt < 1 ? 1 : (ppt > 16 ? 16 : (int)ppt);
+}
 template <typename T, int K, int S, int CQ>
-int launch_fwd_lds(const DwK& a, hipStream_t st) {
+int launch_fwd_lds(const DwK& a0, hipStream_t st) {
   typedef DwTile<K, S> TL;
-  const size_t lds = (size_t)TL::npiece(64 / CQ) * 1024 + (size_t)K * K * CQ * Elem<T>::CE * 4;
-  dim3 grid(a.B * ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), (a.nch + CQ - 1) / CQ);
+  DwK a = a0;
+  const size_t tile = (size_t)TL::npiece(64 / CQ) * 1024, wb = (size_t)K * K * CQ * Elem<T>::CE * 4;
+  const int tpi = ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), nslab = (a.nch + CQ - 1) / CQ;
+  a.ppt = tiles_per_wg((long long)tpi * a.B * nslab);
+  if (a.ppt > tpi) a.ppt = tpi;
+  static const int nb_env = getenv("EFFDET_DW_NBUF") ? atoi(getenv("EFFDET_DW_NBUF")) : 0;    // A/B switch
+  a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024 && nb_env != 1) ? 2 : 1;                  // keep >= 2 workgroups per CU
+  const size_t lds = a.nbuf * tile + wb;
+  dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), nslab);
   static bool once = false;   // per instantiation; idempotent, benign race
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile + wb)); once = true; }
   hipLaunchKernelGGL((dw_fwd_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
 template <typename T, int K, int S, int CQ>
-int launch_dgrad_lds(const DwK& a, hipStream_t st) {
+int launch_dgrad_lds(const DwK& a0, hipStream_t st) {
   typedef DgTile<K, S> TL;
-  const size_t lds = (size_t)TL::npiece(64 / CQ) * 1024 + (size_t)K * K * CQ * Elem<T>::CE * 4;
-  dim3 grid(a.B * ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), (a.nch + CQ - 1) / CQ);
+  DwK a = a0;
+  const size_t tile = (size_t)TL::npiece(64 / CQ) * 1024, wb = (size_t)K * K * CQ * Elem<T>::CE * 4;
+  const int tpi = ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), nslab = (a.nch + CQ - 1) / CQ;
+  a.ppt = tiles_per_wg((long long)tpi * a.B * nslab);
+  if (a.ppt > tpi) a.ppt = tpi;
+  static const int nb_env = getenv("EFFDET_DW_NBUF") ? atoi(getenv("EFFDET_DW_NBUF")) : 0;
+  a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024 && nb_env != 1) ? 2 : 1;
+  const size_t lds = a.nbuf * tile + wb;
+  dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), nslab);
   static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile + wb)); once = true; }
   hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
 template <typename T, int K, int S, int CQ>
-int launch_wgrad_lds(const DwK& a, hipStream_t st) {
+int launch_wgrad_lds(const DwK& a0, hipStream_t st) {
   typedef DwTile<K, S> TL;
   size_t lds = (size_t)TL::npiece(64 / CQ) * 1024;
   const size_t red = (size_t)4 * (K * K + 1) * CQ * Elem<T>::CE * 4;
   if (red > lds) lds = red;
-  const int tpi = ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW);
-  dim3 grid(a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + CQ - 1) / CQ);
+  const int tpi = ((a0.Ho + TL::TH - 1) / TL::TH) * ((a0.Wo + TL::TW - 1) / TL::TW);
+  DwK a = a0;
+  dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + CQ - 1) / CQ);
   static bool once = false;
   if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
   hipLaunchKernelGGL((dw_wgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
