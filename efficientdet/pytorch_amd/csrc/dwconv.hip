@@ -150,8 +150,13 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     for (int o = 0; o < NOUT; ++o) {
       float zv[CE], yv[CE];
 #pragma unroll
-      for (int e = 0; e < CE; ++e) { zv[e] = acc[o][e] * sc[e] + sh[e]; yv[e] = swishf_(zv[e]); }
-      zq[o] = Chunk<T>::pack(zv); yq[o] = Chunk<T>::pack(yv);
+      for (int e = 0; e < CE; ++e) zv[e] = acc[o][e] * sc[e] + sh[e];
+      zq[o] = Chunk<T>::pack(zv);
+      // z-only mode (training): consumers recompute Swish from the STORED (rounded) z, so the SE sum must see the same
+      if (!p.y) Chunk<T>::unpack(zq[o], zv);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) yv[e] = swishf_(zv[e]);
+      yq[o] = Chunk<T>::pack(yv);
     }
     // this wave's pieces of the NEXT tile have landed (they had the whole tap loop); waiting here, ahead of the stores,
     // keeps the stores of this tile in flight across the barrier and the next tile's taps
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
       if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
       const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
       if (p.z) *(uint4*)((T*)p.z + off) = zq[o];
-      *(uint4*)((T*)p.y + off) = yq[o];
+      if (p.y) *(uint4*)((T*)p.y + off) = yq[o];
       float yr[CE];
       Chunk<T>::unpack(yq[o], yr);
 #pragma unroll
@@ -687,7 +692,7 @@ int launch_wgrad_lds(const DwK& a0, hipStream_t st) {
 extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* scale, const float* shift, void* y,
                                  void* z, float* pool, int dtype, int B, int H, int W, int C, int k, int stride,
                                  int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
-  if (!x || !w || !y) return EFFDET_EINVAL;
+  if (!x || !w || (!y && !z)) return EFFDET_EINVAL;
   DwK a{}; dim3 grid;
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, ce, Ho * Wo, grid);

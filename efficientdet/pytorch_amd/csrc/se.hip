@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void se_gate_bwd_b_kernel(const float* __restr
   if (i < Cse) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_dmid[(long long)b * Cse + i]; db1[i] = s; }
 }
 
-// ---- y = x * gate[b][c] ----
+// ---- y = act(x) * gate[b][c]   (act = Swish when x is the depthwise PRE-activation: z-only storage) ----
 template <typename T>
 __global__ void channel_scale_kernel(const T* __restrict__ x, const float* __restrict__ gate, T* __restrict__ y,
-                                     long long HW, int C, long long nchunks) {
+                                     long long HW, int C, long long nchunks, int act) {
   constexpr int CE = Elem<T>::CE;
   const int cpr = C / CE;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nchunks; i += (long long)gridDim.x * blockDim.x) {
@@ -152,6 +152,10 @@ __global__ void channel_scale_kernel(const T* __restrict__ x, const float* __res
     float v[CE];
     Chunk<T>::unpack(((const uint4*)x)[i], v);
     const float* g = gate + b * C + cc * CE;
+    if (act == EFFDET_ACT_SWISH) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = swishf_(v[e]);
+    }
 #pragma unroll
     for (int e = 0; e < CE; ++e) v[e] *= g[e];
     ((uint4*)y)[i] = Chunk<T>::pack(v);
@@ -161,7 +165,7 @@ __global__ void channel_scale_kernel(const T* __restrict__ x, const float* __res
 // ---- dgate[b][c] += sum_hw dy*x ; block = (image, pixel slab); LDS accumulate, one global atomic per channel ----
 template <typename T>
 __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                       float* __restrict__ dgate, long long HW, int C, int slabs) {
+                                                       float* __restrict__ dgate, long long HW, int C, int slabs, int act) {
   constexpr int CE = Elem<T>::CE;
   extern __shared__ float accs[];                 // [C]
   const int cpr = C / CE;
@@ -182,6 +186,10 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy,
         float a[CE], q[CE];
         Chunk<T>::unpack(((const uint4*)dy)[i], a);
         Chunk<T>::unpack(((const uint4*)x)[i], q);
+        if (act == EFFDET_ACT_SWISH) {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) q[e] = swishf_(q[e]);
+        }
 #pragma unroll
         for (int e = 0; e < CE; ++e) s[e] = fmaf(a[e], q[e], s[e]);
       }
@@ -342,24 +350,26 @@ extern "C" int effdet_se_gate_bwd(const float* dgate, const float* gate, const f
     EFFDET_CHECK_LAUNCH();                                                                      \
   } while (0)
 
-extern "C" int effdet_channel_scale(const void* x, const float* gate, void* y, int dtype, int B, long long HW, int C,
+extern "C" int effdet_channel_scale(const void* x, const float* gate, void* y, int act, int dtype, int B, long long HW, int C,
                                     effdet_stream_t stream) {
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   if (!x || !gate || !y || C % ce) return EFFDET_EINVAL;
+  if (act != EFFDET_ACT_NONE && act != EFFDET_ACT_SWISH) return EFFDET_EUNSUPPORTED;
   const long long n = (long long)B * HW * (C / ce);
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST, (const float*)x, gate, (float*)y, HW, C, n);
-  else hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)x, gate, (bf16_t*)y, HW, C, n);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(channel_scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST, (const float*)x, gate, (float*)y, HW, C, n, act);
+  else hipLaunchKernelGGL(channel_scale_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, ST, (const bf16_t*)x, gate, (bf16_t*)y, HW, C, n, act);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
-extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate, int dtype, int B, long long HW, int C,
+extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate, int act, int dtype, int B, long long HW, int C,
                                effdet_stream_t stream) {
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   if (!dy || !x || !dgate || C % ce) return EFFDET_EINVAL;
+  if (act != EFFDET_ACT_NONE && act != EFFDET_ACT_SWISH) return EFFDET_EUNSUPPORTED;
   int slabs = (int)((HW + 15) / 16); if (slabs > 64) slabs = 64; if (slabs < 1) slabs = 1;     // >= 16 pixels per workgroup
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const float*)dy, (const float*)x, dgate, HW, C, slabs);
-  else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate, HW, C, slabs);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const float*)dy, (const float*)x, dgate, HW, C, slabs, act);
+  else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate, HW, C, slabs, act);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

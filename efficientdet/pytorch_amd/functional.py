@@ -9,11 +9,15 @@ Frozen-BN backward without re-reading the conv output: for y = act(s
 s = gamma*invstd:   dz = dy*act'(z);  dx = dgrad(dz, W*s);  G = x^T dz;  dW = s*G;
 dgamma = invstd*(sum_k W*G - mean*sum dz);  dbeta = sum dz.
 """
+import os
+
 import torch
 
 from . import ops
 from .config import BN_EPS, conv_out
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE, RES_RELU_MASK, Map
+
+DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: also store the depthwise Swish output in training
 
 
 def chunk_elems(dtype):
@@ -93,11 +97,15 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     wk = ops.dw_pack_weight(P['dw.weight'])
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
     pool = ops.zeros((B, blk.cexp), dev)
-    xd, zd = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=pool)
+    # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):
+    # the gate multiply and the backward of the gate recompute Swish from it
+    z_only = train and not DW_SAVE_Y
+    xd, zd = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=pool,
+                            save_y=not z_only)
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
     gate, mid = ops.se_gate_fwd(pool, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
-    xs = ops.channel_scale(xd, gate)
+    xs = ops.channel_scale(zd, gate, ACT_SWISH) if z_only else ops.channel_scale(xd, gate)
     s2, t2, i2 = ops.bn_fold(P['bn2.weight'], P['bn2.bias'], P['bn2.running_mean'], P['bn2.running_var'], BN_EPS)
     y = Map.new(B, Ho, Wo, blk.cout, dtype, dev)
     ops.conv2d(xs, ops.pack_weight(P['project.weight'], dtype), y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1,
@@ -127,7 +135,7 @@ def mbconv_bwd(sv, dy):
     dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
     ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
     # ---- squeeze-excite ----
-    dgate = ops.se_dgate(dxs, sv['xd'])
+    dgate = ops.se_dgate(dxs, sv['xd']) if sv['xd'] is not None else ops.se_dgate(dxs, sv['zd'], ACT_SWISH)
     w1 = P['se_reduce.weight'].view(Cs, Ce); w2 = P['se_expand.weight'].view(Ce, Cs)
     dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
                                                 sv['inv_hw'])

@@ -395,12 +395,14 @@ def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
     return dw, dgb[0], dgb[1]
 
 
-def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None):
-    y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device)
+def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None, save_y=True):
+    """-> (y, z); save_y=False (needs save_z) stores the pre-activation only: consumers recompute Swish (act=ACT_SWISH)."""
+    assert save_y or save_z
+    y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_y else None
     z = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_z else None
-    nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (2 if save_z else 1))
+    nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (int(save_y) + int(save_z)))
     _timed('dw_fwd_lds_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_fwd(
-        L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t), L.ptr(z.t if z else None), L.ptr(pool),
+        L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t if y else None), L.ptr(z.t if z else None), L.ptr(pool),
         L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd'),
         'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return y, z
@@ -441,16 +443,17 @@ def se_gate_fwd(pool, w1, b1, w2, b2, inv_hw, save_mid=False):
     return gate, mid
 
 
-def channel_scale(x, gate):
+def channel_scale(x, gate, act=ACT_NONE):
+    """act(x) * gate[b][c]; act=ACT_SWISH when x is the depthwise pre-activation (z-only storage)."""
     y = Map.new(x.B, x.H, x.W, x.C, x.dtype, x.t.device)
-    L.check(L.lib().effdet_channel_scale(L.ptr(x.tensor()), L.ptr(gate), L.ptr(y.t), L.dtype_code(x.dtype), x.B,
+    L.check(L.lib().effdet_channel_scale(L.ptr(x.tensor()), L.ptr(gate), L.ptr(y.t), act, L.dtype_code(x.dtype), x.B,
                                          C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_channel_scale')
     return y
 
 
-def se_dgate(dy, x):
+def se_dgate(dy, x, act=ACT_NONE):
     dg = zeros((x.B, x.C), x.t.device)
-    L.check(L.lib().effdet_se_dgate(L.ptr(dy.tensor()), L.ptr(x.tensor()), L.ptr(dg), L.dtype_code(x.dtype), x.B,
+    L.check(L.lib().effdet_se_dgate(L.ptr(dy.tensor()), L.ptr(x.tensor()), L.ptr(dg), act, L.dtype_code(x.dtype), x.B,
                                     C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_se_dgate')
     return dg
 

@@ -141,6 +141,8 @@ int effdet_bn_param_grad(const float* wsum, const float* dsum, const float* mean
  * the per-(image, channel) sum of the output (the squeeze of squeeze-excite) as a side output.
  * Replaces models/efficientnet.py:91 (_depthwise_conv/_bn1/_swish) and the adaptive_avg_pool2d
  * of :95.  w: [k*k][C] fp32.  pool: [B][C] fp32, must be zeroed by the caller (+= atomics).
+ * y (Swish output) and z (pre-activation, for backward) are each optional but not both NULL; with
+ * y == NULL the pooled sum is that of Swish(stored z), i.e. exactly what the consumers recompute.
  * ------------------------------------------------------------------------------------------- */
 int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, const float* shift,
                       void* y, void* z, float* pool, int dtype, int B, int H, int W, int C, int k,
@@ -176,12 +178,14 @@ int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale, const floa
 int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2,
                        const float* b2, float* gate, float* mid, int B, int C, int Cse, float inv_hw,
                        effdet_stream_t stream);
-/* y = x * gate[b][c]  (models/efficientnet.py:98) */
-int effdet_channel_scale(const void* x, const float* gate, void* y, int dtype, int B, long long HW,
+/* y = act(x) * gate[b][c]  (models/efficientnet.py:98).  act = EFFDET_ACT_NONE: x is the depthwise OUTPUT;
+ * act = EFFDET_ACT_SWISH: x is the depthwise PRE-activation z (training stores z only -- the step is bound by HBM
+ * write bandwidth -- and every consumer recomputes Swish from the stored value). */
+int effdet_channel_scale(const void* x, const float* gate, void* y, int act, int dtype, int B, long long HW,
                          int C, effdet_stream_t stream);
-/* backward of (gate, scale):  given dy (grad of x*gate) and x:
- *   dgate_raw[b][c] = sum_hw dy*x   (fp32 atomics into dgate, caller zeroes)   */
-int effdet_se_dgate(const void* dy, const void* x, float* dgate, int dtype, int B, long long HW, int C,
+/* backward of (gate, scale):  given dy (grad of act(x)*gate) and x (act as above):
+ *   dgate_raw[b][c] = sum_hw dy*act(x)   (fp32 atomics into dgate, caller zeroes)   */
+int effdet_se_dgate(const void* dy, const void* x, float* dgate, int act, int dtype, int B, long long HW, int C,
                     effdet_stream_t stream);
 /* tiny FC backward: from dgate[b][c] (grad wrt gate), gate, mid, pool -> dpool[b][c] (grad wrt the
  * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (OVERWRITTEN, fp32; batch reductions with one

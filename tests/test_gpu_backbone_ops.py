@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from tests.gpu_util import assert_close
+from tests.gpu_util import assert_close, assert_close_scale
 
 pytestmark = pytest.mark.gpu
 DT = [torch.float32, torch.bfloat16]
@@ -49,6 +49,12 @@ def test_dwconv_fwd_bwd(dtype, cfg):
     torch.cuda.synchronize()
     assert_close(nchw(zm), z, TOL[dtype], 'dw z'); assert_close(nchw(ym), y, TOL[dtype], 'dw y')
     assert_close(pool.cpu(), q(y.detach()).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool')
+    # z-only storage (training): same stored z, no y, and the pooled sum is that of Swish(stored z)
+    pool2 = torch.zeros(B, C, device=dev)
+    y2, z2 = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=pool2, save_y=False)
+    assert y2 is None and torch.equal(z2.tensor(), zm.tensor())
+    zs = nchw(z2)
+    assert_close(pool2.cpu(), (zs * torch.sigmoid(zs)).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool (z-only)')
     # backward wrt the pre-activation z: dz given
     dz = q(torch.randn(z.shape, generator=g))
     z.backward(dz)
@@ -102,8 +108,14 @@ def test_squeeze_excite_fwd_bwd(dtype, cfg):
     torch.cuda.synchronize()
     assert_close(gd.cpu(), gate.detach().view(B, C), 1e-4, 'se gate')
     assert_close(nchw(ymm), y.detach(), TOL[dtype], 'se scale')
+    # the same two ops fed with the pre-activation (z-only storage): Swish is recomputed inside
+    assert_close(nchw(ops.channel_scale(zm, gd, ops.ACT_SWISH)), y.detach(), TOL[dtype], 'se scale (from z)')
     dym = nhwc(dy, dtype)
     dg = ops.se_dgate(dym, xm)
+    dg_z = ops.se_dgate(dym, zm, ops.ACT_SWISH)
+    # bf16: Swish(z) here is unrounded while xm holds its bf16 rounding -> a 2^-9 perturbation of every term of a sum with
+    # cancellation: compare at tensor scale
+    assert_close_scale(dg_z.cpu(), dg.cpu(), 1e-4 if dtype == torch.float32 else 1e-2, 'se dgate (from z)')
     dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dg, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
     dzm = ops.se_bwd_apply(dym, gd, dpool, zm)
     torch.cuda.synchronize()
