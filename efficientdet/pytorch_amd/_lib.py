@@ -58,7 +58,8 @@ SYMBOLS = [
     'effdet_se_gate_fwd', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
     'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_bwd',
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
-    'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_clip_adamw_step', 'effdet_opt_chunk',
+    'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',
+    'effdet_clip_adamw_step', 'effdet_opt_chunk',
     'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_version',
 ]
 

@@ -223,6 +223,48 @@ __global__ __launch_bounds__(256) void loss_bwd_cls_pix_kernel(const LossK p) {
   store4(out, g);
 }
 
+// Forward AND gradient of the class term in ONE pass over cls (training): the focal sum goes to stat[b].cls_sum as in
+// loss_cls_kernel, and d(loss)/d(logit) for an upstream gradient of 1 is written in the pixel-major padded layout above.
+// The upstream scalar is applied downstream (it multiplies a LINEAR chain: the head's data-gradient conv takes it as its
+// per-image output scale, the retina_cls parameter gradients are scaled after unpacking), so backward never re-reads
+// the 15.7 MB/image of probabilities.  FG_IT 4-element groups per thread keep the same-line atomics per image few.
+constexpr int FG_IT = 4;
+template <typename T>
+__global__ __launch_bounds__(256) void loss_cls_grad_pix_kernel(const LossK p) {
+  const int b = blockIdx.y;
+  const int apix = (int)(p.A / 9), perp = apix * p.dld, cmax = 9 * p.nc;
+  const float* st = p.stat + b * SS;
+  const bool active = st[3] > 0.f;
+  const float gs = 1.0f / ((float)p.B * fmaxf(st[2], 1.0f));
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < FG_IT; ++it) {
+    const int e0 = ((blockIdx.x * FG_IT + it) * 256 + threadIdx.x) * 4;
+    if (e0 >= perp) break;
+    const int pix = e0 / p.dld, ch = e0 - pix * p.dld;
+    f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ch < cmax && active) {
+      const int an = ch / p.nc, k = ch - an * p.nc, a = pix * 9 + an;
+      const int code = p.assign[(long long)b * p.A + a];
+      if (code != -2) {
+        const int lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1;
+        const f32x4 v = *(const f32x4*)(p.cls + (long long)b * p.A * p.nc + (long long)pix * cmax + ch);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float d; s += focal_elem(v[q], lab == k + q, d);
+          g[q] = gs * d * v[q] * (1.f - v[q]);                 // through the sigmoid
+        }
+      }
+    }
+    store4((T*)p.dcls + (long long)b * perp + e0, g);
+  }
+  __shared__ float red[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(p.stat + b * SS + 0, t); }
+}
+
 template <typename T>
 __global__ void loss_bwd_reg_kernel(const LossK p) {
   const long long total = (long long)p.B * p.A;
@@ -325,4 +367,44 @@ extern "C" int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, con
                                          int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream) {
   if (dld <= 0) return EFFDET_EINVAL;
   return loss_bwd(cls, reg, anchors, annots, gscale, workspace, dcls_pix, dld, dreg, dtype, B, A, num_classes, N, stream);
+}
+
+extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, const float* anchors, const float* annots,
+                                          float* losses, void* workspace, long long workspace_bytes, void* dcls_pix, int dld,
+                                          int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream) {
+  if (!cls || !reg || !anchors || !annots || !losses || !workspace || !dcls_pix) return EFFDET_EINVAL;
+  if (workspace_bytes < effdet_loss_workspace_bytes(B, A) || B > 65535 || N < 1) return EFFDET_EINVAL;
+  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  if (dld <= 0 || A % 9 || num_classes % 4 || dld % 4 || dld < 9 * num_classes) return EFFDET_EINVAL;
+  if (A * num_classes >= 0x7fffffffLL || (A / 9) * dld >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
+  LossK k{}; k.cls = cls; k.reg = reg; k.anchors = anchors; k.annots = annots; k.losses = losses;
+  k.dcls = dcls_pix; k.dld = dld; k.B = B; k.nc = num_classes; k.N = N; k.A = A;
+  carve_loss(k, workspace, B, A);
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(k.stat, 0, (size_t)B * SS * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+  hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)((A + 255) / 256), B), dim3(256), 0, st, k);
+  EFFDET_CHECK_LAUNCH();
+  const long long groups = (A / 9) * dld / 4;
+  dim3 g1((unsigned)((groups + 256 * FG_IT - 1) / (256 * FG_IT)), B);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(loss_cls_grad_pix_kernel<float>, g1, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(loss_cls_grad_pix_kernel<bf16_t>, g1, dim3(256), 0, st, k);
+  EFFDET_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_focal_loss_bwd_reg(const float* reg, const float* anchors, const float* annots, const float* gscale,
+                                         const void* workspace, void* dreg, int dtype, int B, long long A, int N,
+                                         effdet_stream_t stream) {
+  if (!reg || !anchors || !annots || !gscale || !workspace || !dreg) return EFFDET_EINVAL;
+  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  LossK k{}; k.reg = reg; k.anchors = anchors; k.annots = annots; k.gscale = gscale; k.dreg = dreg;
+  k.B = B; k.N = N; k.A = A;
+  carve_loss(k, const_cast<void*>(workspace), B, A);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(loss_bwd_reg_kernel<float>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
+  else hipLaunchKernelGGL(loss_bwd_reg_kernel<bf16_t>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
 }

@@ -9,6 +9,7 @@ never called; ``functional.py`` drives libeffdet_hip.so with their tensors.  The
 the model refuses to run without the HIP library and a GPU.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -211,6 +212,9 @@ _HEAD_KEYS = [f'{t}_convs.{i}.{k}' for t in ('cls', 'reg') for i in range(4) for
              ['retina_cls.weight', 'retina_cls.bias', 'retina_reg.weight', 'retina_reg.bias']
 
 
+LOSS_FWD_GRAD = os.environ.get('EFFDET_LOSS_FWD_GRAD', '1') == '1'    # A/B switch: class-loss gradient written in forward
+
+
 class _HeadLossFn(torch.autograd.Function):
     """RetinaHead + focal / smooth-L1 loss as ONE node: the loss kernel hands the head's data-gradient convs
     d(logit) and d(reg) directly in the activation dtype (no fp32 gradient tensor round trip)."""
@@ -221,23 +225,35 @@ class _HeadLossFn(torch.autograd.Function):
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
-        losses, ws = ops.focal_loss_fwd(cls, reg, anchors, annots)
-        ctx.saved = (saved, cls, reg, anchors, annots, ws, dtype) if train else None
+        nc = num_classes
+        if train and nc % 4 == 0 and LOSS_FWD_GRAD:
+            # ONE pass over the 15.7 MB/image of probabilities: losses + d(logits) for an upstream gradient of one, already in
+            # the pixel-major, 64-channel-padded rows the head's gradient convs read; cls itself is not kept for backward
+            dld = (9 * nc + 63) // 64 * 64
+            losses, ws, dpix = ops.focal_loss_fwd_grad(cls, reg, anchors, annots, dtype, dld)
+            ctx.saved = (saved, None, reg, anchors, annots, ws, dtype, dpix, dld)
+        else:
+            losses, ws = ops.focal_loss_fwd(cls, reg, anchors, annots)
+            ctx.saved = (saved, cls, reg, anchors, annots, ws, dtype, None, 0) if train else None
         return losses[0:1].clone(), losses[1:2].clone()
 
     @staticmethod
     def backward(ctx, gcls, greg):
         ops.set_prep(ctx.prep)
-        saved, cls, reg, anchors, annots, ws, dtype = ctx.saved
+        saved, cls, reg, anchors, annots, ws, dtype, dpix, dld = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
-        nc = cls.shape[2]
-        if nc % 4 == 0:      # d(logits) straight into the pixel-major, 64-channel-padded rows the head's gradient convs read
-            dld = (9 * nc + 63) // 64 * 64
-            dcls, dreg = ops.focal_loss_bwd_pix(cls, reg, anchors, annots, gscale, ws, dtype, dld)
+        if dpix is not None:
+            dreg = ops.focal_loss_bwd_reg(reg, anchors, annots, gscale, ws, dtype)
+            dp, g = Fn.head_bwd(saved, dpix, dreg, dtype, dcls_ld=dld, cls_gscale=gscale[0:1])
         else:
-            dld = 0
-            dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
-        dp, g = Fn.head_bwd(saved, dcls, dreg, dtype, dcls_ld=dld)
+            nc = cls.shape[2]
+            if nc % 4 == 0:      # d(logits) straight into the pixel-major, 64-channel-padded rows the head's gradient convs read
+                dld = (9 * nc + 63) // 64 * 64
+                dcls, dreg = ops.focal_loss_bwd_pix(cls, reg, anchors, annots, gscale, ws, dtype, dld)
+            else:
+                dld = 0
+                dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
+            dp, g = Fn.head_bwd(saved, dcls, dreg, dtype, dcls_ld=dld)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(Fn.level_tensor(m) for m in dp) + tuple(g[k] for k in _HEAD_KEYS)
 

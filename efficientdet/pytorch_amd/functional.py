@@ -316,9 +316,12 @@ def head_fwd(p, HP, num_classes, dtype, train):
     return cls, reg, saved
 
 
-def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0):
+def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
     """dcls_logit [B,A,nc] (or, with dcls_ld, pixel-major and channel-padded [B,A/9,dcls_ld]: ops.focal_loss_bwd_pix),
-    dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.  -> (dp: 5 Maps, grads dict keyed like HP)."""
+    dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.  -> (dp: 5 Maps, grads dict keyed like HP).
+    cls_gscale (fp32 tensor [1]): dcls_logit was computed for an upstream gradient of one (ops.focal_loss_fwd_grad); the
+    real scalar enters here where the chain is linear: as the per-image output scale of retina_cls's data-gradient conv
+    and as a factor on retina_cls's own parameter gradients."""
     p, acts, sizes, HP, nc = saved
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
@@ -343,11 +346,15 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0):
         db = ar.take(Cf)
         G = ops.conv2d_wgrad(acts[tower][3], dzmaps, None, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
         dw = torch.empty_like(wf); ops.unpack_wgrad(G, dw)
+        rows = None
+        if tower == 'cls' and cls_gscale is not None:
+            dw = dw * cls_gscale; db = db * cls_gscale
+            rows = cls_gscale.expand(B).contiguous()
         g[fin + '.weight'], g[fin + '.bias'] = dw, db
         # data gradient with the ReLU mask of the producing tower layer fused into the epilogue
         _, dz = pyramid_alloc(B, sizes, 256, dtype, dev)
         ops.conv2d(dzmaps, ops.pack_weight(wf, dtype, mode=1, cin_pad=Cfp), dz, Cin=Cfp, Cout=256, KH=3, KW=3, pad_t=1,
-                   pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK)
+                   pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK, rowscale=rows)
         for t in range(3, -1, -1):
             w = HP[f'{tower}_convs.{t}.weight']
             xin = acts[tower][t - 1] if t > 0 else p

@@ -613,6 +613,29 @@ def focal_loss_bwd_pix(cls, reg, anc, annots, gscale, ws, dtype, dld):
     return dcls, dreg
 
 
+def focal_loss_fwd_grad(cls, reg, anc, annots, dtype, dld):
+    """Training fast path: -> (losses [2], ws, dcls_pix [B, A/9, dld]) in one pass over cls; dcls_pix is the gradient wrt the
+    logits for an upstream gradient of ONE (the caller scales downstream, see effdet_hip.h)."""
+    B, A, nc = cls.shape
+    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A)))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=cls.device)
+    losses = torch.empty(2, dtype=torch.float32, device=cls.device)
+    dcls = torch.empty((B, A // 9, dld), dtype=dtype, device=cls.device)
+    L.check(L.lib().effdet_focal_loss_fwd_grad(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(losses), L.ptr(ws),
+                                               C.c_longlong(nbytes), L.ptr(dcls), dld, L.dtype_code(dtype), B, C.c_longlong(A), nc,
+                                               annots.shape[1], L.stream_ptr()), 'effdet_focal_loss_fwd_grad')
+    return losses, ws, dcls
+
+
+def focal_loss_bwd_reg(reg, anc, annots, gscale, ws, dtype):
+    B, A, _ = reg.shape
+    dreg = torch.empty((B, A, 4), dtype=dtype, device=reg.device)
+    L.check(L.lib().effdet_focal_loss_bwd_reg(L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(gscale), L.ptr(ws), L.ptr(dreg),
+                                              L.dtype_code(dtype), B, C.c_longlong(A), annots.shape[1], L.stream_ptr()),
+            'effdet_focal_loss_bwd_reg')
+    return dreg
+
+
 def pad_rows(src_map, cpad):
     """Level map with unaligned channel count -> fresh contiguous [B,H,W,cpad] map, zero padded."""
     m = src_map

@@ -282,6 +282,16 @@ int effdet_focal_loss_bwd(const float* cls, const float* reg, const float* ancho
 int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, const float* anchors, const float* annots,
                               const float* gscale, const void* workspace, void* dcls_pix, int dld, void* dreg, int dtype,
                               int B, long long A, int num_classes, int N, effdet_stream_t stream);
+/* Training fast path: forward losses AND d(loss)/d(cls logits) in ONE pass over cls.  dcls_pix (layout as above) holds
+ * the gradient for an upstream gradient of 1 (gscale[0] = 1); the caller applies the real upstream scalar downstream,
+ * where the chain is linear (effdet_conv2d rowscale on the data gradient, a scalar on the retina_cls parameter
+ * gradients).  effdet_focal_loss_bwd_reg then produces d(reg) (scaled by gscale[1]) without touching cls. */
+int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, const float* anchors, const float* annots,
+                               float* losses, void* workspace, long long workspace_bytes, void* dcls_pix, int dld,
+                               int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream);
+int effdet_focal_loss_bwd_reg(const float* reg, const float* anchors, const float* annots, const float* gscale,
+                              const void* workspace, void* dreg, int dtype, int B, long long A, int N,
+                              effdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Train-step tail: torch.nn.utils.clip_grad_norm_(params, max_norm) followed by

@@ -113,6 +113,13 @@ def test_focal_loss_fwd_bwd(dtype, nc):
         assert dpix.shape == (B, A // 9, dld)
         assert torch.equal(dpix[:, :, :9 * nc].reshape(B, A, nc), dcls) and torch.equal(dreg2, dreg)
         assert float(dpix[:, :, 9 * nc:].float().abs().max()) == 0.0
+        # training fast path: losses + the gradient for an upstream gradient of ONE in a single pass over cls, d(reg) separately
+        losses2, ws2, dpix1 = ops.focal_loss_fwd_grad(cls.detach().cuda(), reg.detach().cuda(), anc.cuda(), ann.cuda(), dtype, dld)
+        assert_close(losses2.cpu(), torch.cat([cl.detach(), rl.detach()]), 2e-4, 'losses (fwd_grad)')
+        assert_close(dpix1.float().cpu() * float(gs[0]), dpix.float().cpu(), 1e-5 if dtype == torch.float32 else 1e-2, 'dcls (fwd_grad)')
+        assert float(dpix1[:, :, 9 * nc:].float().abs().max()) == 0.0
+        dreg3 = ops.focal_loss_bwd_reg(reg.detach().cuda(), anc.cuda(), ann.cuda(), gs.cuda(), ws2, dtype)
+        assert torch.equal(dreg3, dreg)
 
 
 @pytest.mark.parametrize('max_norm', [0.1, 0.0])
