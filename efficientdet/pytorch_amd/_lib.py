@@ -60,6 +60,7 @@ SYMBOLS = [
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
     'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',
     'effdet_clip_adamw_step', 'effdet_opt_chunk',
+    'effdet_drop_connect_scales', 'effdet_philox4x32_10', 'effdet_preprocess_batch', 'effdet_finalize_dets', 'effdet_head_out_bwd',
     'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_version',
 ]
 

@@ -15,6 +15,20 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     if (e_ != hipSuccess) return EFFDET_ELAUNCH;              \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property: apply it once per (call site, device), not once
+// per process, so that a single process driving several GPUs gets it on each of them (bit mask over device ordinals).
+#define EFFDET_SET_MAX_LDS(kernel, bytes)                                                                           \
+  do {                                                                                                              \
+    static unsigned long long done_ = 0ull;                                                                         \
+    int dev_ = 0;                                                                                                   \
+    (void)hipGetDevice(&dev_);                                                                                      \
+    const unsigned long long bit_ = 1ull << (dev_ & 63);                                                            \
+    if (!(done_ & bit_)) {                                                                                          \
+      (void)hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));  \
+      done_ |= bit_;                                                                                                \
+    }                                                                                                               \
+  } while (0)
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 // fp32 -> bf16, round-to-nearest-even, through the native v_cvt_pk_bf16_f32 (one instruction per PAIR; the software
 // rounding sequence was ~6 VALU per value and made the conv epilogues VALU-bound)

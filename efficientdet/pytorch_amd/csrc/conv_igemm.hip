@@ -284,11 +284,7 @@ template <typename T, int BN, int WAVES_N, int NWAVES>
 int launch(const ConvK& k, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);                     // double-buffered operand tiles
   const int grid = k.mtiles * k.ntiles;
-  static bool attr_set = false;  // idempotent; benign race
-  if (!attr_set && lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv_igemm_kernel<T, BN, WAVES_N, NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES>), lds);
   hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;

@@ -622,20 +622,17 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   kf.nseg = nf; ks.nseg = ns;
   ks.slab = k.slab + (long long)sf * n;
   if (nf > 0) {
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_tr_kernel<TR_NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+    EFFDET_SET_MAX_LDS((conv_wgrad_tr_kernel<TR_NW>), lds);
     hipLaunchKernelGGL(conv_wgrad_tr_kernel<TR_NW>, dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(TR_NW * 64), lds, st, kf);
     EFFDET_CHECK_LAUNCH();
   }
   if (ns > 0) {
     dim3 grid((unsigned)(k.ntiles * k.jtiles * ss));
     if (p->dtype == EFFDET_F32) {
-      static bool once = false;
-      if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+      EFFDET_SET_MAX_LDS((conv_wgrad_kernel<float>), lds);
       hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(256), lds, st, ks);
     } else {
-      static bool once = false;
-      if (!once) { (void)hipFuncSetAttribute((const void*)conv_wgrad_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+      EFFDET_SET_MAX_LDS((conv_wgrad_kernel<bf16_t>), lds);
       hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, ks);
     }
     EFFDET_CHECK_LAUNCH();

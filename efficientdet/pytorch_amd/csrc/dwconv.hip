@@ -636,8 +636,7 @@ int launch_fwd_lds(const DwK& a0, hipStream_t st) {
   a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024 && nb_env != 1) ? 2 : 1;                  // keep >= 2 workgroups per CU
   const size_t lds = a.nbuf * tile + wb;
   dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), nslab);
-  static bool once = false;   // per instantiation; idempotent, benign race
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_fwd_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile + wb)); once = true; }
+  EFFDET_SET_MAX_LDS((dw_fwd_lds_kernel<T, K, S, CQ>), (2 * tile + wb));
   hipLaunchKernelGGL((dw_fwd_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
@@ -653,8 +652,7 @@ int launch_dgrad_lds(const DwK& a0, hipStream_t st) {
   a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024 && nb_env != 1) ? 2 : 1;
   const size_t lds = a.nbuf * tile + wb;
   dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), nslab);
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_dgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * tile + wb)); once = true; }
+  EFFDET_SET_MAX_LDS((dw_dgrad_lds_kernel<T, K, S, CQ>), (2 * tile + wb));
   hipLaunchKernelGGL((dw_dgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }
@@ -667,8 +665,7 @@ int launch_wgrad_lds(const DwK& a0, hipStream_t st) {
   const int tpi = ((a0.Ho + TL::TH - 1) / TL::TH) * ((a0.Wo + TL::TW - 1) / TL::TW);
   DwK a = a0;
   dim3 grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), (a.nch + CQ - 1) / CQ);
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)dw_wgrad_lds_kernel<T, K, S, CQ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  EFFDET_SET_MAX_LDS((dw_wgrad_lds_kernel<T, K, S, CQ>), lds);
   hipLaunchKernelGGL((dw_wgrad_lds_kernel<T, K, S, CQ>), grid, dim3(256), lds, st, a);
   return EFFDET_OK;
 }

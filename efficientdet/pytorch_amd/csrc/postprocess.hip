@@ -450,8 +450,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
   EFFDET_CHECK_LAUNCH();
   const size_t lds = (size_t)16 * NT * 8 + (size_t)(NT + 8) * 16 + (size_t)(NT + 8) * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
-  static bool once = false;
-  if (!once) { (void)hipFuncSetAttribute((const void*)nms_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; }
+  EFFDET_SET_MAX_LDS((nms_round_kernel), lds);
   const int rounds = (int)((A + ROUND - 1) / ROUND);
   for (int r = 0; r < rounds; ++r) {
     if (r > 0) {

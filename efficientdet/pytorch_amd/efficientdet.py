@@ -48,6 +48,7 @@ class _Backbone(_Holder):
     def __init__(self, name):
         super().__init__()
         stem_c, stem_pad, blocks, head_c, native = backbone_plan(name)
+        self.model_name = name                                  # 'efficientnet-bN' (checkpoint.load_pretrained_backbone)
         self.plan = blocks
         self.stem_pad = stem_pad
         self._conv_stem = nn.Conv2d(3, stem_c, 3, stride=2, bias=False)
@@ -122,6 +123,25 @@ class FocalLoss(nn.Module):
         return losses[0:1], losses[1:2]
 
 
+class PackedImages:
+    """A batch already in the stem conv's input layout (NHWC, compute dtype, channels zero-padded to one 16-byte chunk),
+    as produced on the device by data.DeviceCollater -- accepted wherever the model takes an NCHW fp32 image batch, and
+    skips the NCHW -> NHWC repack.  Quacks like the [B,3,H,W] tensor it stands for (shape / device / is_cuda / float())."""
+
+    def __init__(self, nhwc_map):
+        self.map = nhwc_map
+        self.shape = torch.Size((nhwc_map.B, 3, nhwc_map.H, nhwc_map.W))
+        self.device = nhwc_map.t.device
+        self.is_cuda = nhwc_map.t.is_cuda
+        self.dtype = nhwc_map.t.dtype
+
+    def float(self):
+        return self
+
+    def contiguous(self):
+        return self
+
+
 # --------------------------------------------------------------------------- autograd nodes
 def _t(m):
     return m.tensor()
@@ -131,6 +151,9 @@ class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train):
         ctx.prep = ops.get_prep()
+        if isinstance(img, PackedImages) and (img.map.dtype != dtype or img.map.C != Fn.chunk_elems(dtype)):
+            raise RuntimeError('PackedImages were packed for %s / %d channels, the model computes in %s'
+                               % (img.map.dtype, img.map.C, dtype))
         y, saved = Fn.stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train)
         ctx.saved = saved if train else None
         return _t(y)
@@ -212,6 +235,30 @@ _HEAD_KEYS = [f'{t}_convs.{i}.{k}' for t in ('cls', 'reg') for i in range(4) for
              ['retina_cls.weight', 'retina_cls.bias', 'retina_reg.weight', 'retina_reg.bias']
 
 
+class _HeadFn(torch.autograd.Function):
+    """RetinaHead alone as a differentiable node: (classification [B,A,nc] probabilities, regression [B,A,4]) of
+    models/efficientdet.py:64-66 for callers that bring their own criterion (the training forward uses the fused
+    head+loss node below, which never materialises d(probabilities))."""
+
+    @staticmethod
+    def forward(ctx, dtype, num_classes, train, *args):
+        ctx.prep = ops.get_prep()
+        p = [Map.of(t) for t in args[:5]]
+        HP = dict(zip(_HEAD_KEYS, args[5:]))
+        cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
+        ctx.saved = (saved, cls, dtype) if train else None
+        return cls, reg
+
+    @staticmethod
+    def backward(ctx, dcls, dreg):
+        ops.set_prep(ctx.prep)
+        saved, cls, dtype = ctx.saved
+        dlogit, dr = ops.head_out_bwd(dcls.contiguous().float(), cls, dreg.contiguous().float(), dtype)
+        dp, g = Fn.head_bwd(saved, dlogit, dr, dtype)
+        ctx.saved = None
+        return (None, None, None) + tuple(Fn.level_tensor(m) for m in dp) + tuple(g[k] for k in _HEAD_KEYS)
+
+
 LOSS_FWD_GRAD = os.environ.get('EFFDET_LOSS_FWD_GRAD', '1') == '1'    # A/B switch: class-loss gradient written in forward
 
 
@@ -273,6 +320,7 @@ class EfficientDet(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
         self._prep = {}                                         # (compute dtype, device) -> ops.ParamPrep (batched per-step repacks)
+        self._dc = {}                                           # drop_connect generator state (seed, step counter, per-device keep table)
         self.batched_prep = True                                # False: every repack is its own launch (debug / A-B)
         for m in self.modules():                                # models/efficientdet.py:47-53
             if isinstance(m, nn.Conv2d):
@@ -310,6 +358,43 @@ class EfficientDet(nn.Module):
         self._prep = {}                                         # parameter storage may move: drop the recorded job tables
         return super()._apply(fn, *a, **k)
 
+    def __getstate__(self):
+        """copy.deepcopy / pickle / torch.save(model): the recorded job tables hold raw device addresses of THIS module's
+        parameters and arenas -- a copy must record its own (a replay against the original's addresses would write into
+        foreign or freed memory)."""
+        st = self.__dict__.copy()
+        st['_prep'] = {}
+        st['_dc'] = {k: v for k, v in self._dc.items() if k in ('seed', 'step')}
+        return st
+
+    def _drop_connect_rowscales(self, B, device):
+        """{block index: rowscale [B] fp32} for this training step: floor(keep + u)/keep per identity-skip block
+        (models/efficientnet.py:199-203 rate schedule, models/utils.py:79-90), all blocks from ONE HIP launch
+        (Philox4x32-10 keyed by (seed, step)).  backbone.drop_masks = {block: 0/1 tensor [B]} overrides the generator
+        (parity tests inject the reference's own Bernoulli draws)."""
+        bb = self.backbone
+        nblk = len(bb.plan)
+        idx = [i for i, blk in enumerate(bb.plan) if blk.skip and bb.drop_connect_rate * float(i) / nblk]
+        if not idx:
+            return {}
+        keep = [1.0 - bb.drop_connect_rate * float(i) / nblk for i in idx]
+        inject = getattr(bb, 'drop_masks', None)
+        if inject is not None:
+            return {i: (inject[i].to(device=device, dtype=torch.float32) / kp).contiguous() for i, kp in zip(idx, keep) if i in inject}
+        dc = self._dc
+        if 'seed' not in dc:
+            # one draw from torch's default generator: torch.manual_seed() controls the stream; ranks decorrelate by rank
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+            if torch.distributed.is_available() and torch.distributed.is_initialized():
+                seed ^= (torch.distributed.get_rank() + 1) * 0x9E3779B97F4A7C15
+            dc['seed'], dc['step'] = seed & (2 ** 64 - 1), 0
+        tk = ('keep', str(device), bb.drop_connect_rate)
+        if tk not in dc:
+            dc[tk] = torch.tensor(keep, dtype=torch.float32, device=device)
+        rows = ops.drop_connect_scales(dc[tk], B, dc['seed'], dc['step'])
+        dc['step'] += 1
+        return {i: rows[j] for j, i in enumerate(idx)}
+
     def _backbone(self, img):
         bb, dt = self.backbone, self.compute_dtype
         # every forward path starts here: replay (or start recording) this model's batched parameter preparation
@@ -325,7 +410,7 @@ class EfficientDet(nn.Module):
         train = torch.is_grad_enabled()
         x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train)
         feats = []
-        nblk = len(bb.plan)
+        rowscales = self._drop_connect_rowscales(int(img.shape[0]), img.device) if (self.training and bb.drop_connect_rate) else {}
         for i, (blk, m) in enumerate(zip(bb.plan, bb._blocks)):
             buffers = {'bn1.running_mean': m._bn1.running_mean, 'bn1.running_var': m._bn1.running_var,
                        'bn2.running_mean': m._bn2.running_mean, 'bn2.running_var': m._bn2.running_var}
@@ -335,11 +420,7 @@ class EfficientDet(nn.Module):
                 params += [m._expand_conv.weight, m._bn0.weight, m._bn0.bias]
             params += [m._depthwise_conv.weight, m._bn1.weight, m._bn1.bias, m._se_reduce.weight, m._se_reduce.bias,
                        m._se_expand.weight, m._se_expand.bias, m._project_conv.weight, m._bn2.weight, m._bn2.bias]
-            rowscale = None
-            rate = bb.drop_connect_rate * float(i) / nblk if bb.drop_connect_rate else 0.0
-            if blk.skip and rate and self.training:              # models/efficientnet.py:199-203, models/utils.py:79-90
-                keep = 1.0 - rate
-                rowscale = torch.floor(keep + torch.rand(img.shape[0], device=img.device)) / keep
+            rowscale = rowscales.get(i)                         # models/efficientnet.py:199-203, models/utils.py:79-90
             x = _MBConvFn.apply(x, blk, dt, rowscale, buffers, train, *params)
             if blk.stage_end:
                 feats.append(x)
@@ -368,18 +449,19 @@ class EfficientDet(nn.Module):
             return tuple(ops.nhwc_to_nchw(Map.of(t)) for t in p)
 
     def forward_raw(self, img):
-        """(classification [B,A,nc] probabilities, regression [B,A,4], anchors [1,A,4]) of models/efficientdet.py:64-66."""
+        """(classification [B,A,nc] probabilities, regression [B,A,4], anchors [1,A,4]) of models/efficientdet.py:64-66.
+        Differentiable when gradients are enabled (backbone, neck and head nodes all record), so a caller may apply its
+        own criterion to the triple the way the reference's forward does (:67)."""
         self._check(img)
-        with torch.no_grad():
-            p = self._neck(self._backbone(img.float())[-5:])
-            HP = dict(zip(_HEAD_KEYS, [t.detach() for t in self._head_params()]))
-            cls, reg, _ = Fn.head_fwd([Map.of(t) for t in p], HP, self.num_classes, self.compute_dtype, False)
+        p = self._neck(self._backbone(img.float())[-5:])
+        cls, reg = _HeadFn.apply(self.compute_dtype, self.num_classes, torch.is_grad_enabled(), *p, *self._head_params())
         return cls, reg, self.anchors(img)
 
     def detect(self, img):
         """Eval post-processing for EVERY image of the batch (the reference handles image 0 only).
         -> list of (scores[K], labels[K] int64, boxes[K,4]) per image, score-descending."""
-        cls, reg, anc = self.forward_raw(img)
+        with torch.no_grad():
+            cls, reg, anc = self.forward_raw(img)
         H, W = int(img.shape[2]), int(img.shape[3])
         boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
         idx, count = ops.nms(boxes, score, float(self.threshold), float(self.iou_threshold))

@@ -1,0 +1,44 @@
+"""Batched evaluation consumer: what the reference's eval.py does per image on the host
+(_get_detections :96-127, evaluate_coco :279-306: D2H of every detection, numpy threshold + argsort + top-100, box
+rescale) done for the whole batch on the device, ONE device->host copy of [B, max_det, 6] + counts.
+
+Output formats are the reference's: ``all_detections[image][label] -> ndarray [n, 5] (x1,y1,x2,y2,score)`` and the
+MS-COCO result dicts {'image_id', 'category_id', 'score', 'bbox': [x, y, w, h]}."""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def detections_batched(model, images, scales, score_threshold=0.05, max_detections=100, xywh=False):
+    """-> (dets [B, max_detections, 6] fp32 on the HOST: x1,y1,x2,y2 (or x,y,w,h), score, label; counts [B] ints).
+    images: NCHW fp32 batch or PackedImages; scales: [B] resize factors (tensor, array or list)."""
+    with torch.no_grad():
+        cls, reg, anc = model.forward_raw(images)
+        H, W = int(images.shape[2]), int(images.shape[3])
+        boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
+        idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
+        s, l, b = ops.gather_dets(boxes, score, label, idx, count)
+        sc = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else scales,
+                             dtype=torch.float32, device=s.device).contiguous()
+        out, oc = ops.finalize_dets(s, l, b, count, sc, score_threshold, max_detections, xywh)
+        return out.cpu().numpy(), oc.cpu().numpy()         # the one device->host transfer of the batch
+
+
+def all_detections_rows(dets, counts, num_classes):
+    """eval.py:118-123: per image, per label -> [n,5] arrays (boxes + score)."""
+    rows = []
+    for d, n in zip(dets, counts):
+        d = d[:int(n)]
+        rows.append([d[d[:, 5] == c, :5] if n else np.zeros((0, 5)) for c in range(num_classes)])
+    return rows
+
+
+def coco_results(dets_xywh, counts, image_ids, label_to_coco_label=lambda c: c):
+    """eval.py:296-306: one dict per detection (dets must come from detections_batched(..., xywh=True))."""
+    res = []
+    for d, n, iid in zip(dets_xywh, counts, image_ids):
+        for k in range(int(n)):
+            res.append({'image_id': iid, 'category_id': label_to_coco_label(int(d[k, 5])), 'score': float(d[k, 4]),
+                        'bbox': [float(v) for v in d[k, :4]]})
+    return res

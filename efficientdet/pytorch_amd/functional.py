@@ -54,7 +54,10 @@ def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train):
     """models/efficientnet.py:193  swish(bn0(conv_stem(img)))  (3x3 s2, static same pad)."""
     ce = chunk_elems(dtype)
     B, _, H, W = img.shape
-    x = ops.nchw_to_nhwc(img.contiguous().float(), dtype, cpad=ce)
+    if hasattr(img, 'map'):       # efficientdet.PackedImages: already NHWC / compute dtype / one chunk of channels
+        x = img.map
+    else:
+        x = ops.nchw_to_nhwc(img.contiguous().float(), dtype, cpad=ce)
     s, t, inv = ops.bn_fold(gamma, beta, mean, var, BN_EPS)
     wp = ops.pack_weight(w, dtype, cin_pad=ce)
     Cout = w.shape[0]

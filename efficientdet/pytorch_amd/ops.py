@@ -643,3 +643,55 @@ def pad_rows(src_map, cpad):
     L.check(L.lib().effdet_pad_rows(L.ptr(m.t), L.ptr(dst.t), L.dtype_code(m.dtype), C.c_longlong(m.off), C.c_longlong(m.bstride),
                                     m.ld, m.B, m.H * m.W, m.C, cpad, L.stream_ptr()), 'effdet_pad_rows')
     return dst
+
+
+# ----------------------------------------------------------------------------- boundary kernels (csrc/pipeline.hip)
+def drop_connect_scales(keep_dev, B, seed, step):
+    """-> [nslot, B] fp32 rows of floor(keep + u)/keep (models/utils.py:79-90), one launch for every skip block of a step."""
+    n = keep_dev.numel()
+    out = torch.empty((n, B), dtype=torch.float32, device=keep_dev.device)
+    L.check(L.lib().effdet_drop_connect_scales(L.ptr(out), L.ptr(keep_dev), n, B, C.c_ulonglong(seed & (2 ** 64 - 1)),
+                                               C.c_ulonglong(step), L.stream_ptr()), 'effdet_drop_connect_scales')
+    return out
+
+
+def philox_host(ctr, key):
+    """Host twin of the device generator (Philox4x32-10): -> 4 uint32 words."""
+    c = (C.c_uint * 4)(*ctr); k = (C.c_uint * 2)(*key); o = (C.c_uint * 4)()
+    f = L.lib().effdet_philox4x32_10
+    f.restype = None
+    f(c, k, o)
+    return [int(x) for x in o]
+
+
+def preprocess_batch(src_u8, src_off, src_hw, S, dtype, cpad, mean, std, flip=None, annots=None):
+    """uint8 HWC images (concatenated, device) -> (Map [B,S,S,cpad] normalised / resized / padded, scale [B] fp32).
+    annots [B,M,5] fp32 (device) is transformed in place (datasets/augmentation.py:69-150)."""
+    B = src_hw.shape[0]
+    out = Map.new(B, S, S, cpad, dtype, src_u8.device)
+    scale = torch.empty(B, dtype=torch.float32, device=src_u8.device)
+    m = (C.c_float * 3)(*mean); s = (C.c_float * 3)(*std)
+    L.check(L.lib().effdet_preprocess_batch(L.ptr(src_u8), L.ptr(src_off), L.ptr(src_hw), L.ptr(flip), L.ptr(out.t), L.ptr(scale),
+                                            L.ptr(annots), annots.shape[1] if annots is not None else 0, L.dtype_code(dtype), B, S,
+                                            cpad, m, s, L.stream_ptr()), 'effdet_preprocess_batch')
+    return out, scale
+
+
+def finalize_dets(score, label, boxes, count, scale, score_threshold, max_det, xywh=False):
+    """Batched eval consumer: -> (out [B,max_det,6] = x1,y1,x2,y2,score,label with boxes / scale, out_count [B] int32)."""
+    B, A = score.shape
+    out = torch.empty((B, max_det, 6), dtype=torch.float32, device=score.device)
+    oc = torch.empty(B, dtype=torch.int32, device=score.device)
+    L.check(L.lib().effdet_finalize_dets(L.ptr(score), L.ptr(label), L.ptr(boxes), L.ptr(count), L.ptr(scale),
+                                         C.c_float(score_threshold), max_det, int(xywh), L.ptr(out), L.ptr(oc), B, C.c_longlong(A),
+                                         L.stream_ptr()), 'effdet_finalize_dets')
+    return out, oc
+
+
+def head_out_bwd(dprob, prob, dreg, dtype):
+    """(d loss / d probability, probability, d loss / d regression) fp32 -> (dlogit, dreg) in the compute dtype."""
+    dl = torch.empty(prob.shape, dtype=dtype, device=prob.device)
+    dr = torch.empty(dreg.shape, dtype=dtype, device=prob.device)
+    L.check(L.lib().effdet_head_out_bwd(L.ptr(dprob), L.ptr(prob), L.ptr(dreg), L.ptr(dl), L.ptr(dr), L.dtype_code(dtype),
+                                        C.c_longlong(prob.numel()), C.c_longlong(dreg.numel()), L.stream_ptr()), 'effdet_head_out_bwd')
+    return dl, dr

@@ -56,15 +56,48 @@ class ClipAdamW(torch.optim.Optimizer):
             'v_ptr': i64([self.exp_avg_sq.data_ptr() + 4 * int(o) for o in offs[:-1]]),
             'numel': i64(numel), 'block_tensor': i32(block_tensor), 'block_first': i32(block_first),
             'g_ptr': torch.zeros(n, dtype=torch.int64, device=dev),
-            'g_host': torch.zeros(n, dtype=torch.int64).pin_memory(), 'g_last': None,
+            # pinned staging ring for the gradient-pointer upload: a slot is rewritten only after the event recorded behind
+            # its previous H2D copy has completed (the host may run a step ahead of the stream)
+            'g_host': [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)], 'g_evt': [None, None], 'g_slot': 0,
+            'g_last': None,
             'scratch': torch.zeros(64 + nb, dtype=torch.float32, device=dev), 'offs': offs,
             'steps': torch.zeros(n, dtype=torch.int32, device=dev), 'p_sig': [p.data_ptr() for p in ps],
         }
         for i, p in enumerate(ps):                                     # per-parameter views for state_dict()
-            self.state[p] = {'step': torch.tensor(float(self._step)),
+            self.state[p] = {'step': torch.tensor(0.0),                # refreshed from the device counters in state_dict()
                              'exp_avg': self.exp_avg[int(offs[i]):int(offs[i]) + numel[i]].view_as(p),
                              'exp_avg_sq': self.exp_avg_sq[int(offs[i]):int(offs[i]) + numel[i]].view_as(p)}
         self._table = t
+
+    # ---- checkpointing (train.py:279-291 saves only the model; resuming needs the moments + per-tensor step counters) ----
+    def state_dict(self):
+        """torch.optim.AdamW-compatible: per-parameter {'step', 'exp_avg', 'exp_avg_sq'}; 'step' is read back from the
+        device-resident counters (they advance on the GPU), the moments are views of the two arenas."""
+        if self._table is not None:
+            steps = self._table['steps'].cpu()
+            for i, p in enumerate(self._table['params']):
+                self.state[p]['step'] = torch.tensor(float(steps[i]))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        """Loads a state_dict of this class or of torch.optim.AdamW over the same parameter list: moments are copied INTO
+        the arenas and the step counters into the device array (super() alone would leave self.state pointing at fresh
+        tensors the kernels never see)."""
+        super().load_state_dict(state_dict)
+        loaded = {p: dict(st) for p, st in self.state.items()}
+        self.state.clear()
+        self._build()
+        t = self._table
+        steps = torch.zeros(t['n'], dtype=torch.int32)
+        for i, p in enumerate(t['params']):
+            st = loaded.get(p)
+            if not st:
+                continue
+            self.state[p]['exp_avg'].copy_(st['exp_avg'].to(p.device, torch.float32).view_as(p))
+            self.state[p]['exp_avg_sq'].copy_(st['exp_avg_sq'].to(p.device, torch.float32).view_as(p))
+            steps[i] = int(float(st['step']))
+        t['steps'].copy_(steps)
+        self._step = int(steps.max()) if t['n'] else 0
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -85,8 +118,13 @@ class ClipAdamW(torch.optim.Optimizer):
                 gr = gr.float().contiguous(); p.grad = gr
             ptrs.append(gr.data_ptr())
         if ptrs != t['g_last']:                                        # (DDP bucket views keep their addresses: no upload)
-            t['g_host'].copy_(torch.tensor(ptrs, dtype=torch.int64))
-            t['g_ptr'].copy_(t['g_host'], non_blocking=True)
+            slot = t['g_slot']; t['g_slot'] = slot ^ 1
+            if t['g_evt'][slot] is not None:
+                t['g_evt'][slot].synchronize()                         # the copy that last read this pinned slot has finished
+            t['g_host'][slot].copy_(torch.tensor(ptrs, dtype=torch.int64))
+            t['g_ptr'].copy_(t['g_host'][slot], non_blocking=True)
+            ev = torch.cuda.Event(); ev.record()
+            t['g_evt'][slot] = ev
             t['g_last'] = ptrs
         self._step += 1
         b1, b2 = g['betas']

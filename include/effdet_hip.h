@@ -324,6 +324,44 @@ int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, in
 /* Cpad >= C: channels C..Cpad-1 of the NHWC output are written as zeros */
 int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, int W, int C, int Cpad, effdet_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Boundary kernels either side of the conv path (csrc/pipeline.hip).
+ *
+ * drop_connect (models/utils.py:79-90; one draw per identity-skip MBConv block, models/efficientnet.py:98-101):
+ *   out[slot][b] = floor(keep_prob[slot] + u) / keep_prob[slot],  u = (x >> 8) * 2^-24 with x = word 0 of
+ *   Philox4x32-10(counter = {b, slot, step_lo, step_hi}, key = {seed_lo, seed_hi}).  One launch per step for all slots;
+ *   the result is the `rowscale` of the block's project conv (forward) and of its dz (backward).
+ *   effdet_philox4x32_10 is the HOST twin of the generator (pure function, no device work; tests pin the stream on it).
+ * ------------------------------------------------------------------------------------------- */
+int effdet_drop_connect_scales(float* out, const float* keep_prob, int nslot, int B, unsigned long long seed,
+                               unsigned long long step, effdet_stream_t stream);
+void effdet_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4]);
+
+/* Device-side input pipeline (datasets/augmentation.py:69-150: Normalizer -> Augmenter -> Resizer -> collater):
+ *   src      : uint8 RGB HWC images of mixed sizes, concatenated; image b starts at byte src_off[b], size src_hw[2b], [2b+1]
+ *   flip     : optional [B] bytes, non-zero = horizontal flip (Augmenter)
+ *   out_nhwc : [B][S][S][Cpad] in `dtype`: cv2.resize(INTER_LINEAR) so that the longer side is S, (v/255 - mean)/std,
+ *              zeros outside the resized region and in channels 3..Cpad-1  (what the stem conv reads: no NCHW round trip)
+ *   scale_out: optional [B] resize factors (eval.py:105 divides boxes by it)
+ *   annots   : optional [B][max_annots][5] fp32, transformed IN PLACE (flip, then * scale); rows with label -1 untouched
+ * mean / std are HOST arrays of 3 floats. */
+int effdet_preprocess_batch(const unsigned char* src, const long long* src_off, const int* src_hw, const unsigned char* flip,
+                            void* out_nhwc, float* scale_out, float* annots, int max_annots, int dtype, int B, int S,
+                            int Cpad, const float mean[3], const float std[3], effdet_stream_t stream);
+
+/* Batched evaluation consumer (eval.py:96-127 and :279-306) over effdet_gather_dets' score-descending rows:
+ *   out[b][k] = (x1, y1, x2, y2, score, label) / scale[b] on the boxes, for the first out_count[b] =
+ *   min(max_det, #{score > score_threshold}) detections of image b; xywh != 0 emits (x, y, w, h) (MS COCO);
+ *   rows beyond out_count[b] are zero with label -1.  out: [B][max_det][6] fp32. */
+int effdet_finalize_dets(const float* score, const long long* label, const float* boxes, const int* count, const float* scale,
+                         float score_threshold, int max_det, int xywh, float* out, int* out_count, int B, long long A,
+                         effdet_stream_t stream);
+
+/* Gradient of the head outputs (models/retinahead.py:119-127 under autograd):  dlogit = dprob * p * (1 - p) and dreg,
+ * both stored in `dtype` for the head's data-gradient convs.  ncls / nreg: element counts. */
+int effdet_head_out_bwd(const float* dprob, const float* prob, const float* dreg, void* dlogit, void* dreg_out, int dtype,
+                        long long ncls, long long nreg, effdet_stream_t stream);
+
 /* library identification: returns "effdet-hip gfx950 <version>" */
 const char* effdet_version(void);
 

@@ -94,7 +94,7 @@ def taps_from_reference(m, img):
     return taps, hooks
 
 
-def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=True, seed=0):
+def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=True, seed=0, dets=True):
     sd = O.make_state_dict(network, num_classes, seed=seed)
     m = build_ref(EfficientDet, network, num_classes, sd, is_training=False, threshold=threshold)
     m.eval()
@@ -107,8 +107,8 @@ def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=Tr
         anc = m.anchors(img)
     for h_ in hooks:
         h_.remove()
-    with torch.no_grad():
-        dets = [m(img[b:b + 1]) for b in range(B)]       # the reference only post-processes image 0 (Q8)
+    with torch.no_grad():                                # the reference only post-processes image 0 (Q8)
+        dets = [m(img[b:b + 1]) for b in range(B)] if dets else []
     d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed, threshold=threshold,
              anchors_sha256=sha(anc.numpy()), anchors_first=anc[0, :4].numpy(), anchors_last=anc[0, -4:].numpy(),
              cls_summary=summary(cls), reg_summary=summary(reg), cls_sample=sample(cls, 4096), reg_sample=sample(reg, 4096))
@@ -119,6 +119,10 @@ def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=Tr
         d['tap_' + k + '_summary'] = summary(v)
     for b, (s_, c_, bx) in enumerate(dets):
         d[f'det{b}_scores'] = s_.numpy(); d[f'det{b}_labels'] = c_.numpy(); d[f'det{b}_boxes'] = bx.numpy()
+    if not dets:                                         # (D4 @1024: 196k candidates x python greedy NMS -- forward only)
+        np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+        print(name, 'cls', tuple(cls.shape), 'forward only')
+        return
     # NMS candidates of image 0 exactly as the reference builds them (models/efficientdet.py:69-83)
     with torch.no_grad():
         boxes = m.clipBoxes(m.regressBoxes(anc, reg[:1]), img[:1])
@@ -131,16 +135,44 @@ def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=Tr
     print(name, 'cls', tuple(cls.shape), 'cands', int(mask.sum()), 'kept', [len(x[0]) for x in dets])
 
 
-def case_train(EfficientDet, name, network, num_classes, B, S, seed=0):
+def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_last=True, drop_connect=0.0):
     sd = O.make_state_dict(network, num_classes, seed=seed)
     m = build_ref(EfficientDet, network, num_classes, sd, is_training=True)
     m.train(); m.is_training = True; m.freeze_bn()
     img, ann = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
-    ann[-1, :, :] = -1.0            # last image has no annotations -> zero-loss branch (losses.py:54-58)
-    cl, rl = m([img, ann])
+    if empty_last:
+        ann[-1, :, :] = -1.0        # last image has no annotations -> zero-loss branch (losses.py:54-58)
+    draws = []
+    if drop_connect:
+        # drop_connect ACTIVE (models/utils.py:79-90): the reference draws torch.rand([B,1,1,1]) once per MBConv block with an
+        # identity skip (models/efficientnet.py:98-101), block order; record every draw so that the SAME Bernoulli masks
+        # can be injected into the oracle (drop_masks=) and into the HIP model (backbone.drop_masks)
+        m.backbone._global_params = m.backbone._global_params._replace(drop_connect_rate=drop_connect)
+        real_rand = torch.rand
+
+        def rec_rand(*a, **k):
+            r = real_rand(*a, **k)
+            draws.append(r.reshape(-1).clone())
+            return r
+        torch.manual_seed(1234)
+        torch.rand = rec_rand
+    try:
+        cl, rl = m([img, ann])
+    finally:
+        if drop_connect:
+            torch.rand = real_rand
     (cl.mean() + rl.mean()).backward()
     d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed,
              cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), annots=ann.numpy())
+    if drop_connect:
+        _, blocks, _, _ = O.backbone_blocks(network)
+        skip_idx = [i for i, b in enumerate(blocks) if b['skip']]
+        assert len(draws) == len(skip_idx), (len(draws), len(skip_idx))
+        nb = len(blocks)
+        keep = np.array([1.0 - drop_connect * float(i) / nb for i in skip_idx], dtype=np.float64)
+        masks = np.stack([torch.floor(torch.tensor(k, dtype=torch.float32) + r).numpy() for k, r in zip(keep, draws)])
+        d.update(drop_connect_rate=drop_connect, drop_blocks=np.array(skip_idx), drop_keep=keep, drop_masks=masks.astype(np.float32))
+        print(name, 'drop masks: kept fraction', float(masks.mean()), 'blocks', len(skip_idx))
     dead = []
     for k, p in m.named_parameters():
         if p.grad is None:
@@ -150,6 +182,10 @@ def case_train(EfficientDet, name, network, num_classes, B, S, seed=0):
     d['dead_params'] = np.array(dead)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
     print(name, 'losses', cl.item(), rl.item(), 'dead', dead)
+
+
+def case_train_dropconnect(EfficientDet, name, network, num_classes, B, S):
+    case_train(EfficientDet, name, network, num_classes, B, S, drop_connect=0.5)     # rate 0.5: plenty of dropped rows at B=4
 
 
 def case_anchors(EfficientDet):
@@ -164,13 +200,24 @@ def case_anchors(EfficientDet):
     print('anchors', {k: v for k, v in d.items() if k.startswith('n_')})
 
 
+CASES = {
+    'anchors': lambda E: case_anchors(E),
+    'd0_128_eval': lambda E: case_eval(E, 'd0_128_eval', 'efficientdet-d0', 20, 2, 128, threshold=0.5),
+    'd0_128_train': lambda E: case_train(E, 'd0_128_train', 'efficientdet-d0', 20, 3, 128),
+    'd0_512_eval': lambda E: case_eval(E, 'd0_512_eval', 'efficientdet-d0', 80, 1, 512, threshold=0.6, full=False),
+    'd4_256_eval': lambda E: case_eval(E, 'd4_256_eval', 'efficientdet-d4', 4, 1, 256, threshold=0.5, full=False),
+    'd1_128_train': lambda E: case_train(E, 'd1_128_train', 'efficientdet-d1', 6, 2, 128),
+    # the BASELINE.json geometries themselves: configs[2] = D0 train @512 with every parameter gradient,
+    # configs[4] = D4 @1024 (80 classes, the COCO shape both are quoted on)
+    'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),
+    'd4_1024_eval': lambda E: case_eval(E, 'd4_1024_eval', 'efficientdet-d4', 80, 1, 1024, threshold=0.6, full=False, dets=False),
+    'd0_128_dropconnect': lambda E: case_train_dropconnect(E, 'd0_128_dropconnect', 'efficientdet-d0', 20, 4, 128),
+}
+
+
 if __name__ == '__main__':
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     E = import_reference()
-    case_anchors(E)
-    case_eval(E, 'd0_128_eval', 'efficientdet-d0', 20, 2, 128, threshold=0.5)
-    case_train(E, 'd0_128_train', 'efficientdet-d0', 20, 3, 128)
-    case_eval(E, 'd0_512_eval', 'efficientdet-d0', 80, 1, 512, threshold=0.6, full=False)
-    case_eval(E, 'd4_256_eval', 'efficientdet-d4', 4, 1, 256, threshold=0.5, full=False)
-    case_train(E, 'd1_128_train', 'efficientdet-d1', 6, 2, 128)
+    for name in (sys.argv[1:] or list(CASES)):
+        CASES[name](E)

@@ -35,7 +35,7 @@ def test_anchors_bit_exact(golden_dir):
         np.testing.assert_array_equal(a[0, :18], g[f'head_{H}x{W}'])
 
 
-@pytest.mark.parametrize('case', ['d0_128_eval', 'd0_512_eval', 'd4_256_eval'])
+@pytest.mark.parametrize('case', ['d0_128_eval', 'd0_512_eval', 'd4_256_eval', 'd4_1024_eval'])     # last: BASELINE configs[4] geometry
 def test_eval_forward_matches_reference(golden_dir, case):
     g = _load(golden_dir, case)
     net, nc, B, S = str(g['network']), int(g['num_classes']), int(g['B']), int(g['S'])
@@ -73,7 +73,7 @@ def test_nms_and_detections(golden_dir, case):
         np.testing.assert_allclose(s.numpy()[:16], g[f'det{b}_scores'][:16], rtol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['d0_128_train', 'd1_128_train'])
+@pytest.mark.parametrize('case', ['d0_128_train', 'd1_128_train', 'd0_512_train'])                  # last: BASELINE configs[2] geometry
 def test_train_losses_and_grads(golden_dir, case):
     g = _load(golden_dir, case)
     net, nc, B, S = str(g['network']), int(g['num_classes']), int(g['B']), int(g['S'])
