@@ -8,8 +8,10 @@ Prints ONE JSON line on rank 0.  metric = BASELINE.json's "images/sec EfficientD
 workload = configs[2] (batch 32 per GPU @ 512x512, synthetic COCO-shape targets, random-init weights,
 80 classes, W_bifpn 64 / D_bifpn 2).  Weak scaling: per-GPU batch fixed, value = total images / s.
 Extra objects: roofline (dominant kernel = the bf16 MFMA implicit-GEMM conv, timed live with HIP events
-on the launch stream), cpu_baseline (the oracle = torch-CPU restatement of the reference, bounded sample),
-inference (configs[1]: batch-32 eval forward + decode + on-device NMS, ms/img).
+on the launch stream), parity_mode (the SAME train step in fp32 = the dtype that meets the 1e-3 parity gate, with its own
+roofline against the fp32 MFMA peak), inference (configs[1]: batch-32 eval forward + decode + on-device NMS, ms/img, both
+dtypes), inference_d4 (configs[4]: D4 batch 8 @ 1024), cpu_baseline (the oracle = torch-CPU restatement of the reference,
+bounded sample, thread sweep + configs[0]).
 """
 import argparse
 import json
@@ -39,70 +41,121 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-parity-mode', action='store_true', help='skip the fp32 (parity dtype) legs')
+    ap.add_argument('--no-d4', action='store_true', help='skip configs[4] (D4 batch 8 @ 1024 inference)')
+    ap.add_argument('--parity-steps', type=int, default=6)
+    ap.add_argument('--parity-warmup', type=int, default=2)
     ap.add_argument('--torch-optim', action='store_true', help='stock clip_grad_norm_ + torch.optim.AdamW(fused) instead of the HIP ClipAdamW')
     return ap.parse_args()
 
 
 def cpu_baseline(network, size, seconds_budget=25.0):
-    """The oracle (kind 'port': torch-CPU restatement of the reference, pinned on its golden vectors) timed on
-    this host: B=4 forward + FocalLoss + backward at 512x512, as many repetitions as fit the budget."""
+    """The oracle (kind 'port': torch-CPU restatement of the reference, pinned on its golden vectors) timed on this host:
+    forward + FocalLoss + backward at 512x512 over a sweep of intra-op thread counts (an over-subscribed pool is SLOWER than
+    a moderate one for these small-batch convs), best reported with its thread count; plus BASELINE configs[0]
+    (B=1 forward to (cls, reg, anchors))."""
     from oracle import effdet_oracle as O
-    nc, B = 80, 4
-    cores = torch.get_num_threads()
+    nc, B = 80, 2
+    ncpu = os.cpu_count() or 1
     sd = O.make_state_dict(network, nc, seed=0)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running_' not in k
               and not k.startswith(('backbone._conv_head', 'backbone._bn1', 'backbone._fc'))}
     live = dict(sd); live.update(params)
     img, ann = O.synthetic_batch(B, size, seed=1, num_classes=nc)
-    times = []
-    t_end = time.perf_counter() + seconds_budget
-    while True:
+
+    def one():
         t0 = time.perf_counter()
         cl, rl = O.train_losses(live, network, nc, img, ann)
         (cl.mean() + rl.mean()).backward()
-        times.append(time.perf_counter() - t0)
+        dt = time.perf_counter() - t0
         for p in params.values():
             p.grad = None
-        if time.perf_counter() + times[-1] > t_end or len(times) >= 6:
+        return dt
+    t_start = time.perf_counter()
+    sweep, first = {}, True
+    for nt in [t for t in (8, 16, 32, 64, 128) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(nt)
+        if first:
+            one(); first = False                       # warm-up (allocator, oneDNN primitive cache)
+        ts = [one()]
+        if time.perf_counter() - t_start < seconds_budget * 0.7:
+            ts.append(one())
+        sweep[nt] = round(B / min(ts), 3)
+        if time.perf_counter() - t_start > seconds_budget:
             break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {'value': round(B / best, 3), 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle (torch-CPU fp32 restatement of the reference) %s B=%d %dx%d fwd+loss+bwd, %d reps, best of reps after warm-up'
-                      % (network, B, size, size, len(times))}
+    best_nt = max(sweep, key=sweep.get)
+    torch.set_num_threads(best_nt)
+    with torch.no_grad():                               # configs[0]: D0, 1x3x512x512, forward only
+        O.forward_raw(sd, network, nc, img[:1])
+        f = []
+        for _ in range(3):
+            t0 = time.perf_counter(); O.forward_raw(sd, network, nc, img[:1]); f.append(time.perf_counter() - t0)
+    return {'value': sweep[best_nt], 'unit': 'images/sec', 'cores': best_nt, 'kind': 'port', 'host_cpus': ncpu,
+            'threads_sweep_img_per_s': sweep,
+            'config0_forward_ms': round(min(f) * 1e3, 1), 'config0_threads': best_nt,
+            'sample': 'oracle (torch-CPU fp32 restatement of the reference) %s B=%d %dx%d fwd+loss+bwd per thread count (best of <=2 reps after '
+                      'one warm-up); config0 = B=1 forward, best of 3' % (network, B, size, size)}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
-    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
-    ndev = torch.cuda.device_count()
-    if local >= ndev:      # debug only (EFFDET_BENCH_BACKEND=gloo): several ranks sharing one GPU to exercise the N>1 control flow
-        assert os.environ.get('EFFDET_BENCH_BACKEND') == 'gloo', 'rank %d has no GPU of its own (%d visible)' % (local, ndev)
-        local %= ndev
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, ops, ddp
-    import torch.distributed as dist
-    if world > 1:
-        ddp.init_process_group_from_env(os.environ.get('EFFDET_BENCH_BACKEND', 'nccl'))     # 'nccl' IS RCCL on ROCm
-    dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-    cfg = EFFICIENTDET[a.network]
+def build_model(network, dtype, dev, training):
+    from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET
+    cfg = EFFICIENTDET[network]
     torch.manual_seed(0)
-    model = EfficientDet(num_classes=80, network=a.network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'],
-                         D_class=cfg['D_class'], compute_dtype=dtype).to(dev)
-    model.train(); model.is_training = True; model.freeze_bn()
+    m = EfficientDet(num_classes=80, network=network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'], D_class=cfg['D_class'],
+                     is_training=training, compute_dtype=dtype).to(dev)
+    if training:
+        m.train(); m.is_training = True; m.freeze_bn()
+    else:
+        m.eval(); m.is_training = False
+    return m
+
+
+def roofline_of(summ, dtype_name, batch, size):
+    """Dominant MFMA kernel of one instrumented step (per-launch HIP events on the launch stream) against the dense peak."""
+    peak = BF16_MFMA_PEAK_TFLOPS if dtype_name == 'bf16' else F32_MFMA_PEAK_TFLOPS
+    hbm = {k: v for k, v in summ.items() if not k.startswith('conv_')}       # byte-counted (HBM-bound) kernels
+    mf = {k: v for k, v in summ.items() if k.startswith('conv_')}            # flop-counted MFMA kernels
+    name, d = max(mf.items(), key=lambda kv: kv[1]['ms'])
+    ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+    # HBM bytes per launch and MFMA-pipe utilisation of the dominant kernel: PMC counters cannot be read from inside this
+    # process; the values are those measured by separate `rocprofv3 --pmc` passes on this same command and committed
+    # under profiles/ (null when no such file / another dtype or shape)
+    traffic = util = src = None
+    for fn in ('r02_pmc.json', 'r01_hbm_traffic.json'):
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+            if tj.get('dtype', 'bf16') == dtype_name and batch == 32 and size == 512:
+                kk = tj['kernels'].get(name, {})
+                traffic, util, src = kk.get('hbm_bytes_per_launch'), kk.get('mfma_busy_frac'), 'profiles/' + fn
+                break
+        except Exception:
+            pass
+    return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': (src + ' (rocprofv3 PMC, per launch)') if src else None,
+            'launches_per_step': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+            'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+            'all_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
+                            for k, v in mf.items()},
+            'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)}
+                            for k, v in hbm.items()}}
+
+
+def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofline):
+    """EXACTLY `steps` timed train steps (after `warmup` untimed ones) in one compute dtype -> (img/s, ms/step, loss, roofline)."""
+    import torch.distributed as dist
+    from efficientdet.pytorch_amd import ops, ddp
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    from efficientdet.pytorch_amd.synthetic import synthetic_batch      # the package's own generator: the GPU legs are oracle-free
+    dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
+    model = build_model(a.network, dtype, dev, True)
     ddp.freeze_dead_parameters(model)
     net = ddp.wrap(model, device_ids=[local]) if world > 1 else model
     params = [p for p in model.parameters() if p.requires_grad]
     if a.torch_optim:
         opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
-    else:   # the same arithmetic (clip_grad_norm_(0.1) + AdamW(lr 1e-4, wd 1e-2)) as three HIP launches (SURVEY §8(f) rank 1)
-        from efficientdet.pytorch_amd.optim import ClipAdamW
+    else:   # the same arithmetic (clip_grad_norm_(0.1) + AdamW(lr 1e-4, wd 1e-2)) as three HIP launches (SURVEY 8(f) rank 1)
         opt = ClipAdamW(params, lr=1e-4, max_norm=0.1)
-
-    # synthetic data resident in HBM before the timed region (SURVEY §8d: randn images, COCO-shape targets)
-    sys.path.insert(0, ROOT)
-    from oracle.effdet_oracle import synthetic_batch     # input generator only (no compute): same seeded inputs as parity tests
+    # synthetic data resident in HBM before the timed region (SURVEY 8d: randn images, COCO-shape targets)
     img, ann = synthetic_batch(a.batch, a.size, seed=1 + rank, num_classes=80)
     img, ann = img.to(dev), ann.to(dev)
 
@@ -121,11 +174,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         loss = step()
     sync_all()
     dt = time.perf_counter() - t0
@@ -133,83 +186,110 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ms_step = dt / a.steps * 1e3
-    value = a.batch * world * a.steps / dt
+    roof = None
+    if want_roofline:
+        # live per-launch timing with HIP events on the launch stream (one instrumented step).  EVERY rank runs the step
+        # (under DDP its gradient all-reduce is collective); only rank 0 instruments it.
+        if rank == 0:
+            ops.PROFILE = ops.LaunchProfile()
+        step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            summ = ops.PROFILE.summary(); ops.PROFILE = None
+            roof = roofline_of(summ, dtype_name, a.batch, a.size)
+        if world > 1:
+            dist.barrier()
+    final = float(loss.item())
+    del opt, net, model
+    torch.cuda.empty_cache()
+    return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img
 
+
+def inference_leg(network, dtype, dev, img, reps=5):
+    """eval forward + decode + per-image NMS (thr 0.01, IoU 0.5) on RANDOM-INIT weights: every anchor passes the threshold = the
+    NMS worst case.  -> (ms/img end to end, ms/img forward only, kept boxes of image 0)."""
+    model = build_model(network, dtype, dev, False)
+    B = img.shape[0]
+    with torch.no_grad():
+        for _ in range(2):
+            model.detect(img)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(reps):
+            dets = model.detect(img)
+        torch.cuda.synchronize(); ti = (time.perf_counter() - t1) / reps
+        for _ in range(2):
+            model.forward_raw(img)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(reps):
+            model.forward_raw(img)
+        torch.cuda.synchronize(); tf = (time.perf_counter() - t1) / reps
+    kept = int(dets[0][0].numel())
+    del model
+    torch.cuda.empty_cache()
+    return round(ti * 1e3 / B, 4), round(tf * 1e3 / B, 4), kept
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1)); local = int(os.environ.get('LOCAL_RANK', 0))
+    assert world == a.gpus, 'launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)' % (a.gpus, world)
+    ndev = torch.cuda.device_count()
+    if local >= ndev:      # debug only (EFFDET_BENCH_BACKEND=gloo): several ranks sharing one GPU to exercise the N>1 control flow
+        assert os.environ.get('EFFDET_BENCH_BACKEND') == 'gloo', 'rank %d has no GPU of its own (%d visible)' % (local, ndev)
+        local %= ndev
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    from efficientdet.pytorch_amd import EFFICIENTDET, ddp
+    import torch.distributed as dist
+    if world > 1:
+        ddp.init_process_group_from_env(os.environ.get('EFFDET_BENCH_BACKEND', 'nccl'))     # 'nccl' IS RCCL on ROCm
+    cfg = EFFICIENTDET[a.network]
+    d0_512 = a.network == 'efficientdet-d0' and a.size == 512
+
+    value, ms_step, final_loss, roof, img = train_leg(a, a.dtype, a.steps, a.warmup, rank, world, local, dev, not a.no_roofline)
     out = {
         'metric': 'images/sec EfficientDet-D0 512px fwd+bwd', 'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
         'config': {'workload': 'EfficientDet-D0 train step (fwd + FocalLoss/SmoothL1 + bwd + clip_grad_norm + AdamW), batch %d/GPU @ %dx%d, '
-                               'synthetic COCO-shape targets, 80 classes, random-init, W_bifpn=%d D_bifpn=%d' % (a.batch, a.size, a.size, cfg['W_bifpn'], cfg['D_bifpn']),
+                               'synthetic COCO-shape targets, 80 classes, random-init, W_bifpn=%d D_bifpn=%d, drop_connect 0.2 active'
+                               % (a.batch, a.size, a.size, cfg['W_bifpn'], cfg['D_bifpn']),
                    'network': a.network, 'global_batch': a.batch * world, 'image_size': a.size, 'parallelism': 'dp%d' % world,
-                   'final_loss': round(float(loss.item()), 4)},
-        'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / ms_step, 2) if a.network == 'efficientdet-d0' and a.size == 512 else None,
+                   'final_loss': round(final_loss, 4)},
+        'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / ms_step, 2) if d0_512 else None,
     }
+    if roof is not None:
+        out['roofline'] = roof
 
-    if not a.no_roofline:
-        # live per-launch timing of the MFMA kernels with HIP events on the launch stream (one instrumented step).
-        # EVERY rank runs the step (under DDP its gradient all-reduce is collective); only rank 0 instruments it.
-        if rank == 0:
-            ops.PROFILE = ops.LaunchProfile()
-        step()
-        torch.cuda.synchronize()
-    if rank == 0 and not a.no_roofline:
-        summ = ops.PROFILE.summary(); ops.PROFILE = None
-        peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == 'bf16' else F32_MFMA_PEAK_TFLOPS
-        hbm = {k: v for k, v in summ.items() if not k.startswith('conv_')}       # byte-counted (HBM-bound) kernels
-        summ = {k: v for k, v in summ.items() if k.startswith('conv_')}          # flop-counted MFMA kernels
-        dom = max(summ.items(), key=lambda kv: kv[1]['ms'])
-        name, d = dom
-        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        # HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
-        # the one measured by `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, FETCH x2 gfx950
-        # correction) on this same command and committed under profiles/ (null when no such file / other dtype)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, 'profiles', 'r01_hbm_traffic.json')))
-            if a.dtype == 'bf16' and a.batch == 32 and a.size == 512:
-                traffic = tj['kernels'].get(name, {}).get('hbm_bytes_per_launch')
-        except Exception:
-            traffic = None
-        out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4), 'traffic': traffic,
-                           'traffic_source': 'profiles/r01_hbm_traffic.json (rocprofv3 PMC, per launch)' if traffic else None,
-                           'launches_per_step': d['launches'],
-                           'avg_launch_ms': round(d['ms'] / d['launches'], 4),
-                           'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
-                           'all_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                               'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)} for k, v in summ.items()},
-                           'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3),
-                                               'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)} for k, v in hbm.items()}}
-    if world > 1:
-        dist.barrier()
+    if world == 1 and a.dtype == 'bf16' and not a.no_parity_mode:
+        # the SAME workload in the parity dtype: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the mode that meets north_star's
+        # 1e-3 gate against the reference (tests/test_gpu_model.py); its own roofline is priced against the fp32 MFMA peak
+        pv, pms, ploss, proof, _ = train_leg(a, 'f32', a.parity_steps, a.parity_warmup, rank, world, local, dev, not a.no_roofline)
+        out['parity_mode'] = {'dtype': 'f32', 'value': round(pv, 2), 'unit': 'images/sec', 'ms_per_step': round(pms, 3),
+                              'steps': a.parity_steps, 'warmup': a.parity_warmup, 'final_loss': round(ploss, 4),
+                              'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / pms, 2) if d0_512 else None,
+                              'note': 'same step, fp32 storage + exact-fp32 MFMA: the 1e-3 parity mode', 'roofline': proof}
 
     if rank == 0 and world == 1 and not a.no_inference:
-        # configs[1] is quoted on RANDOM-INIT weights (every anchor passes the 0.01 threshold = NMS worst case); the model
-        # above has been updated by the timed AdamW steps, so use a fresh one
-        del opt
-        torch.manual_seed(0)
-        model = EfficientDet(num_classes=80, network=a.network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'],
-                             D_class=cfg['D_class'], is_training=False, compute_dtype=dtype).to(dev)
-        model.eval(); model.is_training = False
-        with torch.no_grad():
-            for _ in range(2):
-                model.detect(img)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                dets = model.detect(img)
-            torch.cuda.synchronize(); ti = (time.perf_counter() - t1) / reps
-            for _ in range(2):
-                model.forward_raw(img)
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            for _ in range(reps):
-                model.forward_raw(img)
-            torch.cuda.synchronize(); tf = (time.perf_counter() - t1) / reps
-        out['inference'] = {'workload': 'D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
-                            'ms_per_img': round(ti * 1e3 / a.batch, 4), 'forward_only_ms_per_img': round(tf * 1e3 / a.batch, 4),
-                            'kept_boxes_img0': int(dets[0][0].numel())}
+        dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+        ti, tf, kept = inference_leg(a.network, dtype, dev, img)
+        out['inference'] = {'workload': 'configs[1]: D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
+                            'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+        if a.dtype == 'bf16' and not a.no_parity_mode:
+            ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3)
+            out['inference']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+        del img
+        torch.cuda.empty_cache()
+        if not a.no_d4:
+            from efficientdet.pytorch_amd.synthetic import synthetic_batch
+            img4 = synthetic_batch(8, 1024, seed=1, num_classes=80)[0].to(dev)
+            ti, tf, kept = inference_leg('efficientdet-d4', dtype, dev, img4, reps=3)
+            out['inference_d4'] = {'workload': 'configs[4]: D4 eval batch 8 @ 1024: forward + decode + per-image NMS (thr 0.01, IoU 0.5)',
+                                   'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
+                                   'forward_tflops': round(455.596 * 8 / (tf * 8) , 2)}
+            if a.dtype == 'bf16' and not a.no_parity_mode:
+                ti, tf, kept = inference_leg('efficientdet-d4', torch.float32, dev, img4, reps=2)
+                out['inference_d4']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a.network, a.size)

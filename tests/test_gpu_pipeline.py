@@ -1,0 +1,258 @@
+"""GPU parity of the boundary kernels (csrc/pipeline.hip) and of the rows they close: drop_connect (a7), device input
+pipeline (f2), batched eval consumer (f3), differentiable (cls, reg, anchors) triple (a2), optimizer checkpointing (f4)."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import effdet_oracle as O
+from oracle import pipeline_oracle as PO
+from tests.gpu_util import assert_close, assert_close_scale
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(net, nc, dtype, seed=0, **kw):
+    from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET
+    c = EFFICIENTDET[net]
+    m = EfficientDet(nc, network=net, W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'], compute_dtype=dtype, **kw)
+    m.load_state_dict(O.make_state_dict(net, nc, seed=seed))
+    return m.cuda()
+
+
+# ------------------------------------------------------------------------------------------------ drop_connect (a7)
+def test_drop_connect_device_stream_is_bit_exact():
+    """Integer parity: the HIP generator == the Philox4x32-10 oracle (pinned on Random123's known answers), word for word."""
+    from efficientdet.pytorch_amd import ops
+    keep = [1.0 - 0.2 * i / 16 for i in (2, 4, 6, 7, 9, 10, 12, 13, 14)]
+    kd = torch.tensor(keep, dtype=torch.float32, device='cuda')
+    for seed, step, B in [(1234, 0, 32), (2 ** 63 + 12345, 2 ** 33 + 7, 5), (0, 1, 1)]:
+        got = ops.drop_connect_scales(kd, B, seed, step).cpu().numpy()
+        assert np.array_equal(got, PO.drop_connect_scales(keep, B, seed, step)), (seed, step, B)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_drop_connect_injected_masks_vs_real_reference(golden_dir, dtype):
+    """The REAL reference ran with drop_connect active (rate 0.5) and its Bernoulli draws were recorded; the HIP model with
+    the same masks injected through the rowscale path (conv epilogue forward, act_bwd backward) must reproduce its losses
+    and every parameter gradient (models/utils.py:79-90, models/efficientnet.py:98-101)."""
+    g = np.load(os.path.join(golden_dir, 'd0_128_dropconnect.npz'), allow_pickle=False)
+    net, nc = str(g['network']), int(g['num_classes'])
+    m = _model(net, nc, dtype, seed=int(g['seed']))
+    m.backbone.drop_connect_rate = float(g['drop_connect_rate'])
+    m.backbone.drop_masks = {int(i): torch.from_numpy(r) for i, r in zip(g['drop_blocks'], g['drop_masks'])}
+    m.train(); m.is_training = True; m.freeze_bn()
+    img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
+    cl, rl = m([img.cuda(), torch.from_numpy(g['annots']).cuda()])
+    (cl.mean() + rl.mean()).backward()
+    torch.cuda.synchronize()
+    ltol, gtol = (1e-3, 1e-3) if dtype == torch.float32 else (3e-2, 0.15)
+    assert_close(cl.detach().cpu(), torch.from_numpy(g['cls_loss']), ltol, 'cls loss')
+    assert_close(rl.detach().cpu(), torch.from_numpy(g['reg_loss']), ltol, 'reg loss')
+    dead = set(str(x) for x in g['dead_params'])
+    for k, p in m.named_parameters():
+        if k in dead:
+            continue
+        ref = g['grad_' + k + '_summary']
+        l2 = float(p.grad.double().pow(2).sum().sqrt())
+        assert abs(l2 - ref[2]) <= gtol * ref[2] + 1e-7, (k, l2, ref[2])
+    # without the injected masks the generator path runs (different masks -> different loss), and eval ignores the rate
+    m.backbone.drop_masks = None
+    torch.manual_seed(3)
+    cl2, _ = m([img.cuda(), torch.from_numpy(g['annots']).cuda()])
+    assert abs(float(cl2) - float(g['cls_loss'])) > 1e-4 * abs(float(g['cls_loss']))
+    cl3, _ = m([img.cuda(), torch.from_numpy(g['annots']).cuda()])
+    assert float(cl3) != float(cl2)                       # the step counter advances the stream
+
+
+def test_drop_connect_generator_statistics_and_seeding():
+    m = _model('efficientdet-d0', 4, torch.bfloat16)
+    m.train()
+    torch.manual_seed(11)
+    a = m._drop_connect_rowscales(256, torch.device('cuda'))
+    b = m._drop_connect_rowscales(256, torch.device('cuda'))
+    assert sorted(a) == [2, 4, 6, 7, 9, 10, 12, 13, 14]          # the identity-skip blocks of B0 (block 0.. of each stage skipped)
+    for i, r in a.items():
+        kp = 1.0 - 0.2 * i / 16
+        assert abs(float((r > 0).float().mean()) - kp) < 0.08 and not torch.equal(r, b[i])
+    m2 = _model('efficientdet-d0', 4, torch.bfloat16); m2.train()
+    torch.manual_seed(11)
+    a2 = m2._drop_connect_rowscales(256, torch.device('cuda'))
+    assert all(torch.equal(a[i], a2[i]) for i in a)              # torch.manual_seed controls the stream
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline (f2)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_device_collater_vs_reference_chain(dtype):
+    from efficientdet.pytorch_amd.data import DeviceCollater
+    from efficientdet.pytorch_amd.synthetic import synthetic_raw_images
+    from efficientdet.pytorch_amd import ops
+    imgs, annots = synthetic_raw_images(5, seed=3, min_side=40, max_side=150)
+    imgs.append(np.random.RandomState(1).randint(0, 256, (96, 96, 3), dtype=np.uint8)); annots.append(np.zeros((0, 5), np.float32))
+    samples = [{'img': i, 'annot': a} for i, a in zip(imgs, annots)]
+    col = DeviceCollater(common_size=96, dtype=dtype, flip_x=0.5, seed=4)
+    flips = np.random.RandomState(4).rand(len(samples)) < 0.5
+    assert flips.any() and not flips.all()
+    packed, ann, scale = col(samples)
+    ref_img, ref_ann, ref_scale = PO.collate_reference(samples, 96, flips)
+    got = ops.nhwc_to_nchw(packed.map).cpu().numpy()
+    assert got.shape == (6, packed.map.C, 96, 96) and np.all(got[:, 3:] == 0)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2          # bf16 storage of values up to ~2.6
+    assert np.abs(got[:, :3] - ref_img).max() <= tol * max(1.0, np.abs(ref_img).max()), np.abs(got[:, :3] - ref_img).max()
+    np.testing.assert_allclose(scale.cpu().numpy(), ref_scale, rtol=1e-6)
+    np.testing.assert_allclose(ann.cpu().numpy(), ref_ann, rtol=1e-5, atol=1e-4)
+    # the 96x96 image is not resized: exact normalisation, bit-for-bit in fp32
+    if dtype == torch.float32 and not flips[5]:
+        want = ((imgs[5].astype(np.float32) * np.float32(1 / 255.0) - np.array(PO.MEAN[0, 0], np.float32)) *
+                (np.float32(1) / np.array(PO.STD[0, 0], np.float32))).transpose(2, 0, 1)
+        np.testing.assert_allclose(got[5, :3], want, rtol=0, atol=1e-6)
+
+
+def test_packed_images_feed_the_model_like_nchw():
+    """model(PackedImages) == model(NCHW tensor holding the same values): the stem reads the packed batch directly."""
+    from efficientdet.pytorch_amd import ops, PackedImages
+    m = _model('efficientdet-d0', 6, torch.float32, is_training=False)
+    m.eval()
+    img, _ = O.synthetic_batch(2, 128, seed=3, num_classes=6)
+    img = img.cuda()
+    packed = PackedImages(ops.nchw_to_nhwc(img, torch.float32, cpad=4))
+    c1, r1, a1 = m.forward_raw(img)
+    c2, r2, a2 = m.forward_raw(packed)
+    assert torch.equal(a1, a2)
+    assert_close(c2.cpu(), c1.cpu(), 1e-5, 'cls'); assert_close(r2.cpu(), r1.cpu(), 1e-5, 'reg')
+    mb = _model('efficientdet-d0', 6, torch.bfloat16, is_training=False)
+    with pytest.raises(RuntimeError):
+        mb.forward_raw(packed)                               # fp32 pack into a bf16 model: refused, not reinterpreted
+
+
+# ------------------------------------------------------------------------------------------------ eval consumer (f3)
+def test_batched_eval_consumer_vs_reference_loop():
+    from efficientdet.pytorch_amd import evaluate as EV
+    m = _model('efficientdet-d0', 8, torch.float32, is_training=False, threshold=0.4)
+    m.eval()
+    img, _ = O.synthetic_batch(3, 128, seed=2, num_classes=8)
+    scales = np.array([0.5, 1.25, 2.0], dtype=np.float32)
+    per_image = m.detect(img.cuda())
+    assert min(len(s) for s, _, _ in per_image) > 100          # random init: plenty above the threshold
+    thr = float(np.median(per_image[0][0].cpu().numpy()[:100]))         # a threshold that cuts inside the top-100
+    dets, counts = EV.detections_batched(m, img.cuda(), scales, score_threshold=thr, max_detections=100)
+    for b, (s, l, bx) in enumerate(per_image):
+        ref = PO.finalize_reference(s.cpu().numpy(), l.cpu().numpy(), bx.cpu().numpy(), scales[b], thr, 100)
+        assert counts[b] == len(ref) and 0 < counts[b] <= 100
+        np.testing.assert_array_equal(dets[b, :counts[b]], ref)             # same divisions, same rows: bit-exact
+        assert np.all(dets[b, counts[b]:, 5] == -1)
+    rows = EV.all_detections_rows(dets, counts, 8)
+    assert len(rows) == 3 and len(rows[0]) == 8 and sum(len(r) for r in rows[0]) == counts[0] and rows[0][0].shape[1] == 5
+    dx, cx = EV.detections_batched(m, img.cuda(), scales, score_threshold=thr, max_detections=100, xywh=True)
+    res = EV.coco_results(dx, cx, image_ids=[10, 11, 12], label_to_coco_label=lambda c: c + 1)
+    s, l, bx = per_image[1]
+    ref = PO.coco_results_reference(s.cpu().numpy()[:100], l.cpu().numpy()[:100], bx.cpu().numpy()[:100], scales[1], 11, thr, lambda c: c + 1)
+    got = [r for r in res if r['image_id'] == 11]
+    assert got == ref
+
+
+# ------------------------------------------------------------------------------------------------ differentiable triple (a2)
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_forward_raw_is_differentiable(dtype):
+    """(classification, regression, anchors) of models/efficientdet.py:64-66 under autograd: a caller-side criterion on the
+    triple gives the same parameter gradients as the oracle's autograd through the same criterion."""
+    net, nc = 'efficientdet-d0', 6
+    m = _model(net, nc, dtype)
+    m.backbone.drop_connect_rate = 0.0
+    m.train(); m.freeze_bn()
+    img, _ = O.synthetic_batch(2, 128, seed=4, num_classes=nc)
+    gen = torch.Generator().manual_seed(0)
+    cls, reg, anc = m.forward_raw(img.cuda())
+    wc = torch.randn(cls.shape, generator=gen); wr = torch.randn(reg.shape, generator=gen)
+    assert cls.requires_grad and reg.requires_grad and not anc.requires_grad
+    ((cls * wc.cuda()).sum() + (reg * wr.cuda()).sum()).backward()
+    sd = O.make_state_dict(net, nc, seed=0)
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running_' not in k}
+    live = dict(sd); live.update(params)
+    rc, rr, _ = O.forward_raw(live, net, nc, img)
+    ((rc * wc).sum() + (rr * wr).sum()).backward()
+    tol = 2e-3 if dtype == torch.float32 else 0.12
+    assert_close_scale(cls.detach().cpu(), rc.detach(), 1e-3 if dtype == torch.float32 else 4e-2, 'cls')
+    for k, p in m.named_parameters():
+        if params[k].grad is None:
+            assert p.grad is None, k
+            continue
+        assert_close_scale(p.grad.cpu(), params[k].grad, tol, k)
+
+
+# ------------------------------------------------------------------------------------------------ optimizer checkpoint (f4) + async race
+def _toy_params(n=7, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(33,), (64, 3, 3, 3), (5, 17), (4096 + 13,), (1,), (256, 64), (8, 8, 8)][:n]
+    return [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+
+
+def test_clip_adamw_state_dict_roundtrip_matches_torch():
+    """save -> load -> step: the resumed optimizer continues exactly like torch.optim.AdamW + clip_grad_norm_ that never stopped."""
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    ps = _toy_params(); rs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a = ClipAdamW(ps, lr=1e-2, max_norm=0.5); r = torch.optim.AdamW(rs, lr=1e-2)
+    gen = torch.Generator().manual_seed(1)
+
+    def step(opt, params, ref):
+        grads = [torch.randn(p.shape, generator=gen) for p in params]
+        for p, q, g in zip(params, ref, grads):
+            p.grad = g.cuda().clone(); q.grad = g.cuda().clone()
+        opt.step()
+        torch.nn.utils.clip_grad_norm_(ref, 0.5); r.step()
+    for _ in range(3):
+        step(a, ps, rs)
+    sd = copy.deepcopy(a.state_dict())
+    assert [float(s['step']) for s in sd['state'].values()] == [3.0] * len(ps)          # the DEVICE counters, not a stale host copy
+    ps2 = [p.detach().clone().requires_grad_(True) for p in ps]
+    b = ClipAdamW(ps2, lr=1e-2, max_norm=0.5)
+    b.load_state_dict(sd)
+    for _ in range(2):
+        step(b, ps2, rs)
+    for p, q in zip(ps2, rs):
+        assert_close(p.detach().cpu(), q.detach().cpu(), 2e-5, 'resumed parameters')
+    # torch.optim.AdamW's own state_dict loads too (same keys)
+    c = ClipAdamW([p.detach().clone().requires_grad_(True) for p in ps], lr=1e-2, max_norm=0.5)
+    c.load_state_dict(r.state_dict())
+    assert float(c.state_dict()['state'][0]['step']) == 5.0
+
+
+def test_clip_adamw_no_sync_between_steps():
+    """The host may run steps ahead of the stream (bench.py never synchronises): gradient tensors are fresh every step, so
+    the pointer table changes every step; the pinned staging ring must not be rewritten under an in-flight upload."""
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    ps = _toy_params(); rs = [p.detach().clone().requires_grad_(True) for p in ps]
+    a = ClipAdamW(ps, lr=1e-2, max_norm=0.0); r = torch.optim.AdamW(rs, lr=1e-2)
+    gen = torch.Generator().manual_seed(2)
+    gl = [[torch.randn(p.shape, generator=gen).cuda() for p in ps] for _ in range(12)]
+    big = torch.randn(4096, 4096, device='cuda')
+    torch.cuda.synchronize()
+    keep = []
+    for it in range(12):
+        _ = big @ big                                        # keeps the stream busy so the host gets ahead
+        for p, g in zip(ps, gl[it]):
+            p.grad = g.clone(); keep.append(p.grad)          # distinct addresses every step
+        a.step()
+    for it in range(12):
+        for q, g in zip(rs, gl[it]):
+            q.grad = g.clone()
+        r.step()
+    torch.cuda.synchronize()
+    for p, q in zip(ps, rs):
+        assert_close(p.detach().cpu(), q.detach().cpu(), 2e-5, 'parameters after 12 unsynchronised steps')
+
+
+def test_deepcopy_model_runs_independently():
+    m = _model('efficientdet-d0', 4, torch.float32, is_training=False); m.eval()
+    img, _ = O.synthetic_batch(1, 128, seed=1, num_classes=4)
+    c1, _, _ = m.forward_raw(img.cuda()); c1b, _, _ = m.forward_raw(img.cuda())      # second call replays the recorded table
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        for p in m2.parameters():
+            p.mul_(1.5)
+    del m; torch.cuda.empty_cache()
+    c2, _, _ = m2.forward_raw(img.cuda()); c2b, _, _ = m2.forward_raw(img.cuda())
+    assert bool(torch.isfinite(c2).all()) and not torch.allclose(c2, c1)
+    assert_close(c2b.cpu(), c2.cpu(), 1e-5, 'replayed copy')
