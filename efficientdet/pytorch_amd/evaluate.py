@@ -10,19 +10,30 @@ import torch
 from . import ops
 
 
+def postprocess(model, cls, reg, anc, H, W):
+    """models/efficientdet.py:69-86 for every image of the batch, on the device: decode + clip + class max + threshold + NMS.
+    -> (scores [B,A], labels [B,A] int64, boxes [B,A,4], count [B] int32): score-descending rows, count[b] of them valid."""
+    boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
+    idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
+    s, l, b = ops.gather_dets(boxes, score, label, idx, count)
+    return s, l, b, count
+
+
+def finalize(s, l, b, count, scales, score_threshold=0.05, max_detections=100, xywh=False):
+    """eval.py:104-117 / :279-292 for the batch on the device -> (dets [B,max_detections,6], counts [B]) on the HOST."""
+    sc = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else scales,
+                         dtype=torch.float32, device=s.device).contiguous()
+    out, oc = ops.finalize_dets(s, l, b, count, sc, score_threshold, max_detections, xywh)
+    return out.cpu().numpy(), oc.cpu().numpy()             # the one device->host transfer of the batch
+
+
 def detections_batched(model, images, scales, score_threshold=0.05, max_detections=100, xywh=False):
     """-> (dets [B, max_detections, 6] fp32 on the HOST: x1,y1,x2,y2 (or x,y,w,h), score, label; counts [B] ints).
     images: NCHW fp32 batch or PackedImages; scales: [B] resize factors (tensor, array or list)."""
     with torch.no_grad():
         cls, reg, anc = model.forward_raw(images)
-        H, W = int(images.shape[2]), int(images.shape[3])
-        boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
-        idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
-        s, l, b = ops.gather_dets(boxes, score, label, idx, count)
-        sc = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else scales,
-                             dtype=torch.float32, device=s.device).contiguous()
-        out, oc = ops.finalize_dets(s, l, b, count, sc, score_threshold, max_detections, xywh)
-        return out.cpu().numpy(), oc.cpu().numpy()         # the one device->host transfer of the batch
+        s, l, b, count = postprocess(model, cls, reg, anc, int(images.shape[2]), int(images.shape[3]))
+        return finalize(s, l, b, count, scales, score_threshold, max_detections, xywh)
 
 
 def all_detections_rows(dets, counts, num_classes):

@@ -10,16 +10,16 @@ for s in $STEPS; do
   case $s in
     tests)  timeout 1500 python -m pytest tests -m gpu -q -s > $OUT/pytest.log 2>&1; echo "tests rc=$?" | tee -a $OUT/rc.txt; tail -5 $OUT/pytest.log ;;
     bench)  timeout 900 python bench.py > $OUT/bench.log 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/rc.txt; tail -c 3000 $OUT/bench.log ;;
-    stats)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/stats_bf16 -o run -- python /root/repo/bench.py --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 10 --warmup 3 > /root/repo/$OUT/stats_bf16.log 2>&1); echo "stats_bf16 rc=$?" | tee -a $OUT/rc.txt
-            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/$OUT/stats_f32 -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 4 --warmup 2 > /root/repo/$OUT/stats_f32.log 2>&1); echo "stats_f32 rc=$?" | tee -a $OUT/rc.txt ;;
+    stats)  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_bf16 -o run -- python /root/repo/bench.py --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 10 --warmup 3 > /root/repo/$OUT/stats_bf16.log 2>&1); echo "stats_bf16 rc=$?" | tee -a $OUT/rc.txt
+            (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_f32 -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 4 --warmup 2 > /root/repo/$OUT/stats_f32.log 2>&1); echo "stats_f32 rc=$?" | tee -a $OUT/rc.txt ;;
     pmc)    for p in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
               n=$(echo $p | cut -d' ' -f1)
-              (cd /tmp && timeout 600 rocprofv3 --pmc $p -d /root/repo/$OUT/pmc_$n -o run -- python /root/repo/bench.py --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 2 --warmup 1 > /root/repo/$OUT/pmc_$n.log 2>&1); echo "pmc $n rc=$?" | tee -a $OUT/rc.txt
+              (cd /tmp && timeout 600 rocprofv3 --pmc $p --output-format csv -d /root/repo/$OUT/pmc_$n -o run -- python /root/repo/bench.py --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 2 --warmup 1 > /root/repo/$OUT/pmc_$n.log 2>&1); echo "pmc $n rc=$?" | tee -a $OUT/rc.txt
             done
             python tools/pmc_summary.py $OUT/pmc_bf16.json bf16 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES > $OUT/pmc_summary.log 2>&1; cat $OUT/pmc_summary.log
             # the raw counter CSVs are large: keep the summaries only
             rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;
-    pmcf32) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /root/repo/$OUT/pmcf_SQ -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcf_SQ.log 2>&1); echo "pmcf32 rc=$?" | tee -a $OUT/rc.txt
+    pmcf32) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$OUT/pmcf_SQ -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcf_SQ.log 2>&1); echo "pmcf32 rc=$?" | tee -a $OUT/rc.txt
             python tools/pmc_summary.py $OUT/pmc_f32.json f32 $OUT/none $OUT/none $OUT/pmcf_SQ > $OUT/pmcf_summary.log 2>&1; cat $OUT/pmcf_summary.log; rm -rf $OUT/pmcf_SQ ;;
     *)      echo "unknown step $s" ;;
   esac
