@@ -24,6 +24,11 @@
 //   * 1-D grid with a bijective XCD remap: the 8 blocks that land on one XCD walk neighbouring
 //     tiles (n fastest), so the activation tile is fetched into one private L2 only.
 #include "common.h"
+#include <stdlib.h>
+
+#ifndef EFFDET_IGEMM_BIG_DEFAULT
+#define EFFDET_IGEMM_BIG_DEFAULT 1
+#endif
 
 namespace {
 
@@ -43,6 +48,7 @@ struct ConvK {
   int act, res_mode, out_f32, vec_ok;
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
+  int kord;                    // K walk of the persistent kernel: 0 tap-major, 1 channel-group-major
   SegD seg[EFFDET_MAX_SEG];
 };
 
@@ -280,6 +286,396 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Big-tile variant for the MFMA-bound convolutions (bf16, Cin % 64 == 0: the RetinaHead towers, retina_cls / retina_reg
+// and their data gradients = 95 % of the step's FLOPs).
+//
+// Why another kernel: at 128x128x(K 64) a workgroup moves 32 KiB through the vector-memory path and reads 96 KiB of
+// fragments from LDS for every 2.1 MFLOP.  Per CU that is ~64 B/clk of L1->LDS DMA and >100 % of the LDS port at the
+// full MFMA rate -- three co-saturated resources (measured: MFMA pipe 44 % busy; removing the DMA alone +36 %, the LDS
+// reads alone +23 %).  This variant cuts both per FLOP:
+//   * v_mfma_f32_32x32x16_bf16: a 16-byte fragment feeds 2x the MACs of the 16x16x32 form (LDS read bytes / FLOP halve);
+//   * wave tile 64x64 (2x2 MFMA tiles, 64 accumulator VGPRs), workgroup tile (64*WM) x (64*WN) with WM*WN waves:
+//     256x256 / 16 waves moves 64 KiB per 8.4 MFLOP (DMA bytes / FLOP halve) and still keeps 4 waves per SIMD;
+//     each wave issues 4 DMA pieces per 16 MFMAs of 32 cycles (the 128x128 kernel: 4 pieces per 16 MFMAs of 16 cycles);
+//   * a K-step (64 channels) never straddles a filter tap (Cin % 64 == 0), so the tap walk is SCALAR: the per-lane
+//     VGPR offset is the pixel's own (centre) address, chosen once per tap between "valid" and the out-of-range
+//     sentinel from a precomputed tap-validity bit mask, and the tap / channel advance rides in the buffer
+//     instruction's SGPR offset (excluded from the bounds check, so the sentinel still zero-fills).  The SRD base is
+//     moved back by the pad margin so that SGPR offset is never negative.  ~0 address VALU per K-step.
+// Same LDS image (128-byte rows, chunk ^ ((row>>1)&7) applied at the DMA source), same two-level software pipeline
+// (DMA two tiles ahead, fragments one K16-slice ahead, one barrier per K-step) and the same fused epilogue.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Out-of-range sentinel of this kernel's VGPR offsets.  The SGPR offset takes part in the hardware range check (measured:
+// a valid lane whose voffset + soffset passes num_records reads zeros), so (a) num_records covers the whole extent
+// relative to the shifted base and (b) the sentinel leaves headroom for the largest soffset without wrapping 32 bits.
+#define BIG_OOB 0x80000000u
+
+__device__ __forceinline__ void dma16_async_s(u32x4_t rsrc, unsigned lds_byte_addr, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :: "s"(lds_byte_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Persistent form of the big-tile kernel (one workgroup per CU walks tiles blockIdx.x, +gridDim.x, ...).
+// Measured on the 256x256 / 16-wave tile with everything in the K loop knocked out (no DMA, no LDS reads, no barrier) the
+// launch still ran at 963 TFLOP/s against 1721 for bare 32x32x16 MFMAs on random data: with ONE workgroup per CU the
+// first-tile fetch (every CU pulls 128 KiB at once) and the 8-byte-per-lane store tail are fully exposed between the K
+// loops.  Here the NEXT tile's addressing and its first two DMA stages are issued before the current tile's epilogue, so
+// the fetch latency and the store tail overlap, and the bf16 stores are 16 bytes per lane: lanes l and l+32 of an MFMA
+// 32x32 accumulator hold adjacent 4-channel groups of the same pixel, one v_permlane32_swap per dword pairs them up.
+// NS = LDS stages (DMA runs NS-1 K-steps ahead).  With two stages a tile's DMA has exactly one K-step to land and the
+// barrier waits for the slowest of ~500 cache lines per CU (PMC: 22 % of them L2 misses): the K-step time tracked the miss tail,
+// not the MFMA time -- whatever the tile shape.
+template <int WM, int WN, int NS>
+__global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const ConvK p) {
+  constexpr int NW = WM * WN, TM = 64 * WM, TN = 64 * WN;
+  constexpr int XP = TM / (8 * NW), WP = TN / (8 * NW);
+  constexpr int XT = TM * 8, STG = (TM + TN) * 8, NP = XP + WP;
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const unsigned lds0 = lds_addr(smem);
+  const int total = p.mtiles * p.ntiles;
+  const int taps = p.Kc / p.cpt, cpt8 = p.cpt >> 3, nk = taps * cpt8;
+  const u32x4_t rw = make_srd_raw(p.w, p.w_bytes);
+  const int prow = lane >> 3;
+  const int l31 = lane & 31, lh = lane >> 5, lsw = (l31 >> 1) & 7;
+  int ai[2], bi[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) ai[a] = XT + (wn * 64 + a * 32 + l31) * 8;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) bi[b] = (wm * 64 + b * 32 + l31) * 8;
+
+  // per-tile DMA state: `c*` = the tile being computed, `n*` = the next one (set up ahead of the epilogue)
+  u32x4_t c_rx; int c_si, c_mbase, c_nbase, c_W;
+  unsigned c_xv[XP], c_vm[XP], c_wv[WP];
+  auto setup = [&](int tile, u32x4_t& rx, int& si, int& m_base, int& n_base, int& sW, unsigned (&xv_c)[XP], unsigned (&vmask)[XP],
+                   unsigned (&wv)[WP]) {
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    si = 0;
+#pragma unroll
+    for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+      if (s < p.nseg && mt >= p.seg[s].tile_start) si = s;
+    const SegD sg = p.seg[si];
+    m_base = (mt - sg.tile_start) * TM; n_base = nt * TN; sW = sg.W;
+    const int HoWo = sg.Ho * sg.Wo;
+    const long long margin = ((long long)p.pad_t * sg.W + p.pad_l) * p.ldx;
+    {
+      const u32x4_t r0 = make_srd_raw((const bf16_t*)p.x + sg.in_off - margin, sg.x_bytes + (unsigned)(margin * 2));
+      rx = u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)r0[0]), (unsigned)__builtin_amdgcn_readfirstlane((int)r0[1]),
+                   (unsigned)__builtin_amdgcn_readfirstlane((int)r0[2]), (unsigned)__builtin_amdgcn_readfirstlane((int)r0[3])};
+    }
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int row = (wave + j * NW) * 8 + prow, m = m_base + row;
+      const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+      xv_c[j] = BIG_OOB; vmask[j] = 0u;
+      if (m < sg.M) {
+        const int b = m / HoWo, rem = m - b * HoWo;
+        const int ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+        const int hc = ho * p.stride, wc = wo * p.stride;
+        xv_c[j] = (unsigned)(((long long)b * sg.in_bs + ((long long)hc * sg.W + wc) * p.ldx) * 2) + chunk * 16u;
+        for (int t = 0; t < taps; ++t) {
+          const int kh = t / p.KW, kw = t - kh * p.KW;
+          const int hi = hc - p.pad_t + kh, wi = wc - p.pad_l + kw;
+          if (hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W) vmask[j] |= 1u << t;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const int row = (wave + j * NW) * 8 + prow, n = n_base + row;
+      const unsigned chunk = (unsigned)((lane & 7) ^ ((row >> 1) & 7));
+      wv[j] = (n < p.Cout) ? (unsigned)n * (unsigned)p.Kc * 16u + chunk * 16u : BIG_OOB;
+    }
+  };
+  // scalar K cursor of the NEXT K-step to issue (reset per tile)
+  // p.kord = 0: tap-major (all channel groups of a tap, then the next tap) -- the packed-weight order;
+  // p.kord = 1: channel-group-major (the 9 taps of one 64-channel group back to back): a 128-byte activation line is
+  //             re-read by its 9 taps within 9 consecutive K-steps instead of across the whole K loop, so the re-reads hit
+  //             in L2 (per-CU working set 6 rows x 128 B instead of 6 rows x Cin x 2 B)
+  int st_c, st_t, st_kh, st_kw; unsigned s_x, s_w, s_tapbit;
+  auto reset_cursor = [&]() { st_c = 0; st_t = 0; st_kh = 0; st_kw = 0; s_x = 0u; s_w = 0u; s_tapbit = 1u; };
+  auto piece = [&](int stage, int q, const u32x4_t& rx, const unsigned (&xv_c)[XP], const unsigned (&vmask)[XP], const unsigned (&wv)[WP]) {
+    const unsigned base = lds0 + (unsigned)(stage * STG) * 16u;
+    if (q < XP)
+      dma16_async_s(rx, base + (unsigned)(wave + q * NW) * 1024u, (vmask[q < XP ? q : 0] & s_tapbit) ? xv_c[q < XP ? q : 0] : BIG_OOB, (unsigned)__builtin_amdgcn_readfirstlane((int)s_x));
+    else
+      dma16_async_s(rw, base + (unsigned)(XT * 16) + (unsigned)(wave + (q - XP) * NW) * 1024u, wv[q >= XP ? q - XP : 0], (unsigned)__builtin_amdgcn_readfirstlane((int)s_w));
+  };
+  auto advance = [&](int sW) {
+    if (p.kord == 0) {
+      s_w += 128u;
+      if (++st_c == cpt8) {
+        st_c = 0; s_tapbit <<= 1;
+        if (++st_kw == p.KW) { st_kw = 0; ++st_kh; }
+        s_x = (unsigned)((st_kh * sW + st_kw) * p.ldx) * 2u;
+      } else {
+        s_x += 128u;
+      }
+    } else {
+      ++st_t; s_tapbit <<= 1;
+      if (++st_kw == p.KW) { st_kw = 0; ++st_kh; }
+      if (st_t == taps) { st_t = 0; st_kh = 0; st_kw = 0; s_tapbit = 1u; ++st_c; }
+      s_x = (unsigned)((st_kh * sW + st_kw) * p.ldx) * 2u + (unsigned)st_c * 128u;
+      s_w = (unsigned)(st_t * cpt8 + st_c) * 128u;
+    }
+  };
+  auto wait_tiles = [&](bool deep) {            // vmcnt such that only the tiles issued AFTER the one needed may be in flight
+    if constexpr (NS == 2) { dma_wait_all(); }
+    else {
+      if (deep) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NP * (NS - 2)) : "memory"); }
+      else dma_wait_all();
+    }
+  };
+  auto load = [&](int stage, int s, uint4 (&wf)[2], uint4 (&xf)[2]) {
+    const int ch = (2 * s + lh) ^ lsw;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) wf[a] = smem[stage * STG + ai[a] + ch];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) xf[b] = smem[stage * STG + bi[b] + ch];
+  };
+  f32x16 acc[2][2];
+  auto mma = [&](const uint4 (&wf)[2], const uint4 (&xf)[2]) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[a]), __builtin_bit_cast(bf16x8, xf[b]), acc[a][b], 0, 0, 0);
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= total) return;
+  setup(xcd_remap(tile, total), c_rx, c_si, c_mbase, c_nbase, c_W, c_xv, c_vm, c_wv);
+  reset_cursor();
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    if (st < nk) {
+#pragma unroll
+      for (int q = 0; q < NP; ++q) piece(st, q, c_rx, c_xv, c_vm, c_wv);
+      advance(c_W);
+    }
+  }
+  for (;;) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    uint4 wA[2], xA[2], wB[2], xB[2];
+    dma_wait_all();        // (the previous tile's epilogue stores share the counter and retire out of order with loads: wait for all)
+    __syncthreads();
+    load(0, 0, wA, xA);
+    int cur = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      const int nxt = (cur + 1 == NS) ? 0 : cur + 1;
+      load(cur, 1, wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wA, xA);
+      load(cur, 2, wA, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wB, xB);
+      load(cur, 3, wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wA, xA);
+      wait_tiles(kt + NS - 1 < nk);        // tile kt+1 has landed (this wave's pieces) ...
+      __syncthreads();                     // ... and everyone's; all fragment reads of tile kt are complete (in registers)
+      if (kt + NS < nk) {                  // refill the stage just drained with tile kt+NS
+#pragma unroll
+        for (int q = 0; q < NP; ++q) piece(cur, q, c_rx, c_xv, c_vm, c_wv);
+        advance(c_W);
+      }
+      load(nxt, 0, wA, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wB, xB);
+      cur = nxt;
+    }
+    {
+      load(cur, 1, wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wA, xA);
+      load(cur, 2, wA, xA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wB, xB);
+      load(cur, 3, wB, xB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wA, xA);
+      mma(wB, xB);
+    }
+    // ---- hand-over: every wave has its last fragments in registers -> both LDS stages are free for the next tile ----
+    const int e_si = c_si, e_mbase = c_mbase, e_nbase = c_nbase;
+    const int next = tile + (int)gridDim.x;
+    const bool has_next = next < total;
+    __syncthreads();
+    if (has_next) {
+      setup(xcd_remap(next, total), c_rx, c_si, c_mbase, c_nbase, c_W, c_xv, c_vm, c_wv);
+      reset_cursor();
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        if (st < nk) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) piece(st, q, c_rx, c_xv, c_vm, c_wv);
+          advance(c_W);
+        }
+      }
+    }
+    // ---- epilogue of the finished tile (its stores overlap the fetch just issued) ----
+    {
+      const SegD sg = p.seg[e_si];
+      const int HoWo = sg.Ho * sg.Wo;
+      long long orow[2]; float rsv[2]; bool mok[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int m = e_mbase + wm * 64 + b * 32 + l31;
+        mok[b] = m < sg.M;
+        const int mm = mok[b] ? m : 0;
+        const int bimg = mm / HoWo, pix = mm - bimg * HoWo;
+        orow[b] = sg.out_off + (long long)bimg * sg.out_bs + (long long)pix * p.ldy;
+        rsv[b] = p.rowscale ? p.rowscale[bimg] : 1.0f;
+      }
+      const int nw0 = e_nbase + wn * 64;
+      // wide path: whole 8-channel runs inside Cout, bf16 output, 16-byte aligned rows
+      const bool wide_ok = p.vec_ok && !p.out_f32 && !p.z && (p.ldy % 8 == 0) && (sg.out_off % 8 == 0) && (sg.out_bs % 8 == 0) && (nw0 + 64 <= p.Cout) &&
+                           (p.res_mode == EFFDET_RES_NONE || p.res_mode == EFFDET_RES_RELU_MASK);
+      // ReLU-mask residual of the wide path (the head's data-gradient convs): read as 16 bytes per lane in the POST-swap
+      // layout -- the same 8 consecutive channels the lane stores -- all 8 loads of the tile issued up front, and applied to
+      // the packed bf16 pairs with integer ops (res > 0  <=>  magnitude bits != 0 and sign bit clear: exact)
+      const bool res_wide = wide_ok && p.res_mode == EFFDET_RES_RELU_MASK;
+      uint4 rr[2][2][2];
+      if (res_wide) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              rr[a][h][b] = mok[b] ? *(const uint4*)((const bf16_t*)p.res + orow[b] + nw0 + a * 32 + h * 16 + lh * 8) : make_uint4(0u, 0u, 0u, 0u);
+      }
+      auto relu_mask2 = [](unsigned v, unsigned r) -> unsigned {      // two packed bf16: keep v's half where r's half > 0
+        const unsigned lo = ((r & 0x7fffu) != 0u && !(r & 0x8000u)) ? 0x0000ffffu : 0u;
+        const unsigned hi = ((r & 0x7fff0000u) != 0u && !(r & 0x80000000u)) ? 0xffff0000u : 0u;
+        return v & (lo | hi);
+      };
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {            // group pair (2h, 2h+1) of MFMA tile row a: 16 consecutive channels across the two lane halves
+        const int a = i >> 1, h = i & 1;
+        __builtin_amdgcn_sched_barrier(0);     // (keeps hipcc from hoisting every pair's loads: the kernel lives in 128 VGPRs)
+        uint2 pk[2][2];                         // [g in pair][b] packed bf16 x4
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * h + gg;
+          const int n0 = nw0 + a * 32 + g * 8 + lh * 4;
+          f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (n0 + 3 < p.Cout) {
+            if (p.scale) sc = *(const f32x4*)(p.scale + n0);
+            if (p.shift) sh = *(const f32x4*)(p.shift + n0);
+          } else {
+            for (int r = 0; r < 4; ++r)
+              if (n0 + r < p.Cout) { if (p.scale) sc[r] = p.scale[n0 + r]; if (p.shift) sh[r] = p.shift[n0 + r]; }
+          }
+          const bool full = p.vec_ok && (n0 + 3 < p.Cout);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            f32x4 v;
+            if (g == 0) v = f32x4{acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            else if (g == 1) v = f32x4{acc[a][b][4], acc[a][b][5], acc[a][b][6], acc[a][b][7]};
+            else if (g == 2) v = f32x4{acc[a][b][8], acc[a][b][9], acc[a][b][10], acc[a][b][11]};
+            else v = f32x4{acc[a][b][12], acc[a][b][13], acc[a][b][14], acc[a][b][15]};
+            v = v * sc + sh;
+            const long long o = orow[b] + n0;
+            const bool live = mok[b] && n0 < p.Cout;
+            if (p.z && live) {
+              if (full) store4((bf16_t*)p.z + o, v);
+              else
+                for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<bf16_t>::st((bf16_t*)p.z + o + r, v[r]);
+            }
+            if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+            else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+            if (p.rowscale) v *= rsv[b];
+            if (p.res_mode != EFFDET_RES_NONE && live && !res_wide) {
+              f32x4 q;
+              if (full) q = load4((const bf16_t*)p.res + o);
+              else
+                for (int r = 0; r < 4; ++r) q[r] = (n0 + r < p.Cout) ? Elem<bf16_t>::ld((const bf16_t*)p.res + o + r) : 0.f;
+              if (p.res_mode == EFFDET_RES_ADD) { v += q; }
+              else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
+              else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
+            }
+            pk[gg][b] = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            if (!wide_ok && live) {
+              if (p.out_f32) {
+                if (full) store4((float*)p.y + o, v);
+                else
+                  for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) ((float*)p.y)[o + r] = v[r];
+              } else {
+                if (full) store4((bf16_t*)p.y + o, v);
+                else
+                  for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<bf16_t>::st((bf16_t*)p.y + o + r, v[r]);
+              }
+            }
+          }
+        }
+        if (wide_ok) {
+          // lanes < 32 end up with channels 16h + 0..7, lanes >= 32 with 16h + 8..15 of their pixel: one 16-byte store
+          const int nq = nw0 + a * 32 + h * 16 + lh * 8;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            auto sx = __builtin_amdgcn_permlane32_swap(pk[0][b].x, pk[1][b].x, false, false);
+            auto sy = __builtin_amdgcn_permlane32_swap(pk[0][b].y, pk[1][b].y, false, false);
+            uint4 o4 = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+            if (res_wide) {
+              const uint4 r4 = rr[a][h][b];
+              o4 = make_uint4(relu_mask2(o4.x, r4.x), relu_mask2(o4.y, r4.y), relu_mask2(o4.z, r4.z), relu_mask2(o4.w, r4.w));
+            }
+            if (mok[b]) *(uint4*)((bf16_t*)p.y + orow[b] + nq) = o4;
+          }
+        }
+      }
+    }
+    if (!has_next) break;
+    tile = next;
+  }
+}
+
+// tile_start of every segment in units of BM-row tiles; returns the total
+static int retile(ConvK& k, int bm) {
+  int tiles = 0;
+  for (int s = 0; s < k.nseg; ++s) { k.seg[s].tile_start = tiles; tiles += (k.seg[s].M + bm - 1) / bm; }
+  for (int s = k.nseg; s < EFFDET_MAX_SEG; ++s) k.seg[s].tile_start = 0x7fffffff;
+  k.mtiles = tiles;
+  return tiles;
+}
+
+template <int WM, int WN, int NS>
+int launch_pers(ConvK& k, hipStream_t st) {
+  constexpr int TM = 64 * WM, TN = 64 * WN;
+  retile(k, TM);
+  k.ntiles = (k.Cout + TN - 1) / TN;
+  const size_t lds = (size_t)NS * (TM + TN) * 128;
+  EFFDET_SET_MAX_LDS((conv_igemm_pers_kernel<WM, WN, NS>), lds);
+  static int ncu = 0;                                   // CUs of the current device (all devices of a node are alike)
+  if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+  const int total = k.mtiles * k.ntiles;
+  const int grid = total < ncu ? total : ncu;          // one workgroup per CU (the LDS footprint allows no second one)
+  hipLaunchKernelGGL((conv_igemm_pers_kernel<WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+// Tuning knobs (effdet_tuning_set; A/B experiments and tests): which persistent big-tile shape serves an eligible conv
+// (0 = off | 1 = 442 | 242 | 243 | 423; env EFFDET_IGEMM_BIG overrides the built-in default), from how many output pixels
+// per launch, and its K walk.  Speed only: every setting computes the same values.
+static int g_tuning[EFFDET_TUNE_COUNT] = {-1, 16384, 0, 1};
+static int big_variant() {
+  if (g_tuning[EFFDET_TUNE_IGEMM_BIG] < 0)
+    g_tuning[EFFDET_TUNE_IGEMM_BIG] = getenv("EFFDET_IGEMM_BIG") ? atoi(getenv("EFFDET_IGEMM_BIG")) : EFFDET_IGEMM_BIG_DEFAULT;
+  return g_tuning[EFFDET_TUNE_IGEMM_BIG];
+}
+
 template <typename T, int BN, int WAVES_N, int NWAVES>
 int launch(const ConvK& k, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);                     // double-buffered operand tiles
@@ -305,7 +701,18 @@ int dispatch(ConvK& k, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
+extern "C" int effdet_tuning_set(int key, int value) {
+  if (key < 0 || key >= EFFDET_TUNE_COUNT) return EFFDET_EINVAL;
+  (void)big_variant();
+  const int old = g_tuning[key];
+  g_tuning[key] = value;
+  return old;
+}
+
+// Validates the descriptor, fills the kernel arguments and picks the kernel: -> EFFDET_E* (< 0), or the kernel id
+// 0..3 = conv_igemm_kernel with a 128 / 64 / 32 / 16-channel block tile, 10 + v = persistent big-tile variant v
+// (v = 442 | 242 | 243 | 423; 4420 / 4220 = their <= 128-channel forms).
+static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   if (!p || !p->x || !p->w || !p->y) return EFFDET_EINVAL;
   if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
   if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
@@ -313,13 +720,12 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   if (p->Cin % ce || p->ldx % ce || p->KH < 1 || p->KW < 1 || p->stride < 1) return EFFDET_EUNSUPPORTED;
   if (p->res_mode != EFFDET_RES_NONE && !p->res) return EFFDET_EINVAL;
   if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
-  ConvK k;
   k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res;
   k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
   k.ldx = p->ldx; k.ldy = p->ldy;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt;
-  k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32;
+  k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32; k.kord = g_tuning[EFFDET_TUNE_IGEMM_KORD];
   k.nseg = p->nseg;
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
@@ -348,6 +754,48 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   const long long wb = (long long)p->Cout * k.Kc * 16;
   if (wb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
   k.w_bytes = (unsigned)wb;
+  if (p->dtype == EFFDET_BF16 && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
+    long long mtot = 0;
+    bool fits = true;        // offsets + the tap walk's SGPR offset must stay below the 2-GiB sentinel
+    for (int s = 0; s < p->nseg; ++s) {
+      mtot += k.seg[s].M;
+      if ((long long)k.seg[s].x_bytes + 2LL * ((long long)p->KH * p->seg[s].W + p->KW) * p->ldx * 2 >= 0x70000000LL) fits = false;
+    }
+    if (fits && mtot >= g_tuning[EFFDET_TUNE_IGEMM_BIG_MIN_M]) {
+      const int v = big_variant();
+      if (v == 1) {
+        // measured on the RetinaHead shapes (tools/kbench2.py, B = 32 @512): the persistent 256x256 kernel wins where the K
+        // loop is long enough to amortise its exposed epilogue -- tower forward 885 vs 797 TFLOP/s, d(cls) data gradient
+        // 1005-1036 vs 957 -- and loses where the epilogue reads a residual behind a short K loop (tower data gradient
+        // 726 vs 866) or K is short (first tower layer 560 vs 658): those stay on the two-workgroups-per-CU kernel
+        const long long K = (long long)k.Kc * 8;
+        if (p->Cout >= 192 && mtot >= 65536 && ((p->res_mode == EFFDET_RES_NONE && K >= 2304) || K >= 4608)) return 10 + 442;
+      } else if (v == 442 || v == 242 || v == 243 || v == 423) {
+        return 10 + ((p->Cout > 128 || v == 423) ? v : (v == 243 ? 4230 : 4220));
+      }
+    }
+  }
+  return k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
+}
+
+extern "C" int effdet_conv2d_kernel(const effdet_conv_t* p) {
+  ConvK k;
+  return plan_conv(p, k);
+}
+
+extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
+  ConvK k;
+  const int id = plan_conv(p, k);
+  if (id < 0) return id;
   hipStream_t st = (hipStream_t)stream;
+  switch (id) {
+    case 10 + 442: return launch_pers<4, 4, 2>(k, st);
+    case 10 + 242: return launch_pers<2, 4, 2>(k, st);
+    case 10 + 243: return launch_pers<2, 4, 3>(k, st);
+    case 10 + 423: return launch_pers<4, 2, 3>(k, st);
+    case 10 + 4220: return launch_pers<4, 2, 2>(k, st);
+    case 10 + 4230: return launch_pers<4, 2, 3>(k, st);
+    default: break;
+  }
   return p->dtype == EFFDET_F32 ? dispatch<float>(k, st) : dispatch<bf16_t>(k, st);
 }

@@ -41,9 +41,13 @@ def _timed(name, flops, fn, note=''):
     return r
 
 
-def _igemm_symbol(dtype, cout):
-    bn = 128 if cout > 64 else 64 if cout > 32 else 32 if cout > 16 else 16
-    return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', bn)
+def _igemm_symbol(dtype, desc):
+    """Kernel symbol the library will launch for this descriptor (profiling attribution only)."""
+    kid = int(L.lib().effdet_conv2d_kernel(C.byref(desc)))
+    if kid >= 10:
+        v = str(kid - 10)
+        return 'conv_igemm_pers_kernel<%s,%s,%s>' % (v[0], v[1], v[2])
+    return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', (128, 64, 32, 16)[max(kid, 0)])
 
 
 class Map:
@@ -258,7 +262,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
     d.act, d.res_mode = act, res_mode
     _segs(d, xs, ys, base_x, base_y, isx, isy)
     flops = 2.0 * KH * KW * Cin * Cout * sum(y.B * y.H * y.W for y in ys)
-    _timed(_igemm_symbol(x0.dtype, Cout), flops,
+    _timed(_igemm_symbol(x0.dtype, d) if PROFILE is not None else '', flops,
            lambda: L.check(L.lib().effdet_conv2d(C.byref(d), L.stream_ptr()), 'effdet_conv2d'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
@@ -695,3 +699,8 @@ def head_out_bwd(dprob, prob, dreg, dtype):
     L.check(L.lib().effdet_head_out_bwd(L.ptr(dprob), L.ptr(prob), L.ptr(dreg), L.ptr(dl), L.ptr(dr), L.dtype_code(dtype),
                                         C.c_longlong(prob.numel()), C.c_longlong(dreg.numel()), L.stream_ptr()), 'effdet_head_out_bwd')
     return dl, dr
+
+
+def tuning_set(key, value):
+    """Kernel-selection knob of the library (speed only; see effdet_tuning_set in include/effdet_hip.h) -> previous value."""
+    return int(L.lib().effdet_tuning_set(int(key), int(value)))

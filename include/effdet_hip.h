@@ -65,6 +65,19 @@ typedef struct {
   effdet_seg_t seg[EFFDET_MAX_SEG];
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
+/* Which kernel effdet_conv2d would launch for this descriptor (no device work): a negative EFFDET_E* code, 0..3 = the
+ * implicit-GEMM kernel with a 128 / 64 / 32 / 16-channel block tile, >= 10 = 10 + the persistent big-tile variant. */
+int effdet_conv2d_kernel(const effdet_conv_t* p);
+
+/* Kernel-selection knobs (speed only -- every setting computes the same values; process-wide, meant for A/B runs and
+ * tests).  Returns the previous value, or EFFDET_EINVAL for an unknown key.
+ *   EFFDET_TUNE_IGEMM_BIG       : persistent big-tile bf16 implicit-GEMM (v_mfma_f32_32x32x16_bf16) for Cin % 64 == 0,
+ *                                 Cout >= 128 convs: 0 off | 1 = 442 (256x256 tile, 16 waves, 2 LDS stages) | 242 | 243 | 423
+ *                                 (waves along pixels, waves along channels, LDS stages)
+ *   EFFDET_TUNE_IGEMM_BIG_MIN_M : minimum output pixels per launch for that variant */
+enum { EFFDET_TUNE_IGEMM_BIG = 0, EFFDET_TUNE_IGEMM_BIG_MIN_M = 1, EFFDET_TUNE_RESERVED = 2,
+       EFFDET_TUNE_IGEMM_KORD = 3 /* K walk of the persistent variants: 0 tap-major, 1 channel-group-major */, EFFDET_TUNE_COUNT = 4 };
+int effdet_tuning_set(int key, int value);
 
 /* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]
  * (fp32, packed [Cout][KH*KW][Cin]; split-K partial slabs + a reduce pass, so levels / K-splits add up),

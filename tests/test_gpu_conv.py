@@ -75,6 +75,46 @@ def test_conv3x3_head_shapes(dtype):
     _run(dtype, 1, 2, 128, 64, 128, 3)
 
 
+@pytest.fixture
+def big_igemm():
+    """Route eligible bf16 convs (Cin % 64 == 0, Cout >= 128) through the big-tile 32x32x16 kernel regardless of size."""
+    from efficientdet.pytorch_amd import ops, _lib as L
+    old_min = ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, 0)
+    old = ops.tuning_set(L.TUNE_IGEMM_BIG, 0)
+
+    def use(variant):
+        ops.tuning_set(L.TUNE_IGEMM_BIG, variant)
+    yield use
+    ops.tuning_set(L.TUNE_IGEMM_BIG, old); ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, old_min)
+
+
+@pytest.mark.parametrize('variant', [442, 242, 243, 423])
+def test_conv_big_tile_variants(big_igemm, variant):
+    """The big-tile kernel (v_mfma_f32_32x32x16_bf16, scalar tap walk through the SGPR offset) == F.conv2d on the shapes it
+    serves: head towers / retina_cls (+ their data gradients), partial M and N tiles, borders, every fused epilogue."""
+    big_igemm(variant)
+    dt = torch.bfloat16
+    _run(dt, 2, 16, 16, 64, 256, 3, act=1)                          # tower layer 0 (one K-step per tap)
+    _run(dt, 1, 8, 8, 256, 256, 3, act=1)                           # tower (4 K-steps per tap)
+    _run(dt, 1, 8, 8, 256, 720, 3, act=3, out_f32=True)             # retina_cls + sigmoid, fp32 out, 3 n-tiles (last partial)
+    _run(dt, 3, 13, 9, 64, 200, 3, act=1, res=True)                 # ragged m tiles, H != W, partial n tile
+    _run(dt, 2, 20, 20, 768, 256, 3)                                # the d(cls logits) data gradient (Cin padded to 768)
+    _run(dt, 3, 4, 4, 256, 128, 3, act=2, bn=True, save_z=True)
+    _run(dt, 1, 64, 64, 64, 192, 3, rowscale=True)
+    _run(dt, 2, 24, 24, 128, 144, 1, pad=(0, 0, 0, 0), act=2, bn=True, save_z=True)    # pointwise
+    _run(dt, 1, 17, 17, 64, 128, 3, stride=2, pad=(0, 1, 0, 1), act=2, bn=True)        # TF-same stride 2 (asymmetric pad)
+    _run(dt, 2, 12, 12, 64, 160, 5, pad=(2, 2, 2, 2))                                  # 25 taps
+    _run(dt, 2, 1, 1, 64, 256, 3)                                                      # 1x1 map: 8 of 9 taps fall outside
+    _run(dt, 1, 2, 128, 64, 130, 3)                                                    # Cout % 4 != 0 tail
+
+
+@pytest.mark.parametrize('variant', [442, 243])
+def test_conv_big_tile_grouped_pyramid(big_igemm, variant):
+    big_igemm(variant)
+    _grouped(torch.bfloat16, Cin=64, nc=20)
+    _grouped(torch.bfloat16, Cin=256, nc=80, B=3)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_conv1x1_backbone_shapes(dtype):
     for (cin, cout) in [(16, 96), (96, 24), (144, 24), (24, 144), (240, 40), (40, 240), (480, 80), (672, 112),
@@ -94,10 +134,13 @@ def test_conv_odd_geometry(dtype):
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_conv_grouped_pyramid(dtype):
     """One launch over 5 levels with shared weights, outputs written into the [B, A, C] head layout."""
+    _grouped(dtype)
+
+
+def _grouped(dtype, Cin=64, nc=20, B=2):
     from efficientdet.pytorch_amd import ops
     from efficientdet.pytorch_amd.ops import Map
     g = torch.Generator().manual_seed(3)
-    B, Cin, nc = 2, 64, 20
     Cout = 9 * nc
     sizes = [16, 8, 4, 2, 1]
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24.0

@@ -75,3 +75,34 @@ def test_refuses_cpu_tensors():
     m.is_training = True
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         m([torch.zeros(1, 3, 128, 128), torch.zeros(1, 2, 5)])
+
+
+def test_conv_kernel_selection_rule():
+    """effdet_conv2d_kernel (no device work): the persistent 256x256 / 32x32x16 kernel serves the long-K head convs of the
+    benchmark shape, everything else stays on the 128x128 implicit-GEMM kernel (measured rule, csrc/conv_igemm.hip)."""
+    import ctypes as C
+    from efficientdet.pytorch_amd import _lib as L
+
+    def kid(dtype, B, cin, cout, res_mode=0, sizes=((64, 64), (32, 32), (16, 16), (8, 8), (4, 4)), k=3):
+        d = L.ConvDesc()
+        d.x = d.w = d.y = 0x1000
+        d.res = 0x1000 if res_mode else None
+        d.dtype, d.B, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = dtype, B, cin, cout, k, k, 1, k // 2, k // 2
+        d.ldx, d.ldy, d.res_mode, d.nseg = cin, cout, res_mode, len(sizes)
+        off_i = off_o = 0
+        for i, (h, w) in enumerate(sizes):
+            s = d.seg[i]
+            s.H = s.Ho = h; s.W = s.Wo = w
+            s.in_off, s.in_bstride, s.out_off, s.out_bstride = off_i, h * w * cin, off_o, h * w * cout
+            off_i += B * h * w * cin; off_o += B * h * w * cout
+        return int(L.lib().effdet_conv2d_kernel(C.byref(d)))
+    assert kid(L.BF16, 32, 256, 256) == 10 + 442                      # tower forward
+    assert kid(L.BF16, 32, 256, 720) == 10 + 442                      # retina_cls forward
+    assert kid(L.BF16, 32, 768, 256, res_mode=L.RES_RELU_MASK) == 10 + 442      # d(cls logits) data gradient (K = 6912)
+    assert kid(L.BF16, 32, 256, 256, res_mode=L.RES_RELU_MASK) == 0   # tower data gradient: residual behind a short K loop
+    assert kid(L.BF16, 32, 64, 256) == 0                              # first tower layer: K = 576
+    assert kid(L.BF16, 32, 256, 64) == 1 and kid(L.BF16, 32, 256, 36) == 1
+    assert kid(L.F32, 32, 256, 256) == 0                              # the parity dtype never takes the bf16 kernel
+    assert kid(L.BF16, 2, 256, 256) == 0                              # small launches: not enough tiles
+    assert kid(L.BF16, 32, 224, 224) == 0                             # D4 head: Cin % 64 != 0
+    assert kid(7, 32, 256, 256) == -1                                 # EFFDET_EINVAL
