@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='eager launches instead of replaying the captured hipGraph of the step (N=1)')
     ap.add_argument('--no-parity-mode', action='store_true', help='skip the fp32 (parity dtype) legs')
     ap.add_argument('--no-d4', action='store_true', help='skip configs[4] (D4 batch 8 @ 1024 inference)')
     ap.add_argument('--parity-steps', type=int, default=6)
@@ -177,9 +178,28 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     for _ in range(warmup):
         step()
     sync_all()
+    graphed = None
+    if world == 1 and not a.no_graph and not a.torch_optim:
+        # the SAME step (zero_grad, forward, loss, backward, clip + AdamW) captured once as a hipGraph and replayed: one
+        # hipGraphLaunch per step instead of ~560 launches through Python; every replay does the full work on the resident
+        # batch (fresh drop_connect masks from the device-side step counter, parameters updated in place)
+        from efficientdet.pytorch_amd.graph import GraphedTrainStep
+        try:
+            graphed = GraphedTrainStep(model, opt, img, ann, warmup=0)
+            for _ in range(2):
+                graphed()
+            sync_all()
+        except Exception as e:        # report and fall back to eager launches
+            sys.stderr.write('hipGraph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
+            graphed = None
     t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = step()
+    if graphed is not None:
+        for _ in range(steps):
+            cl_rl = graphed()
+        loss = cl_rl[0].mean() + cl_rl[1].mean()
+    else:
+        for _ in range(steps):
+            loss = step()
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -202,7 +222,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     final = float(loss.item())
     del opt, net, model
     torch.cuda.empty_cache()
-    return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img
+    return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img, graphed is not None
 
 
 def inference_leg(network, dtype, dev, img, reps=5):
@@ -246,7 +266,7 @@ def main():
     cfg = EFFICIENTDET[a.network]
     d0_512 = a.network == 'efficientdet-d0' and a.size == 512
 
-    value, ms_step, final_loss, roof, img = train_leg(a, a.dtype, a.steps, a.warmup, rank, world, local, dev, not a.no_roofline)
+    value, ms_step, final_loss, roof, img, graphed = train_leg(a, a.dtype, a.steps, a.warmup, rank, world, local, dev, not a.no_roofline)
     out = {
         'metric': 'images/sec EfficientDet-D0 512px fwd+bwd', 'value': round(value, 2), 'unit': 'images/sec', 'n_gpus': world,
         'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(ms_step, 3), 'higher_is_better': True, 'scaling': 'weak',
@@ -255,7 +275,7 @@ def main():
                                'synthetic COCO-shape targets, 80 classes, random-init, W_bifpn=%d D_bifpn=%d, drop_connect 0.2 active'
                                % (a.batch, a.size, a.size, cfg['W_bifpn'], cfg['D_bifpn']),
                    'network': a.network, 'global_batch': a.batch * world, 'image_size': a.size, 'parallelism': 'dp%d' % world,
-                   'final_loss': round(final_loss, 4)},
+                   'final_loss': round(final_loss, 4), 'launch': 'hipGraph replay (one graph launch per step)' if graphed else 'eager launches'},
         'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / ms_step, 2) if d0_512 else None,
     }
     if roof is not None:
@@ -264,7 +284,7 @@ def main():
     if world == 1 and a.dtype == 'bf16' and not a.no_parity_mode:
         # the SAME workload in the parity dtype: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), the mode that meets north_star's
         # 1e-3 gate against the reference (tests/test_gpu_model.py); its own roofline is priced against the fp32 MFMA peak
-        pv, pms, ploss, proof, _ = train_leg(a, 'f32', a.parity_steps, a.parity_warmup, rank, world, local, dev, not a.no_roofline)
+        pv, pms, ploss, proof, _, _ = train_leg(a, 'f32', a.parity_steps, a.parity_warmup, rank, world, local, dev, not a.no_roofline)
         out['parity_mode'] = {'dtype': 'f32', 'value': round(pv, 2), 'unit': 'images/sec', 'ms_per_step': round(pms, 3),
                               'steps': a.parity_steps, 'warmup': a.parity_warmup, 'final_loss': round(ploss, 4),
                               'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / pms, 2) if d0_512 else None,

@@ -27,17 +27,23 @@ __host__ __device__ inline u32x4s philox4x32_10(u32x4s c, unsigned k0, unsigned 
   return c;
 }
 
-// out[slot][b] = floor(keep[slot] + u) / keep[slot],  u = 24-bit uniform in [0,1) from Philox(seed; step, slot, b)
+// out[slot][b] = floor(keep[slot] + u) / keep[slot],  u = 24-bit uniform in [0,1) from Philox(seed; step, slot, b).
+// ONE workgroup: the step number may live on the device (step_dev: read by every thread, then advanced by thread 0 behind
+// a barrier), so that a captured hipGraph draws fresh masks on every replay.
 __global__ __launch_bounds__(256) void drop_connect_kernel(float* __restrict__ out, const float* __restrict__ keep, int nslot, int B,
-                                                           unsigned long long seed, unsigned long long step) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= nslot * B) return;
-  const int slot = i / B, b = i - slot * B;
-  const u32x4s r = philox4x32_10(u32x4s{(unsigned)b, (unsigned)slot, (unsigned)step, (unsigned)(step >> 32)}, (unsigned)seed,
-                                 (unsigned)(seed >> 32));
-  const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
-  const float kp = keep[slot];
-  out[i] = floorf(kp + u) / kp;
+                                                           unsigned long long seed, unsigned long long step_host,
+                                                           unsigned long long* __restrict__ step_dev) {
+  const unsigned long long step = step_dev ? *step_dev : step_host;
+  __syncthreads();
+  for (int i = threadIdx.x; i < nslot * B; i += 256) {
+    const int slot = i / B, b = i - slot * B;
+    const u32x4s r = philox4x32_10(u32x4s{(unsigned)b, (unsigned)slot, (unsigned)step, (unsigned)(step >> 32)}, (unsigned)seed,
+                                   (unsigned)(seed >> 32));
+    const float u = (float)(r.x >> 8) * (1.0f / 16777216.0f);
+    const float kp = keep[slot];
+    out[i] = floorf(kp + u) / kp;
+  }
+  if (step_dev && threadIdx.x == 0) *step_dev = step + 1;
 }
 
 // ------------------------------------------------------------------------------------------------ input pipeline
@@ -181,9 +187,9 @@ __global__ __launch_bounds__(256) void head_out_bwd_kernel(const float* __restri
 }  // namespace
 
 extern "C" int effdet_drop_connect_scales(float* out, const float* keep_prob, int nslot, int B, unsigned long long seed,
-                                          unsigned long long step, effdet_stream_t stream) {
+                                          unsigned long long step, unsigned long long* step_dev, effdet_stream_t stream) {
   if (!out || !keep_prob || nslot < 1 || B < 1) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(drop_connect_kernel, dim3((nslot * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, out, keep_prob, nslot, B, seed, step);
+  hipLaunchKernelGGL(drop_connect_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, keep_prob, nslot, B, seed, step, step_dev);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -391,7 +391,10 @@ class EfficientDet(nn.Module):
         tk = ('keep', str(device), bb.drop_connect_rate)
         if tk not in dc:
             dc[tk] = torch.tensor(keep, dtype=torch.float32, device=device)
-        rows = ops.drop_connect_scales(dc[tk], B, dc['seed'], dc['step'])
+        sk = ('step_dev', str(device))
+        if sk not in dc:                                         # the step counter lives on the device: graph replays advance it too
+            dc[sk] = torch.tensor([dc['step']], dtype=torch.int64, device=device)
+        rows = ops.drop_connect_scales(dc[tk], B, dc['seed'], 0, dc[sk])
         dc['step'] += 1
         return {i: rows[j] for j, i in enumerate(idx)}
 

@@ -1,0 +1,48 @@
+"""Whole-step hipGraph capture of the reference's training iteration (train.py:95-118: zero_grad -> forward -> loss ->
+backward -> clip -> optimizer.step) for fixed batch shapes.
+
+The eager step issues ~560 launches through Python + ctypes (host floor ~12 ms on D0 B=32); a captured step is ONE
+hipGraphLaunch.  Everything the step does is already capture-safe by construction: kernels never allocate or synchronise
+(include/effdet_hip.h), the per-step parameter repacks replay a recorded table, the drop_connect step counter and the AdamW
+step counters live on the device, and the gradient-pointer table is static inside the graph's private memory pool.
+
+    step = GraphedTrainStep(model, optimizer, images, annotations)       # warm-up + capture
+    for batch in loader:
+        step.images.copy_(batch_images); step.annotations.copy_(batch_annots)
+        cls_loss, reg_loss = step()                                       # device tensors, valid until the next call
+
+Single-process, single-GPU (DDP's bucket hooks are left to eager mode)."""
+import torch
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, images, annotations, warmup=3, clip_fn=None):
+        if not images.is_cuda:
+            raise RuntimeError('GraphedTrainStep needs GPU-resident batches')
+        self.model, self.optimizer = model, optimizer
+        self.images, self.annotations = images.clone(), annotations.clone()      # static input buffers of the graph
+        self.clip_fn = clip_fn                  # e.g. lambda: clip_grad_norm_(params, 0.1) for stock optimizers (ClipAdamW clips itself)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):           # warm-up on a side stream (records the ParamPrep table, sizes the zero pool)
+            for _ in range(warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._step()
+        torch.cuda.synchronize()
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        cl, rl = self.model([self.images, self.annotations])
+        (cl.mean() + rl.mean()).backward()
+        if self.clip_fn is not None:
+            self.clip_fn()
+        self.optimizer.step()
+        return cl, rl
+
+    def __call__(self):
+        self.graph.replay()
+        return self.losses

@@ -650,12 +650,13 @@ def pad_rows(src_map, cpad):
 
 
 # ----------------------------------------------------------------------------- boundary kernels (csrc/pipeline.hip)
-def drop_connect_scales(keep_dev, B, seed, step):
-    """-> [nslot, B] fp32 rows of floor(keep + u)/keep (models/utils.py:79-90), one launch for every skip block of a step."""
+def drop_connect_scales(keep_dev, B, seed, step, step_dev=None):
+    """-> [nslot, B] fp32 rows of floor(keep + u)/keep (models/utils.py:79-90), one launch for every skip block of a step.
+    step_dev (int64 device tensor [1]): the step counter lives on the device and is advanced by the kernel (hipGraph replay)."""
     n = keep_dev.numel()
     out = torch.empty((n, B), dtype=torch.float32, device=keep_dev.device)
     L.check(L.lib().effdet_drop_connect_scales(L.ptr(out), L.ptr(keep_dev), n, B, C.c_ulonglong(seed & (2 ** 64 - 1)),
-                                               C.c_ulonglong(step), L.stream_ptr()), 'effdet_drop_connect_scales')
+                                               C.c_ulonglong(step), L.ptr(step_dev), L.stream_ptr()), 'effdet_drop_connect_scales')
     return out
 
 

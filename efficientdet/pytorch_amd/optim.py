@@ -118,14 +118,21 @@ class ClipAdamW(torch.optim.Optimizer):
                 gr = gr.float().contiguous(); p.grad = gr
             ptrs.append(gr.data_ptr())
         if ptrs != t['g_last']:                                        # (DDP bucket views keep their addresses: no upload)
-            slot = t['g_slot']; t['g_slot'] = slot ^ 1
-            if t['g_evt'][slot] is not None:
-                t['g_evt'][slot].synchronize()                         # the copy that last read this pinned slot has finished
-            t['g_host'][slot].copy_(torch.tensor(ptrs, dtype=torch.int64))
-            t['g_ptr'].copy_(t['g_host'][slot], non_blocking=True)
-            ev = torch.cuda.Event(); ev.record()
-            t['g_evt'][slot] = ev
-            t['g_last'] = ptrs
+            if torch.cuda.is_current_stream_capturing():
+                # hipGraph capture: the memcpy node keeps reading this pinned buffer on every replay, so it gets a buffer of
+                # its own that is never rewritten (gradient addresses are static inside the graph's memory pool)
+                t['g_graph_host'] = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+                t['g_ptr'].copy_(t['g_graph_host'], non_blocking=True)
+                t['g_last'] = None                                     # eager steps after the capture upload again
+            else:
+                slot = t['g_slot']; t['g_slot'] = slot ^ 1
+                if t['g_evt'][slot] is not None:
+                    t['g_evt'][slot].synchronize()                     # the copy that last read this pinned slot has finished
+                t['g_host'][slot].copy_(torch.tensor(ptrs, dtype=torch.int64))
+                t['g_ptr'].copy_(t['g_host'][slot], non_blocking=True)
+                ev = torch.cuda.Event(); ev.record()
+                t['g_evt'][slot] = ev
+                t['g_last'] = ptrs
         self._step += 1
         b1, b2 = g['betas']
         L.check(L.lib().effdet_clip_adamw_step(L.ptr(t['p_ptr']), L.ptr(t['g_ptr']), L.ptr(t['m_ptr']), L.ptr(t['v_ptr']), L.ptr(t['numel']),

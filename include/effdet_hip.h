@@ -344,10 +344,12 @@ int effdet_nchw_f32_to_nhwc(const float* x, void* y, int dtype, int B, int H, in
  *   out[slot][b] = floor(keep_prob[slot] + u) / keep_prob[slot],  u = (x >> 8) * 2^-24 with x = word 0 of
  *   Philox4x32-10(counter = {b, slot, step_lo, step_hi}, key = {seed_lo, seed_hi}).  One launch per step for all slots;
  *   the result is the `rowscale` of the block's project conv (forward) and of its dz (backward).
+ *   step_dev != NULL: the step number is read from that device word and advanced by the kernel (a captured hipGraph
+ *   then draws fresh masks on every replay); NULL: `step` is used.
  *   effdet_philox4x32_10 is the HOST twin of the generator (pure function, no device work; tests pin the stream on it).
  * ------------------------------------------------------------------------------------------- */
 int effdet_drop_connect_scales(float* out, const float* keep_prob, int nslot, int B, unsigned long long seed,
-                               unsigned long long step, effdet_stream_t stream);
+                               unsigned long long step, unsigned long long* step_dev, effdet_stream_t stream);
 void effdet_philox4x32_10(const unsigned ctr[4], const unsigned key[2], unsigned out[4]);
 
 /* Device-side input pipeline (datasets/augmentation.py:69-150: Normalizer -> Augmenter -> Resizer -> collater):
