@@ -185,7 +185,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
         # batch (fresh drop_connect masks from the device-side step counter, parameters updated in place)
         from efficientdet.pytorch_amd.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(model, opt, img, ann, warmup=0)
+            graphed = GraphedTrainStep(model, opt, img, ann, warmup=2)
             for _ in range(2):
                 graphed()
             sync_all()

@@ -16,7 +16,7 @@ import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, images, annotations, warmup=3, clip_fn=None):
+    def __init__(self, model, optimizer, images, annotations, warmup=2, clip_fn=None):
         if not images.is_cuda:
             raise RuntimeError('GraphedTrainStep needs GPU-resident batches')
         self.model, self.optimizer = model, optimizer
@@ -24,9 +24,9 @@ class GraphedTrainStep:
         self.clip_fn = clip_fn                  # e.g. lambda: clip_grad_norm_(params, 0.1) for stock optimizers (ClipAdamW clips itself)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up on a side stream (records the ParamPrep table, sizes the zero pool)
-            for _ in range(warmup):
-                self._step()
+        with torch.cuda.stream(side):           # warm-up on a side stream: records the ParamPrep table, sizes the zero pool, and
+            for _ in range(max(1, warmup)):     # (re)creates the AccumulateGrad nodes off the legacy default stream, which a
+                self._step()                    # capture must not touch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()

@@ -59,6 +59,8 @@ class ClipAdamW(torch.optim.Optimizer):
             # pinned staging ring for the gradient-pointer upload: a slot is rewritten only after the event recorded behind
             # its previous H2D copy has completed (the host may run a step ahead of the stream)
             'g_host': [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)], 'g_evt': [None, None], 'g_slot': 0,
+            'g_graph_host': torch.zeros(n, dtype=torch.int64).pin_memory(),      # source of the memcpy node of a captured step
+
             'g_last': None,
             'scratch': torch.zeros(64 + nb, dtype=torch.float32, device=dev), 'offs': offs,
             'steps': torch.zeros(n, dtype=torch.int32, device=dev), 'p_sig': [p.data_ptr() for p in ps],
@@ -120,8 +122,8 @@ class ClipAdamW(torch.optim.Optimizer):
         if ptrs != t['g_last']:                                        # (DDP bucket views keep their addresses: no upload)
             if torch.cuda.is_current_stream_capturing():
                 # hipGraph capture: the memcpy node keeps reading this pinned buffer on every replay, so it gets a buffer of
-                # its own that is never rewritten (gradient addresses are static inside the graph's memory pool)
-                t['g_graph_host'] = torch.tensor(ptrs, dtype=torch.int64).pin_memory()
+                # its own that is not rewritten by eager steps (gradient addresses are static inside the graph's memory pool)
+                t['g_graph_host'].copy_(torch.tensor(ptrs, dtype=torch.int64))      # (allocated in _build: no pinned allocation under capture)
                 t['g_ptr'].copy_(t['g_graph_host'], non_blocking=True)
                 t['g_last'] = None                                     # eager steps after the capture upload again
             else:

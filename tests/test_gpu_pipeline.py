@@ -297,21 +297,23 @@ def test_graphed_train_step_tracks_eager():
             (cl.mean() + rl.mean()).backward()
             opt.step()
             return cl, rl
-        for _ in range(3):
+        for _ in range(2):
             cl, rl = step(); losses.append(float(cl) + float(rl))
         if mode == 'graph':
-            g = GraphedTrainStep(m, opt, img, ann, warmup=0)
+            g = GraphedTrainStep(m, opt, img, ann, warmup=1)         # one more (untracked-loss) step on the capture side stream
+            losses.append(losses[-1])
             for _ in range(3):
                 cl, rl = g(); losses.append(float(cl) + float(rl))
         else:
-            for _ in range(3):
+            for _ in range(4):
                 cl, rl = step(); losses.append(float(cl) + float(rl))
         torch.cuda.synchronize()
         runs[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu())
     le, lg = runs['eager'][0], runs['graph'][0]
     assert all(np.isfinite(le)) and all(np.isfinite(lg))
-    for a, b in zip(le, lg):
-        assert abs(a - b) <= 2e-2 * abs(a), (le, lg)
+    for i, (a, b) in enumerate(zip(le, lg)):
+        if i != 2:                                                  # (index 2 = the warm-up step inside the constructor)
+            assert abs(a - b) <= 2e-2 * abs(a), (le, lg)
     assert len(set(lg[3:])) == 3                                    # replays do real, different steps
     d = (runs['eager'][1] - runs['graph'][1]).abs()
     assert float(d.mean()) < 0.5 * lr and float(d.max()) <= 6 * 2 * lr + 1e-6, (float(d.mean()), float(d.max()))
