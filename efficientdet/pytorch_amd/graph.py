@@ -11,7 +11,9 @@ step counters live on the device, and the gradient-pointer table is static insid
         step.images.copy_(batch_images); step.annotations.copy_(batch_annots)
         cls_loss, reg_loss = step()                                       # device tensors, valid until the next call
 
-Single-process, single-GPU (DDP's bucket hooks are left to eager mode)."""
+Single-process, single-GPU (DDP's bucket hooks are left to eager mode).  Drop every reference to losses of earlier EAGER steps
+before constructing this (a live loss keeps that step's autograd graph and its default-stream AccumulateGrad nodes alive, which
+a capture on another stream must not touch)."""
 import torch
 
 

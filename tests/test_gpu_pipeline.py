@@ -299,6 +299,7 @@ def test_graphed_train_step_tracks_eager():
             return cl, rl
         for _ in range(2):
             cl, rl = step(); losses.append(float(cl) + float(rl))
+        del cl, rl             # (a live loss keeps the eager autograd graph -- and its default-stream AccumulateGrad nodes -- alive)
         if mode == 'graph':
             g = GraphedTrainStep(m, opt, img, ann, warmup=1)         # one more (untracked-loss) step on the capture side stream
             losses.append(losses[-1])
