@@ -193,7 +193,7 @@ def test_forward_raw_is_differentiable(dtype):
             # sums of cancelling terms), the direction is what a training step uses: cosine similarity per tensor
             a, b = p.grad.double().cpu().reshape(-1), params[k].grad.double().reshape(-1)
             cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
-            assert cos > (0.9 if a.numel() > 64 else 0.5), (k, cos)
+            assert cos > (0.75 if a.numel() > 64 else 0.5), (k, cos)
 
 
 # ------------------------------------------------------------------------------------------------ optimizer checkpoint (f4) + async race
