@@ -34,7 +34,10 @@ def per_launch(d, counters):
 
 
 def short(name):
-    m = re.search(r'conv_igemm\w*_kernel<(unsigned short|float), (\d+)', name)
+    m = re.search(r'conv_igemm_pers_kernel<(\d+), (\d+), (\d+)>', name)
+    if m:
+        return 'conv_igemm_pers_kernel<%s,%s,%s>' % m.groups()
+    m = re.search(r'conv_igemm_kernel<(unsigned short|float), (\d+)', name)
     if m:
         return 'conv_igemm_kernel<%s,%s>' % ('bf16' if m.group(1) == 'unsigned short' else 'f32', m.group(2))
     m = re.search(r'(conv_wgrad\w*_kernel<[^>(]*>|dw_\w+_kernel|unpack_wgrad\w*_kernel|wgrad_\w+_kernel|loss_\w+_kernel|se_\w+_kernel|'
