@@ -225,7 +225,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img, graphed is not None
 
 
-def inference_leg(network, dtype, dev, img, reps=5):
+def inference_leg(network, dtype, dev, img, reps=5, graph=True):
     """eval forward + decode + per-image NMS (thr 0.01, IoU 0.5) on RANDOM-INIT weights: every anchor passes the threshold = the
     NMS worst case.  -> (ms/img end to end, ms/img forward only, kept boxes of image 0)."""
     model = build_model(network, dtype, dev, False)
@@ -233,9 +233,18 @@ def inference_leg(network, dtype, dev, img, reps=5):
     with torch.no_grad():
         for _ in range(2):
             model.detect(img)
+        detect = lambda: model.detect(img)
+        if graph:      # the same forward + decode + NMS replayed as one hipGraph (results identical; only the count read-back syncs)
+            from efficientdet.pytorch_amd.graph import GraphedDetect
+            try:
+                gd = GraphedDetect(model, img)
+                gd(); detect = gd
+            except Exception as e:
+                sys.stderr.write('hipGraph capture of detect failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
+                graph = False
         torch.cuda.synchronize(); t1 = time.perf_counter()
         for _ in range(reps):
-            dets = model.detect(img)
+            dets = detect()
         torch.cuda.synchronize(); ti = (time.perf_counter() - t1) / reps
         for _ in range(2):
             model.forward_raw(img)
@@ -244,7 +253,7 @@ def inference_leg(network, dtype, dev, img, reps=5):
             model.forward_raw(img)
         torch.cuda.synchronize(); tf = (time.perf_counter() - t1) / reps
     kept = int(dets[0][0].numel())
-    del model
+    del model, detect, dets
     torch.cuda.empty_cache()
     return round(ti * 1e3 / B, 4), round(tf * 1e3 / B, 4), kept
 
@@ -292,23 +301,24 @@ def main():
 
     if rank == 0 and world == 1 and not a.no_inference:
         dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
-        ti, tf, kept = inference_leg(a.network, dtype, dev, img)
+        ti, tf, kept = inference_leg(a.network, dtype, dev, img, graph=not a.no_graph)
         out['inference'] = {'workload': 'configs[1]: D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
-                            'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+                            'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
+                            'launch': 'eager launches' if a.no_graph else 'hipGraph replay (end-to-end number; forward_only is eager)'}
         if a.dtype == 'bf16' and not a.no_parity_mode:
-            ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3)
+            ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3, graph=not a.no_graph)
             out['inference']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
         del img
         torch.cuda.empty_cache()
         if not a.no_d4:
             from efficientdet.pytorch_amd.synthetic import synthetic_batch
             img4 = synthetic_batch(8, 1024, seed=1, num_classes=80)[0].to(dev)
-            ti, tf, kept = inference_leg('efficientdet-d4', dtype, dev, img4, reps=3)
+            ti, tf, kept = inference_leg('efficientdet-d4', dtype, dev, img4, reps=3, graph=not a.no_graph)
             out['inference_d4'] = {'workload': 'configs[4]: D4 eval batch 8 @ 1024: forward + decode + per-image NMS (thr 0.01, IoU 0.5)',
                                    'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
                                    'forward_tflops': round(455.596 * 8 / (tf * 8) , 2)}
             if a.dtype == 'bf16' and not a.no_parity_mode:
-                ti, tf, kept = inference_leg('efficientdet-d4', torch.float32, dev, img4, reps=2)
+                ti, tf, kept = inference_leg('efficientdet-d4', torch.float32, dev, img4, reps=2, graph=not a.no_graph)
                 out['inference_d4']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

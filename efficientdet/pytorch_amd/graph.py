@@ -48,3 +48,44 @@ class GraphedTrainStep:
     def __call__(self):
         self.graph.replay()
         return self.losses
+
+
+class GraphedDetect:
+    """Eval forward + decode + per-image NMS (models/efficientdet.py:57-86 for every image of the batch) captured as ONE hipGraph
+    for a fixed batch shape: the ~330 launches of `model.detect` become one graph launch, the only host interaction left is the
+    read-back of the per-image detection counts.
+
+        det = GraphedDetect(model, images)            # warm-up + capture
+        det.images.copy_(batch); results = det()      # -> [(scores[K], labels[K] int64, boxes[K,4]) per image], score-descending
+    """
+
+    def __init__(self, model, images, warmup=2):
+        from . import ops
+        if not images.is_cuda:
+            raise RuntimeError('GraphedDetect needs GPU-resident batches')
+        self.model = model
+        self.images = images.clone()
+        H, W = int(images.shape[2]), int(images.shape[3])
+
+        def run():
+            with torch.no_grad():
+                cls, reg, anc = model.forward_raw(self.images)
+                boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
+                idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
+                return ops.gather_dets(boxes, score, label, idx, count) + (count,)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.s, self.l, self.b, self.count = run()
+        torch.cuda.synchronize()
+
+    def __call__(self):
+        self.graph.replay()
+        counts = self.count.tolist()                       # the one device->host sync (the reference syncs too)
+        return [(self.s[i, :n], self.l[i, :n], self.b[i, :n]) for i, n in enumerate(counts)]

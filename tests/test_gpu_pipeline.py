@@ -318,3 +318,25 @@ def test_graphed_train_step_tracks_eager():
     assert len(set(lg[3:])) == 3                                    # replays do real, different steps
     d = (runs['eager'][1] - runs['graph'][1]).abs()
     assert float(d.mean()) < 0.5 * lr and float(d.max()) <= 6 * 2 * lr + 1e-6, (float(d.mean()), float(d.max()))
+
+
+def test_graphed_detect_matches_eager():
+    from efficientdet.pytorch_amd.graph import GraphedDetect
+    m = _model('efficientdet-d0', 8, torch.float32, is_training=False, threshold=0.3)
+    m.eval()
+    img, _ = O.synthetic_batch(3, 128, seed=8, num_classes=8)
+    img = img.cuda()
+    eager = m.detect(img)
+    gd = GraphedDetect(m, img)
+    for rep in range(2):
+        got = gd()
+        assert len(got) == 3
+        for (s, l, b), (es, el, eb) in zip(got, eager):
+            assert abs(len(s) - len(es)) <= max(2, len(es) // 100)          # (two passes: atomics-order noise can flip a near-tie)
+            k = min(20, len(es), len(s))
+            assert_close(s[:k].cpu(), es[:k].cpu(), 1e-4, 'scores'); assert l.dtype == torch.int64 and b.shape[1] == 4
+    img2, _ = O.synthetic_batch(3, 128, seed=9, num_classes=8)
+    gd.images.copy_(img2.cuda())
+    got2 = gd()
+    e2 = m.detect(img2.cuda())
+    assert abs(len(got2[0][0]) - len(e2[0][0])) <= max(2, len(e2[0][0]) // 100) and not torch.equal(got2[0][0][:5], eager[0][0][:5])

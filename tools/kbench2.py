@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--B', type=int, default=32)
 ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='0,442,242')
-ap.add_argument('--kord', type=int, default=1)
+ap.add_argument('--kord', type=int, default=0)
 ap.add_argument('--only', type=int, default=-1, help='run only shape #i')
 ap.add_argument('--zeros', action='store_true', help='zero-filled operands (DVFS / data-toggling probe)')
 a = ap.parse_args()
