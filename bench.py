@@ -234,7 +234,7 @@ def inference_leg(network, dtype, dev, img, reps=5, graph=True):
         for _ in range(2):
             model.detect(img)
         detect = lambda: model.detect(img)
-        if graph:      # the same forward + decode + NMS replayed as one hipGraph (results identical; only the count read-back syncs)
+        if graph:      # the same forward + decode replayed as one hipGraph, NMS + gather launched eagerly behind it
             from efficientdet.pytorch_amd.graph import GraphedDetect
             try:
                 gd = GraphedDetect(model, img)
@@ -304,7 +304,7 @@ def main():
         ti, tf, kept = inference_leg(a.network, dtype, dev, img, graph=not a.no_graph)
         out['inference'] = {'workload': 'configs[1]: D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
                             'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
-                            'launch': 'eager launches' if a.no_graph else 'hipGraph replay (end-to-end number; forward_only is eager)'}
+                            'launch': 'eager launches' if a.no_graph else 'forward + decode as one hipGraph replay, NMS eager (end-to-end number; forward_only is eager)'}
         if a.dtype == 'bf16' and not a.no_parity_mode:
             ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3, graph=not a.no_graph)
             out['inference']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}

@@ -51,9 +51,10 @@ class GraphedTrainStep:
 
 
 class GraphedDetect:
-    """Eval forward + decode + per-image NMS (models/efficientdet.py:57-86 for every image of the batch) captured as ONE hipGraph
-    for a fixed batch shape: the ~330 launches of `model.detect` become one graph launch, the only host interaction left is the
-    read-back of the per-image detection counts.
+    """Eval forward + decode (models/efficientdet.py:57-72 for every image of the batch) captured as ONE hipGraph for a fixed
+    batch shape -- the ~270 launches of the network become one graph launch -- followed by the on-device NMS + gather launched
+    eagerly.  (The NMS's radix sort is rocPRIM's: its host side stages launch parameters that do not survive a graph replay --
+    the second replay of a captured rocprim::radix_sort_pairs faults -- so the ~60 NMS launches stay outside the graph.)
 
         det = GraphedDetect(model, images)            # warm-up + capture
         det.images.copy_(batch); results = det()      # -> [(scores[K], labels[K] int64, boxes[K,4]) per image], score-descending
@@ -63,16 +64,14 @@ class GraphedDetect:
         from . import ops
         if not images.is_cuda:
             raise RuntimeError('GraphedDetect needs GPU-resident batches')
-        self.model = model
+        self.model, self.ops = model, ops
         self.images = images.clone()
         H, W = int(images.shape[2]), int(images.shape[3])
 
         def run():
             with torch.no_grad():
                 cls, reg, anc = model.forward_raw(self.images)
-                boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
-                idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
-                return ops.gather_dets(boxes, score, label, idx, count) + (count,)
+                return ops.decode_score(anc, reg, cls, H, W)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -82,10 +81,13 @@ class GraphedDetect:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.s, self.l, self.b, self.count = run()
+            self.boxes, self.score, self.label = run()
         torch.cuda.synchronize()
 
     def __call__(self):
+        ops, m = self.ops, self.model
         self.graph.replay()
-        counts = self.count.tolist()                       # the one device->host sync (the reference syncs too)
-        return [(self.s[i, :n], self.l[i, :n], self.b[i, :n]) for i, n in enumerate(counts)]
+        idx, count = ops.nms(self.boxes, self.score, float(m.threshold), float(m.iou_threshold))
+        s, l, b = ops.gather_dets(self.boxes, self.score, self.label, idx, count)
+        counts = count.tolist()                            # the one device->host sync (the reference syncs too)
+        return [(s[i, :n], l[i, :n], b[i, :n]) for i, n in enumerate(counts)]
