@@ -21,6 +21,7 @@
 //   * the bias gradient rides along as one extra MFMA per dz fragment against an all-ones
 //     operand (blocks of j-tile 0 only).
 #include "common.h"
+#include <stdlib.h>
 
 #ifndef EFFDET_WGRAD_TR_WAVES
 #define EFFDET_WGRAD_TR_WAVES 8
@@ -468,6 +469,171 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fp32 (parity dtype) fast path: direct-to-LDS DMA staging and NO transposition at all.
+//
+// v_mfma_f32_16x16x4_f32 wants, per lane (r = l & 15, k = l >> 4), ONE value A[row r][k] -- here dz[pixel k][channel] --
+// so the NHWC image [pixel][channel] is already the operand layout: lane (r, k) reads 16 bytes = channels 4r .. 4r+3 of pixel
+// k0 + k with one ds_read_b128 (a 16-lane service group reads 256 contiguous bytes of one pixel row: all 64 banks, no
+// conflicts) and uses the four dwords as the A operands of FOUR MFMA tiles whose row r stands for channel 4r + j
+// (j = 0..3; which channel an MFMA row means is ours to choose, the epilogue applies the same map).  The x operand likewise.
+// One 4-pixel k-step of a 64x32 wave tile (8 waves) = 2 LDS reads for 8 MFMAs of 32 cycles, fragments read one k-step ahead.
+// Measured on the head shapes (tools/kbench.py --dtype f32): 95 / 104 / 81 TFLOP/s against 92 / 92 / 77 for the
+// register-transpose kernel it replaces (global load -> 4x4 rename -> ds_write_b128 -> barrier per 32 pixels); PMC: matrix
+// pipe 63 % busy at 2.24 GHz, waves resident ~70 % of the launch -- the rest is split-K block scheduling, not the loop.
+//   LDS per stage (32 pixels): dz [32][128 ch] + x [32][128 j] fp32 = 32 KiB, two stages, two workgroups per CU.
+//   A DMA piece = 2 pixels x 512 B (lane -> pixel l >> 5, 16-byte chunk l & 31): lane-linear in LDS, two fully used 512-byte
+//   runs of global memory.  Halo taps, ragged tails and pixels past the split's end are EFFDET_OOB lanes = zeros; the pixel
+//   cursor is scalar per wave, border validity an OR of precomputed 64-bit lane masks (same scheme as the bf16 kernel).
+// Eligibility (host, per pyramid level): stride 1, 'same' geometry with taps in [-1, 1], 16-byte aligned rows, and a piece's
+// two pixels in one image row (Wo even) or two whole rows (Wo = 1, Ho even); contiguous pointwise convs = one long row.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK p) {
+  constexpr int WJ = NW / 2;                    // waves along j (2 along n)
+  constexpr int WTJ = 128 / WJ, JB = WTJ / 16;  // j per wave (64 | 32), B tiles per wave = floats per lane of the B read (4 | 2)
+  constexpr int BKM = 32;                       // pixels per stage
+  constexpr unsigned OPB = 16384, BUFB = 2 * OPB;
+  constexpr int PPW = 16 / NW;                  // 2-pixel pieces per wave per stage and operand
+
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn0 = (wave / WJ) * 64, wj0 = (wave % WJ) * WTJ;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = logical % p.ntiles, jt = (logical / p.ntiles) % p.jtiles, split = logical / (p.ntiles * p.jtiles);
+  int si = 0;
+#pragma unroll
+  for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+    if (s < p.nseg && split >= p.seg[s].split_start) si = s;
+  const WSeg sg = p.seg[si];
+  const int m_begin = (split - sg.split_start) * p.mchunk;
+  const int m_end = min(sg.M, m_begin + p.mchunk);
+  const int nsteps = (m_end - m_begin + BKM - 1) / BKM;
+
+  // ---- staging ----
+  const int Wr = sg.Wo < 2 ? sg.Wo : 2, RP = 2 / Wr;            // pixels per image row / image rows per piece
+  // pixel in the piece, SOURCE 16-byte chunk of the 512-byte row: odd pixels are rotated by 128 B so that the 8-byte B reads of
+  // the 8-wave form (32 lanes per LDS cycle = an even and an odd pixel at the same column) fall into different bank halves
+  const int r = lane >> 5, g = ((lane & 31) - 8 * r) & 31;
+  const int dho = r / Wr, dwo = r - dho * Wr;
+  const int n = nt * 128 + g * 4;
+  const int off_z = (r * p.lddz + n) * 4;
+  const unsigned long long mz_inv = __ballot(n + 4 > p.lddz);
+  const int jq = jt * 32 + g;
+  const bool jok = jq < p.Kc;
+  const int tap = jok ? jq / p.cpt : 0, cc = jok ? jq - tap * p.cpt : 0;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int dkh = kh - p.pad_t, dkw = kw - p.pad_l;
+  const int off_x = ((dkh * sg.W + dkw + r) * p.ldx + cc * 4) * 4;
+  const unsigned long long mx_inv = __ballot(!jok);
+  const unsigned long long mx_up = __ballot(dkh < 0 && dho == 0), mx_dn = __ballot(dkh > 0 && dho == RP - 1);
+  const unsigned long long mx_lf = __ballot(dkw < 0 && dwo == 0), mx_rt = __ballot(dkw > 0 && dwo == Wr - 1);
+  const u32x4_t srd_x = make_srd_raw((const float*)p.x + sg.in_off, sg.x_bytes);
+  const u32x4_t srd_z = make_srd_raw((const float*)p.dz + sg.out_off, sg.dz_bytes);
+  const unsigned x_bs = (unsigned)(sg.in_bs * 4), x_ld = (unsigned)(p.ldx * 4), z_bs = (unsigned)(sg.out_bs * 4), z_ld = (unsigned)(p.lddz * 4);
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned dst0 = lds0 + (unsigned)wave * 1024u;
+
+  const int HoWo = sg.Ho * sg.Wo;
+  int cm = m_begin + 2 * wave;                                   // scalar pixel cursor of the wave's next piece
+  int cb = cm / HoWo, crem = cm - cb * HoWo;
+  int cho = crem / sg.Wo, cwo = crem - cho * sg.Wo;
+
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+      const unsigned long long past = (cm >= m_end) ? ~0ull : 0ull;
+      const unsigned long long c_up = (cho == 0) ? ~0ull : 0ull, c_dn = (cho == sg.Ho - RP) ? ~0ull : 0ull;
+      const unsigned long long c_lf = (cwo == 0) ? ~0ull : 0ull, c_rt = (cwo == sg.Wo - Wr) ? ~0ull : 0ull;
+      const unsigned pix = (unsigned)(cho * sg.Wo + cwo);
+      const unsigned zb = (unsigned)cb * z_bs + pix * z_ld, xb = (unsigned)cb * x_bs + pix * x_ld;
+      const unsigned dst = dst0 + (unsigned)buf * BUFB + (unsigned)(i * NW) * 1024u;
+      dma16_async(srd_z, dst, oob_if(mz_inv | past, zb + (unsigned)off_z));
+      const unsigned long long inv = mx_inv | past | (c_up & mx_up) | (c_dn & mx_dn) | (c_lf & mx_lf) | (c_rt & mx_rt);
+      dma16_async(srd_x, dst + OPB, oob_if(inv, xb + (unsigned)off_x));
+      cm += 2 * NW; cwo += 2 * NW;
+      while (cwo >= sg.Wo) { cwo -= sg.Wo; if (++cho == sg.Ho) { cho = 0; ++cb; } }
+    }
+  };
+
+  // ---- fragments: lane (c = l & 15, k = l >> 4): pixel 4*ks + k of the stage, 4 (or JB) consecutive channels / j ----
+  const int c15 = lane & 15, kq = lane >> 4;
+  const unsigned rot = (unsigned)(kq & 1) * 128u;              // stage pixel 4*ks + kq is odd <=> kq is odd
+  const unsigned a_addr = lds0 + (unsigned)kq * 512u + (((unsigned)(wn0 + 4 * c15) * 4u + rot) & 511u);
+  const unsigned b_addr = lds0 + OPB + (unsigned)kq * 512u + (((unsigned)(wj0 + JB * c15) * 4u + rot) & 511u);
+
+  f32x4 acc[4][JB], bsum[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    bsum[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < JB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_bias = (p.dbias != nullptr) && (jt == 0) && (wj0 == 0);
+  float* slab = p.slab + (long long)split * p.Cout * p.K;
+
+  if (nsteps > 0) {
+    stage(0);
+    for (int kt = 0; kt < nsteps; ++kt) {
+      const unsigned cur = (unsigned)(kt & 1) * BUFB;
+      dma_wait_all();
+      __syncthreads();
+      if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+      // fragments of k-step ks+1 are read BEFORE the 16 MFMAs of k-step ks (register double buffer): the LDS round trip
+      // hides under 512 cycles of matrix work instead of preceding it
+      auto lda = [&](int ks) -> f32x4 { return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(a_addr + cur + (unsigned)ks * 2048u); };
+      auto ldb = [&](int ks) -> f32x4 {
+        if constexpr (JB == 4) return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
+        else {
+          typedef float f32x2l __attribute__((ext_vector_type(2)));
+          const f32x2l t = *(const f32x2l __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
+          return f32x4{t[0], t[1], 0.f, 0.f};
+        }
+      };
+      f32x4 av = lda(0), bv = ldb(0);
+#pragma unroll
+      for (int ks = 0; ks < BKM / 4; ++ks) {
+        f32x4 an = av, bn = bv;
+        if (ks + 1 < BKM / 4) { an = lda(ks + 1); bn = ldb(ks + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < JB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        if (want_bias) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) bsum[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], 1.0f, bsum[a], 0, 0, 0);
+        }
+        av = an; bv = bn;
+      }
+    }
+    // D[i][c] of tile (a, b): row i = 4*(l>>4) + reg stands for channel 4i + a, column c = l & 15 for j = JB*c + b
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int nn = nt * 128 + wn0 + 4 * (4 * kq + reg) + a;
+        if (nn >= p.Cout) continue;
+        const int j0 = jt * 128 + wj0 + JB * c15;
+        float* dst = slab + (long long)nn * p.K + j0;
+        if (j0 + JB <= p.K && (p.K % JB) == 0) {
+          if constexpr (JB == 4) *(f32x4*)dst = f32x4{acc[a][0][reg], acc[a][1][reg], acc[a][2][reg], acc[a][3][reg]};
+          else { dst[0] = acc[a][0][reg]; dst[1] = acc[a][1][reg]; }
+        } else {
+#pragma unroll
+          for (int b = 0; b < JB; ++b) if (j0 + b < p.K) dst[b] = acc[a][b][reg];
+        }
+        if (want_bias && c15 == 0) atomicAdd(p.dbias + nn, bsum[a][reg]);
+      }
+    }
+  } else {
+    for (int i = tid; i < 128 * 128; i += NW * 64) {
+      const int nn = nt * 128 + i / 128, j = jt * 128 + (i & 127);
+      if (nn < p.Cout && j < p.K) slab[(long long)nn * p.K + j] = 0.f;
+    }
+  }
+}
+
 // dw[i] += sum_s slab[s][i]      (16-byte vectorised, fully coalesced)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int splits) {
   const long long n4 = n >> 2;
@@ -586,7 +752,25 @@ bool tr_eligible(const effdet_wgrad_t* p, const WgradK& k, int s) {
   // an aligned run of 8 pixels must be part of one image row, or a whole number of rows of one image
   return g.Wo % 8 == 0 || (8 % g.Wo == 0 && (g.Ho * g.Wo) % 8 == 0);
 }
+// Does pyramid level s qualify for the fp32 DMA kernel?
+bool f32dma_eligible(const effdet_wgrad_t* p, const WgradK& k, int s) {
+  if (p->dtype != EFFDET_F32) return false;
+  const effdet_seg_t& g = p->seg[s];
+  if (p->stride != 1 || g.Ho != g.H || g.Wo != g.W) return false;
+  if (p->KH > 3 || p->KW > 3 || p->pad_t > 1 || p->pad_l > 1 || p->KH - 1 - p->pad_t > 1 || p->KW - 1 - p->pad_l > 1) return false;
+  if (p->ldx % 4 || p->lddz % 4 || g.in_off % 4 || g.out_off % 4 || g.in_bstride % 4 || g.out_bstride % 4) return false;
+  if (((p->Cout + 3) / 4 * 4) > p->lddz) return false;
+  const long long M = (long long)p->B * g.Ho * g.Wo;
+  const bool pointwise_contig = p->KH == 1 && p->KW == 1 && g.in_bstride == (long long)g.H * g.W * p->ldx &&
+                                g.out_bstride == (long long)g.Ho * g.Wo * p->lddz;
+  if (pointwise_contig) return M % 2 == 0;
+  return g.Wo % 2 == 0 || (g.Wo == 1 && g.Ho % 2 == 0);
+}
 constexpr int TR_NW = EFFDET_WGRAD_TR_WAVES;
+#ifndef EFFDET_WGRAD_F32_WAVES
+#define EFFDET_WGRAD_F32_WAVES 8
+#endif
+constexpr int F32_NW = EFFDET_WGRAD_F32_WAVES;
 }  // namespace
 
 extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
@@ -602,11 +786,12 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   hipStream_t st = (hipStream_t)stream;
   // Partition the pyramid levels between the two kernels; each launch numbers its own splits from 0 and owns a
   // contiguous range of slabs (the slab order is irrelevant to the reduction).
-  WgradK kf = k, ks = k;            // fast (DMA + LDS transpose read) / slow (register transpose)
+  WgradK kf = k, ks = k;            // fast (DMA staging: bf16 LDS-transpose-read / fp32 direct-operand) / slow (register transpose)
+  static const int f32dma = getenv("EFFDET_WGRAD_F32DMA") ? atoi(getenv("EFFDET_WGRAD_F32DMA")) : 1;      // A/B switch
   int nf = 0, ns = 0, sf = 0, ss = 0;
   for (int s = 0; s < p->nseg; ++s) {
     const int cnt = (int)((k.seg[s].M + k.mchunk - 1) / k.mchunk);
-    if (tr_eligible(p, k, s)) {
+    if (tr_eligible(p, k, s) || (f32dma && f32dma_eligible(p, k, s))) {
       WSeg d = k.seg[s]; d.split_start = sf; sf += cnt;
       if (p->KH == 1 && p->KW == 1 && d.in_bs == (long long)d.H * d.W * p->ldx && d.out_bs == (long long)d.Ho * d.Wo * p->lddz) {
         d.H = d.Ho = 1; d.W = d.Wo = d.M;           // contiguous pointwise: one long image row, no wrap, no borders
@@ -621,7 +806,11 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   for (int s = ns; s < EFFDET_MAX_SEG; ++s) { ks.seg[s] = ks.seg[0]; ks.seg[s].split_start = 0x7fffffff; }
   kf.nseg = nf; ks.nseg = ns;
   ks.slab = k.slab + (long long)sf * n;
-  if (nf > 0) {
+  if (nf > 0 && p->dtype == EFFDET_F32) {
+    EFFDET_SET_MAX_LDS((conv_wgrad_f32dma_kernel<F32_NW>), lds);
+    hipLaunchKernelGGL(conv_wgrad_f32dma_kernel<F32_NW>, dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(F32_NW * 64), lds, st, kf);
+    EFFDET_CHECK_LAUNCH();
+  } else if (nf > 0) {
     EFFDET_SET_MAX_LDS((conv_wgrad_tr_kernel<TR_NW>), lds);
     hipLaunchKernelGGL(conv_wgrad_tr_kernel<TR_NW>, dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(TR_NW * 64), lds, st, kf);
     EFFDET_CHECK_LAUNCH();

@@ -292,8 +292,8 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
         raise RuntimeError('effdet_conv2d_wgrad: unsupported geometry')
     slabs = torch.empty((splits, Cout, KH * KW, Cin), dtype=torch.float32, device=x0.t.device)
     nbytes = slabs.numel() * 4
-    # (bf16: DMA + LDS-transpose-read kernel; levels it cannot take -- and fp32 -- use the register-transpose kernel)
-    _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else 'conv_wgrad_kernel<f32>', flops,
+    # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
+    _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else 'conv_wgrad_f32dma_kernel<8>', flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(slabs), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))

@@ -180,7 +180,10 @@ def test_forward_raw_is_differentiable(dtype):
     live = dict(sd); live.update(params)
     rc, rr, _ = O.forward_raw(live, net, nc, img)
     ((rc * wc).sum() + (rr * wr).sum()).backward()
-    tol = 2e-3 if dtype == torch.float32 else 0.35      # bf16 through ~100 random-weight layers (measured 0.26 on the stem)
+    # fp32: 5e-3 of the tensor's scale -- the BiFPN max-pool routing and the ReLU masks are discontinuous in the forward values,
+    # so a 1e-7 summation-order difference occasionally moves one gradient entry by a fixed amount (seen: 3.6e-3 on one neck
+    # conv weight in some runs, with bitwise-stable kernels: tools/wgrad_stress.py); bf16: see below
+    tol = 5e-3 if dtype == torch.float32 else 0.35
     assert_close_scale(cls.detach().cpu(), rc.detach(), 1e-3 if dtype == torch.float32 else 4e-2, 'cls')
     for k, p in m.named_parameters():
         if params[k].grad is None:

@@ -20,6 +20,16 @@ __global__ __launch_bounds__(256) void k(const uint4* __restrict__ src, float* o
     }
     float s = 0; for (int e = 0; e < 16; ++e) s += c00[e] + c01[e] + c10[e] + c11[e];
     out[blockIdx.x * 256 + threadIdx.x] = s;
+  } else if (MODE == 2) {
+    f32x4 c[16]; for (int j = 0; j < 16; ++j) c[j] = f32x4{0, 0, 0, 0};
+    const float fa[4] = {__uint_as_float(a0.x), __uint_as_float(a0.y), __uint_as_float(a0.z), __uint_as_float(a0.w)};
+    const float fb[4] = {__uint_as_float(b0.x), __uint_as_float(b0.y), __uint_as_float(b0.z), __uint_as_float(b0.w)};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) c[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j & 3], fb[j >> 2], c[j], 0, 0, 0);
+    }
+    float s = 0; for (int j = 0; j < 16; ++j) s += c[j][0] + c[j][1] + c[j][2] + c[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
   } else {
     f32x4 c[8]; for (int j = 0; j < 8; ++j) c[j] = f32x4{0, 0, 0, 0};
     for (int i = 0; i < iters; ++i) {
@@ -45,18 +55,19 @@ int main() {
       else hs[i] = 0x3f80;   // all ones
     }
     hipMemcpy(src, h, 1024 * 16, hipMemcpyHostToDevice);
-    for (int mode = 0; mode < 2; ++mode) {
-      const int iters = 20000;
+    for (int mode = 0; mode < 3; ++mode) {
+      const int iters = mode == 2 ? 4000 : 20000;
       hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
       for (int rep = 0; rep < 2; ++rep) {
         hipEventRecord(e0);
         if (mode == 0) hipLaunchKernelGGL(k<0>, dim3(nblk), dim3(256), 0, 0, src, out, iters);
-        else hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(256), 0, 0, src, out, iters);
+        else if (mode == 1) hipLaunchKernelGGL(k<1>, dim3(nblk), dim3(256), 0, 0, src, out, iters);
+        else hipLaunchKernelGGL(k<2>, dim3(nblk), dim3(256), 0, 0, src, out, iters);
         hipEventRecord(e1); hipEventSynchronize(e1);
       }
       float ms; hipEventElapsedTime(&ms, e0, e1);
-      const double flops = (double)nblk * 4 * iters * (mode == 0 ? 4.0 * 32768 : 8.0 * 16384);
-      printf("%s data, %s: %.2f ms  %.0f TFLOP/s\n", pass == 0 ? "zero  " : pass == 1 ? "random" : "ones  ", mode == 0 ? "32x32x16" : "16x16x32", ms, flops / ms / 1e9);
+      const double flops = (double)nblk * 4 * iters * (mode == 0 ? 4.0 * 32768 : mode == 1 ? 8.0 * 16384 : 16.0 * 2048);
+      printf("%s data, %s: %.2f ms  %.0f TFLOP/s\n", pass == 0 ? "zero  " : pass == 1 ? "random" : "ones  ", mode == 0 ? "bf16 32x32x16" : mode == 1 ? "bf16 16x16x32" : "f32  16x16x4 ", ms, flops / ms / 1e9);
     }
   }
   return 0;
