@@ -135,6 +135,46 @@ def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=Tr
     print(name, 'cls', tuple(cls.shape), 'cands', int(mask.sum()), 'kept', [len(x[0]) for x in dets])
 
 
+def case_dets_separated(EfficientDet, name, network, num_classes, B, S, gain=1.0, seed=0, want=32):
+    """Eval detections with WELL-SEPARATED scores: at the default thresholds a random-init model has thousands of candidates in a
+    narrow score band (gaps ~1e-7: the other eval goldens can only compare counts and leading scores).  Here the threshold
+    is chosen (per image set, recorded in the fixture) so that only the ~`want` best candidates per image remain and every
+    score gap exceeds 4e-6 and the margin to the threshold 5e-5 -- well above fp32 conv rounding (~1e-7 on a probability) -- so the COMPLETE
+    lists (scores, labels, boxes, per image) of the real reference must be reproduced."""
+    sd = O.make_state_dict(network, num_classes, seed=seed)
+    sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * gain
+    img, _ = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
+    m = build_ref(EfficientDet, network, num_classes, sd, is_training=False, threshold=0.5)
+    m.eval()
+    with torch.no_grad():
+        outs = m.bbox_head(m.extract_feat(img))
+        sc = torch.cat(list(outs[0]), 1).max(dim=2)[0]                      # [B, A] best-class probability
+    srt = torch.sort(sc.reshape(-1), descending=True)[0]
+    thr = None
+    for k in range(want * B, 8, -1):                                         # a threshold in the widest gap below the k-th score
+        lo, hi = float(srt[k]), float(srt[k - 1])
+        if hi - lo > 2e-4:
+            thr = round((lo + hi) / 2, 5)
+            if min(abs(thr - lo), abs(hi - thr)) > 5e-5:
+                break
+    assert thr is not None
+    m.threshold = thr
+    with torch.no_grad():
+        dets = [m(img[b:b + 1]) for b in range(B)]
+    d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed, threshold=thr, gain=gain)
+    gaps = []
+    for b, (s_, c_, bx) in enumerate(dets):
+        cand = torch.sort(sc[b][sc[b] > thr])[0]
+        if len(cand) > 1:
+            gaps.append(float((cand[1:] - cand[:-1]).min()))
+        d[f'det{b}_scores'] = s_.numpy(); d[f'det{b}_labels'] = c_.numpy(); d[f'det{b}_boxes'] = bx.numpy()
+        d[f'det{b}_ncand'] = int(len(cand))
+    assert min(gaps) > 4e-6, gaps
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
+    print(name, 'threshold', thr, 'candidates', [int(d[f'det{b}_ncand']) for b in range(B)], 'kept', [len(x[0]) for x in dets],
+          'smallest candidate score gap', min(gaps))
+
+
 def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_last=True, drop_connect=0.0):
     sd = O.make_state_dict(network, num_classes, seed=seed)
     m = build_ref(EfficientDet, network, num_classes, sd, is_training=True)
@@ -211,6 +251,7 @@ CASES = {
     # configs[4] = D4 @1024 (80 classes, the COCO shape both are quoted on)
     'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),
     'd4_1024_eval': lambda E: case_eval(E, 'd4_1024_eval', 'efficientdet-d4', 80, 1, 1024, threshold=0.6, full=False, dets=False),
+    'd0_128_dets_separated': lambda E: case_dets_separated(E, 'd0_128_dets_separated', 'efficientdet-d0', 20, 2, 128),
     'd0_128_dropconnect': lambda E: case_train_dropconnect(E, 'd0_128_dropconnect', 'efficientdet-d0', 20, 4, 128),
 }
 

@@ -73,6 +73,22 @@ def test_nms_and_detections(golden_dir, case):
         np.testing.assert_allclose(s.numpy()[:16], g[f'det{b}_scores'][:16], rtol=1e-4)
 
 
+def test_complete_detection_lists_when_scores_are_separated(golden_dir):
+    """Oracle == the real reference on every score / label / box of a case with well-separated candidate scores."""
+    g = _load(golden_dir, 'd0_128_dets_separated')
+    net, nc = str(g['network']), int(g['num_classes'])
+    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
+    img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
+    with torch.no_grad():
+        dets = O.detect(sd, net, nc, img, threshold=float(g['threshold']))
+    for b, (s, c, bx) in enumerate(dets):
+        assert len(s) == len(g[f'det{b}_scores']) >= 10
+        np.testing.assert_array_equal(c.numpy(), g[f'det{b}_labels'])
+        np.testing.assert_allclose(s.numpy(), g[f'det{b}_scores'], rtol=1e-5)
+        np.testing.assert_allclose(bx.numpy(), g[f'det{b}_boxes'], rtol=1e-4, atol=1e-3)
+
+
 @pytest.mark.parametrize('case', ['d0_128_train', 'd1_128_train', 'd0_512_train'])                  # last: BASELINE configs[2] geometry
 def test_train_losses_and_grads(golden_dir, case):
     g = _load(golden_dir, case)
