@@ -83,6 +83,56 @@ def test_nms_batched_thresholds_ties_and_empty():
     assert torch.equal(bb[0, :n0].cpu(), boxes[0][idx[0, :n0].cpu().long()])
 
 
+@pytest.mark.parametrize('iou', [0.5, 0.7, 0.3])
+def test_nms_adversarial_geometry(iou):
+    """Spatial-hash NMS (iou >= 0.5) and the round-based form (iou < 0.5) == sequential greedy NMS on inputs built to break a
+    spatial index: a 3000-box dependency chain (every box's fate hinges on its predecessor: the fixed point needs thousands of
+    sweeps), degenerate / inverted / non-finite boxes, extreme aspect ratios, huge and negative coordinates, boxes whose areas
+    sit exactly on octave boundaries, and nested boxes with IoU a hair either side of the threshold."""
+    from efficientdet.pytorch_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows = []
+    # (0) dependency chain: unit squares of side 100 shifted by 30 px: IoU(k, k+1) = 0.538, IoU(k, k+2) = 0.25
+    n = 3000
+    x = torch.arange(n, dtype=torch.float32) * 30.0
+    chain = torch.stack([x, torch.zeros(n), x + 100.0, torch.full((n,), 100.0)], 1)
+    rows.append((chain, torch.linspace(0.99, 0.5, n)))
+    # (1) mixed bag
+    m = 6000
+    xy = torch.rand(m, 2, generator=g) * 900 - 50                       # some negative coordinates
+    wh = torch.exp(torch.rand(m, 2, generator=g) * 7.0)                 # sides 1 .. 1100, aspect ratios up to ~1000
+    mixed = torch.cat([xy, xy + wh], 1)
+    mixed[0:50, 2:] = mixed[0:50, :2]                                   # zero area
+    mixed[50:100, 2] = mixed[50:100, 0] - 5.0                           # inverted in x (negative area)
+    mixed[100:110] = float('nan'); mixed[110:115, 2] = float('inf'); mixed[115:120, 0] = -float('inf')
+    mixed[120:130] = mixed[120:130] * 1.0e6                             # far away, huge
+    side = 2.0 ** torch.arange(2, 12).float()                           # areas exactly 2^4 .. 2^22: octave boundaries
+    for k, sd in enumerate(side):
+        mixed[200 + 3 * k] = torch.tensor([300.0, 300.0, 300.0 + sd, 300.0 + sd])
+        mixed[201 + 3 * k] = torch.tensor([300.0, 300.0, 300.0 + sd, 300.0 + sd * 0.5])        # exactly half the area, nested: IoU = 0.5
+        mixed[202 + 3 * k] = torch.tensor([300.0, 300.0, 300.0 + sd, 300.0 + sd * 0.5000001])
+    rows.append((mixed, torch.rand(m, generator=g)))
+    # (2) dense anchor-like lattice with jitter (the benchmark's regime) + exact score ties
+    gx, gy = torch.meshgrid(torch.arange(0, 256, 8.0), torch.arange(0, 256, 8.0), indexing='ij')
+    ctr = torch.stack([gx.flatten(), gy.flatten()], 1).repeat_interleave(9, 0) + torch.rand(9216, 2, generator=g)
+    sz = torch.tensor([32.0, 40.3, 50.8]).repeat_interleave(3).repeat(1024)[:, None] * torch.tensor([[1.0, 1.0], [0.7, 1.4], [1.4, 0.7]]).repeat(3072, 1)
+    lat = torch.cat([ctr - sz / 2, ctr + sz / 2], 1).clamp(0, 256)
+    rows.append((lat, (torch.rand(9216, generator=g) * 64).floor() / 64))
+    A = max(len(r[0]) for r in rows)
+    boxes = torch.zeros(len(rows), A, 4); score = torch.zeros(len(rows), A)
+    for b, (bx, sc) in enumerate(rows):
+        boxes[b, :len(bx)] = bx; score[b, :len(sc)] = sc
+    idx, cnt = ops.nms(boxes.cuda(), score.cuda(), 0.01, iou)
+    torch.cuda.synchronize()
+    for b in range(len(rows)):
+        ref = _nms_ref(boxes[b], score[b], 0.01, iou)
+        n_ = int(cnt[b])
+        assert n_ == len(ref), (b, n_, len(ref))
+        assert torch.equal(idx[b, :n_].cpu().long(), ref), b
+    if iou == 0.5:
+        assert int(cnt[0]) == 1500                                      # every other box of the chain survives
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('nc', [20, 6])
 def test_focal_loss_fwd_bwd(dtype, nc):
