@@ -97,11 +97,14 @@ constexpr int NT = 1024;          // threads per NMS workgroup = candidates per 
 constexpr int SUBS = EFFDET_NMS_SUBS;
 constexpr int ROUND = SUBS * NT;  // candidates per round
 
+struct KeptGrid { int* kcount; float4* kcell; int* kover_n; float4* kover; int HT; };      // see "spatial hash of the KEPT boxes" below
+constexpr int KG_CAP = 8;                 // boxes per cell (NMS keeps same-size boxes in one cell sparse); more go to the overflow list
+
 struct NmsWs {
   unsigned long long* keys_in; unsigned long long* keys_out; unsigned* vals_in; unsigned* vals_out;
   int* offsets; int* nvalid; int* kept; unsigned* dead; float4* sbox; float4* kbox;
   void* temp; size_t temp_bytes;
-  int* hcount; int* hstart; int* und; int HT;      // spatial-hash form: per-image slot counts / starts, per-sweep undecided counts
+  KeptGrid kg;                                      // spatial hash of the kept boxes (cross phase, iou_threshold >= 0.5)
 };
 
 __device__ __forceinline__ bool suppresses(const float4& a, float aa, const float4& b, float ab, float thr) {
@@ -176,6 +179,113 @@ __global__ void nms_gather_kernel(const float* __restrict__ boxes, const unsigne
   }
 }
 
+// ------------------------------------------------------------------ NMS: spatial hash of the KEPT boxes (iou_threshold >= 0.5)
+// The cross phase (candidates of a round against every box kept in earlier rounds) was the largest part of the NMS: N x K / 2
+// IoU tests per image (1.2e8 for D0's worst case, 1.7e9 for D4 @1024).  For thr >= 0.5 a suppressor must (a) have an area
+// within a factor 2 and (b) contain the candidate's centre and have its own centre inside the candidate (the intersection
+// covers more than half of either box along both axes).  So kept boxes are filed by (area octave, centre cell) in a hashed
+// grid -- cell = half a box side, fixed capacity, one cache line per cell, overflow into a per-image list that everyone scans --
+// and a candidate only visits the cells of <= 3 octaves that its own box covers: tens of tests instead of thousands.
+// (Tried first and dropped: filing ALL candidates and resolving the greedy order by a whole-batch monotone fixed point --
+//  exact, no rounds, but the dependency DAG of the dense-anchor worst case is ~40 layers deep and every sweep re-walks
+//  ~400 divergent, uncoalesced entries per open candidate: 109 ms vs 5 ms for D0 B = 32.)
+// The IoU arithmetic is `suppresses()`, bit for bit; boxes with non-positive / non-finite area suppress nothing and are never
+// suppressed (exactly as there) and are not filed.  Rounding slack: the octave window is taken from a * (0.5, 2) widened by
+// 2^-20 and the query rectangle is grown by 1e-4 of the box size, so a pair whose COMPUTED IoU exceeds thr is never missed;
+// hash collisions only add tests.
+constexpr int SB_MIN = 4, SB_MAX = 40;
+
+
+__device__ __forceinline__ float box_area(const float4& b) { return (b.z - b.x) * (b.w - b.y); }
+__device__ __forceinline__ bool box_live(const float4& b, float a) {       // can take part in suppression at all
+  return a > 0.f && a < 3.0e38f && fabsf(b.x) < 1.0e18f && fabsf(b.y) < 1.0e18f && fabsf(b.z) < 1.0e18f && fabsf(b.w) < 1.0e18f;
+}
+__device__ __forceinline__ int octave(float a) { const int e = ilogbf(a); return e < SB_MIN ? SB_MIN : (e > SB_MAX ? SB_MAX : e); }
+__device__ __forceinline__ float inv_cell(int lvl) { return ldexpf(1.0f, 1 - (lvl >> 1)); }     // 1 / 2^(lvl/2 - 1): cell = half a side
+__device__ __forceinline__ unsigned cell_hash(int lvl, int cx, int cy, unsigned mask) {
+  return (((unsigned)lvl * 0x9E3779B1u) ^ ((unsigned)cx * 73856093u) ^ ((unsigned)cy * 83492791u)) & mask;
+}
+__device__ __forceinline__ int cell_of(float v, float inv) { return (int)fminf(fmaxf(floorf(v * inv), -1.0e9f), 1.0e9f); }
+
+// file one kept box of image b (called by the per-image round kernel: the only writer of that image's grid)
+__device__ __forceinline__ void kg_insert(const KeptGrid& kg, long long b, long long A, const float4& bx) {
+  const float a = box_area(bx);
+  if (!box_live(bx, a)) return;
+  const int lvl = octave(a);
+  const float inv = inv_cell(lvl);
+  const long long hs = b * kg.HT + cell_hash(lvl, cell_of(0.5f * (bx.x + bx.z), inv), cell_of(0.5f * (bx.y + bx.w), inv), (unsigned)kg.HT - 1u);
+  const int pos = atomicAdd(kg.kcount + hs, 1);
+  if (pos < KG_CAP) kg.kcell[hs * KG_CAP + pos] = bx;
+  else kg.kover[b * A + atomicAdd(kg.kover_n + b, 1)] = bx;
+}
+
+// Kernel A': candidates of round `round` vs the hashed grid of boxes kept in earlier rounds.  ONE WAVE per candidate: a thread
+// per candidate walks ~20 cells as a chain of dependent global loads (measured 110 us per round, no better than brute force);
+// here the 64 lanes take (cell, entry) pairs -- 8 cells x 8 entries per pass, count and box loads independent of each other --
+// so a candidate costs a handful of round trips and a round of 2048 candidates fills the chip (B x 2048 waves).
+__global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __restrict__ sbox, const KeptGrid kg, const int* nvalid,
+                                                             unsigned* dead, long long A, int round, float thr) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const long long i = (long long)round * ROUND + blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (i >= nvalid[b]) return;                                        // wave-uniform
+  const float4 me = sbox[b * A + i];
+  const float ma = box_area(me);
+  if (!box_live(me, ma)) return;
+  const float ex = 1.0e-4f * (me.z - me.x) + 1.0e-6f, ey = 1.0e-4f * (me.w - me.y) + 1.0e-6f;
+  const float qx0 = me.x - ex, qx1 = me.z + ex, qy0 = me.y - ey, qy1 = me.w + ey;
+  const int l0 = octave(ma * 0.4999995f), l1 = octave(ma * 2.000002f);          // <= 4 octaves
+  const unsigned mask = (unsigned)kg.HT - 1u;
+  int cxa[4], cya[4], nxa[4], base[5];
+  base[0] = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int lvl = l0 + k;
+    int nx = 0, ny = 0; cxa[k] = 0; cya[k] = 0;
+    if (lvl <= l1) {
+      const float inv = inv_cell(lvl);
+      cxa[k] = cell_of(qx0, inv); cya[k] = cell_of(qy0, inv);
+      nx = cell_of(qx1, inv) - cxa[k] + 1; ny = cell_of(qy1, inv) - cya[k] + 1;
+    }
+    nxa[k] = nx;
+    const long long cells = (long long)nx * ny;
+    base[k + 1] = base[k] + (int)(cells > 100000000LL ? 100000000LL : cells);   // (absurd extents: clamp; such boxes are scanned exhaustively below)
+  }
+  const int T = base[4];
+  bool hit = false;
+  if (T >= 100000000) {
+    // a box spanning > 1e8 cells (coordinates ~1e9 px): walk the image's cells linearly instead -- every filed box is visited
+    for (long long hs0 = lane; hs0 < (long long)kg.HT * KG_CAP && !__ballot(hit); hs0 += 64) {
+      const long long hs = (long long)b * kg.HT + hs0 / KG_CAP; const int e = (int)(hs0 % KG_CAP);
+      if (e < min(kg.kcount[hs], KG_CAP)) { const float4 q = kg.kcell[hs * KG_CAP + e]; hit = suppresses(me, ma, q, box_area(q), thr); }
+    }
+  } else {
+    const int e = lane & 7;
+    for (int c0 = 0; c0 < T; c0 += 8) {
+      const int c = c0 + (lane >> 3);
+      bool h = false;
+      if (c < T) {
+        const int k = (c >= base[1]) + (c >= base[2]) + (c >= base[3]);
+        const int r = c - base[k], nx = nxa[k];
+        const int cy = r / nx, cx = r - cy * nx;
+        const long long hs = (long long)b * kg.HT + cell_hash(l0 + k, cxa[k] + cx, cya[k] + cy, mask);
+        const int n = kg.kcount[hs];
+        const float4 q = kg.kcell[hs * KG_CAP + e];               // (the slot exists whether or not it is filled: no dependent load)
+        h = e < n && suppresses(me, ma, q, box_area(q), thr);
+      }
+      if (__ballot(h)) { hit = true; break; }
+    }
+  }
+  if (!__ballot(hit)) {
+    const int no = kg.kover_n[b];
+    for (int e0 = 0; e0 < no; e0 += 64) {
+      bool h = false;
+      if (e0 + lane < no) { const float4 q = kg.kover[b * A + e0 + lane]; h = suppresses(me, ma, q, box_area(q), thr); }
+      if (__ballot(h)) { hit = true; break; }
+    }
+  }
+  if (__ballot(hit) && lane == 0) dead[b * A + i] = 1u;
+}
+
 // Kernel A: candidates of round `round` vs boxes kept in earlier rounds (split over blockIdx.z).
 __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict__ sbox, const float4* kbox, const int* nvalid,
                                                        const int* kept, unsigned* dead, long long A, int round, int splits, float thr) {
@@ -212,7 +322,7 @@ __device__ unsigned long long nms_prof[8];
 // Kernel B: finish round `round` for one image per workgroup.
 __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict__ sbox, const unsigned* __restrict__ sidx, float4* kbox,
                                                        const int* nvalid, int* kept, const unsigned* dead, int* out_idx,
-                                                       long long A, int round, float thr) {
+                                                       long long A, int round, float thr, const KeptGrid kg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* mask = (unsigned long long*)smem_raw;           // [16][NT] word-major
   float4* tb = (float4*)(smem_raw + (size_t)16 * NT * 8);            // [NT + 8] boxes (kept chunk / survivors)
@@ -330,6 +440,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
       const int pos = kc + koff + krank;
       kbox[b * A + pos] = tb[tid];
       out_idx[b * A + pos] = (int)tidx[tid];
+      if (kg.kcount) kg_insert(kg, b, A, tb[tid]);          // file it for the later rounds' cross phase
     }
     kc += KT;
     __threadfence_block();
@@ -338,197 +449,6 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
   }
   if (tid == 0) kept[b] = kc;
   (void)sh;
-}
-
-// ------------------------------------------------------------------ NMS, spatial-hash form (iou_threshold >= 0.5)
-// Greedy NMS only couples boxes that overlap with IoU > thr.  For thr >= 0.5 that means: intersection > half of EITHER box, so
-// (a) the areas differ by less than 2x and (b) the intersection -- a rectangle covering more than half of box i along both
-// axes -- contains the centre of box i, and likewise of box j.  So the only possible suppressors of candidate i are the
-// candidates j of higher rank whose CENTRE lies inside box i and whose area is within a factor 2.  All candidates are filed
-// once by (area octave, centre cell) in a hashed grid (cell = half a box side; hash collisions only add tests); candidate i
-// then visits the cells of <= 3 octaves that its own box covers: a few hundred tests instead of one per kept box (thousands),
-// and no rounds: the greedy order is resolved by a monotone fixed point over the WHOLE batch at once --
-//     i is DEAD as soon as a KEPT higher-ranked box suppresses it; i is KEPT once every higher-ranked suppressor is DEAD --
-// which reproduces sequential greedy NMS exactly (induction over rank).  Statuses only ever move UNDECIDED -> final, so reads
-// that race with writes are harmless (a stale UNDECIDED merely postpones a decision to the next sweep).
-// The IoU arithmetic is `suppresses()` above, bit for bit; boxes with non-positive / non-finite area suppress nothing and are
-// never suppressed (exactly as there) and are not filed.  Rounding slack: the octave window is taken from a * (0.5, 2) widened
-// by 2^-20 and the query rectangle is grown by 1e-4 of the box size, so a pair whose COMPUTED IoU exceeds thr is never missed.
-constexpr int NMSG_ITERS = 24;            // whole-batch sweeps before the per-image finisher takes over
-constexpr unsigned char ST_UNDECIDED = 0, ST_KEPT = 1, ST_DEAD = 2;
-constexpr int SB_MIN = 4, SB_MAX = 40;
-
-struct NmsG {
-  const float4* sbox; const unsigned* sidx; const int* nvalid;
-  unsigned* cellslot; int* hcount; int* hstart; float4* cbox; unsigned* crank; unsigned char* status; int* und;
-  int* kept; int* out_idx;
-  long long A; int B, HT; float thr;
-};
-
-__device__ __forceinline__ float box_area(const float4& b) { return (b.z - b.x) * (b.w - b.y); }
-__device__ __forceinline__ bool box_live(const float4& b, float a) {       // can take part in suppression at all
-  return a > 0.f && a < 3.0e38f && fabsf(b.x) < 1.0e18f && fabsf(b.y) < 1.0e18f && fabsf(b.z) < 1.0e18f && fabsf(b.w) < 1.0e18f;
-}
-__device__ __forceinline__ int octave(float a) { const int e = ilogbf(a); return e < SB_MIN ? SB_MIN : (e > SB_MAX ? SB_MAX : e); }
-__device__ __forceinline__ float inv_cell(int lvl) { return ldexpf(1.0f, 1 - (lvl >> 1)); }     // 1 / (2^(lvl/2 - 1)): cell = half a side
-__device__ __forceinline__ unsigned cell_hash(int lvl, int cx, int cy, unsigned mask) {
-  return (((unsigned)lvl * 0x9E3779B1u) ^ ((unsigned)cx * 73856093u) ^ ((unsigned)cy * 83492791u)) & mask;
-}
-__device__ __forceinline__ int cell_of(float v, float inv) {
-  const float f = floorf(v * inv);
-  return (int)fminf(fmaxf(f, -1.0e9f), 1.0e9f);
-}
-
-__global__ __launch_bounds__(256) void nmsg_cell_kernel(const NmsG g) {
-  const long long total = g.A * g.B;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long b = i / g.A, p = i - b * g.A;
-    if (p >= g.nvalid[b]) continue;
-    const float4 bx = g.sbox[i];
-    const float a = box_area(bx);
-    unsigned slot = 0xffffffffu;
-    if (box_live(bx, a)) {
-      const int lvl = octave(a);
-      const float inv = inv_cell(lvl);
-      slot = cell_hash(lvl, cell_of(0.5f * (bx.x + bx.z), inv), cell_of(0.5f * (bx.y + bx.w), inv), (unsigned)g.HT - 1u);
-      atomicAdd(g.hcount + b * g.HT + slot, 1);
-    }
-    g.cellslot[i] = slot;
-    g.status[i] = slot == 0xffffffffu ? ST_KEPT : ST_UNDECIDED;
-  }
-}
-
-// one workgroup per image: exclusive scan of the per-slot counts -> start offsets; counts are cleared to serve as fill cursors
-__global__ __launch_bounds__(1024) void nmsg_scan_kernel(const NmsG g) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int* cnt = g.hcount + (long long)b * g.HT; int* st = g.hstart + (long long)b * g.HT;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < g.HT; base += 1024) {
-    const int v = cnt[base + tid];
-    int x = v;                                   // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
-    if (lane == 63) wsum[wave] = x;
-    __syncthreads();
-    int woff = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) if (q < wave) woff += wsum[q];
-    const int c0 = carry;
-    st[base + tid] = c0 + woff + x - v;
-    cnt[base + tid] = 0;
-    __syncthreads();
-    if (tid == 1023) carry = c0 + woff + x;
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(256) void nmsg_fill_kernel(const NmsG g) {
-  const long long total = g.A * g.B;
-  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long b = i / g.A, p = i - b * g.A;
-    if (p >= g.nvalid[b]) continue;
-    const unsigned slot = g.cellslot[i];
-    if (slot == 0xffffffffu) continue;
-    const long long hs = b * g.HT + slot;
-    const int pos = g.hstart[hs] + atomicAdd(g.hcount + hs, 1);
-    g.cbox[b * g.A + pos] = g.sbox[i];
-    g.crank[b * g.A + pos] = (unsigned)p;
-  }
-}
-
-// fate of candidate p of image b given the current statuses: ST_DEAD / ST_KEPT, or ST_UNDECIDED if an undecided
-// higher-ranked box still suppresses it
-__device__ __forceinline__ unsigned char nmsg_decide(const NmsG& g, long long b, int p, const float4 me, float ma) {
-  const float ex = 1.0e-4f * (me.z - me.x) + 1.0e-6f, ey = 1.0e-4f * (me.w - me.y) + 1.0e-6f;
-  const float qx0 = me.x - ex, qx1 = me.z + ex, qy0 = me.y - ey, qy1 = me.w + ey;
-  const int l0 = octave(ma * 0.4999995f), l1 = octave(ma * 2.000002f);
-  const unsigned mask = (unsigned)g.HT - 1u;
-  bool blocked = false;
-  for (int lvl = l0; lvl <= l1; ++lvl) {         // (two octaves share a cell size; they are still separate hash keys)
-    const float inv = inv_cell(lvl);
-    const int cx0 = cell_of(qx0, inv), cx1 = cell_of(qx1, inv), cy0 = cell_of(qy0, inv), cy1 = cell_of(qy1, inv);
-    for (int cy = cy0; cy <= cy1; ++cy)
-      for (int cx = cx0; cx <= cx1; ++cx) {
-        const long long hs = b * g.HT + cell_hash(lvl, cx, cy, mask);
-        const int s0 = g.hstart[hs], n = g.hcount[hs];
-        for (int e = s0; e < s0 + n; ++e) {
-          const unsigned rj = g.crank[b * g.A + e];
-          if ((int)rj >= p) continue;
-          const unsigned char sj = g.status[b * g.A + rj];
-          if (sj == ST_DEAD) continue;
-          const float4 q = g.cbox[b * g.A + e];
-          if (suppresses(me, ma, q, box_area(q), g.thr)) {
-            if (sj == ST_KEPT) return ST_DEAD;
-            blocked = true;
-          }
-        }
-      }
-  }
-  return blocked ? ST_UNDECIDED : ST_KEPT;
-}
-
-// one sweep over the whole batch (thread = candidate, rank order); und[b][t] counts what sweep t left undecided
-__global__ __launch_bounds__(256) void nmsg_iter_kernel(const NmsG g, int t) {
-  const long long total = g.A * g.B;
-  const long long i = blockIdx.x * 256LL + threadIdx.x;
-  if (i >= total) return;
-  const long long b = i / g.A; const int p = (int)(i - b * g.A);
-  bool open = false;
-  if (p < g.nvalid[b] && (t == 0 || g.und[b * (NMSG_ITERS + 1) + t - 1] != 0) && g.status[i] == ST_UNDECIDED) {
-    const float4 me = g.sbox[i];
-    const unsigned char s = nmsg_decide(g, b, p, me, box_area(me));
-    if (s != ST_UNDECIDED) g.status[i] = s; else open = true;
-  }
-  // one atomic per wave (sweep 0 leaves most of 1.5 M candidates open: per-lane atomics on B addresses would serialise);
-  // a wave straddles two images only at an image boundary of the flattened index: those few lanes count on their own
-  const long long b0 = __builtin_amdgcn_readfirstlane((int)b);
-  const unsigned long long mine = __ballot(open && b == b0);
-  if (open && b != b0) atomicAdd(g.und + b * (NMSG_ITERS + 1) + t, 1);
-  if (mine && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(mine)) atomicAdd(g.und + b0 * (NMSG_ITERS + 1) + t, __popcll(mine));
-}
-
-// one workgroup per image: finish whatever the sweeps left (long dependency chains), then emit the kept candidates in rank order
-__global__ __launch_bounds__(1024) void nmsg_final_kernel(const NmsG g) {
-  __shared__ int wsum[16];
-  __shared__ int base_s;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nv = g.nvalid[b];
-  if (g.und[b * (NMSG_ITERS + 1) + NMSG_ITERS - 1] != 0) {
-    for (;;) {
-      int open = 0;
-      for (int p = tid; p < nv; p += 1024) {
-        const long long i = (long long)b * g.A + p;
-        if (g.status[i] != ST_UNDECIDED) continue;
-        const float4 me = g.sbox[i];
-        const unsigned char s = nmsg_decide(g, b, p, me, box_area(me));
-        if (s != ST_UNDECIDED) g.status[i] = s; else open = 1;
-      }
-      __threadfence_block();
-      if (!__syncthreads_or(open)) break;
-    }
-  }
-  if (tid == 0) base_s = 0;
-  __syncthreads();
-  for (int p0 = 0; p0 < nv; p0 += 1024) {
-    const int p = p0 + tid;
-    const bool k = p < nv && g.status[(long long)b * g.A + p] == ST_KEPT;
-    const unsigned long long bal = __ballot(k);
-    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const int c = wsum[q]; if (q < wave) woff += c; tot += c; }
-    const int base = base_s;
-    if (k) g.out_idx[(long long)b * g.A + base + woff + rank] = (int)g.sidx[(long long)b * g.A + p];
-    __syncthreads();
-    if (tid == 0) base_s = base + tot;
-    __syncthreads();
-  }
-  if (tid == 0) g.kept[b] = base_s;
 }
 
 __global__ void gather_dets_kernel(const float* __restrict__ boxes, const float* __restrict__ score, const int* __restrict__ label,
@@ -567,10 +487,10 @@ size_t carve(NmsWs& w, void* base, int B, long long A) {
   w.offsets = (int*)take((size_t)(B + 1) * 4); w.nvalid = (int*)take((size_t)B * 4); w.kept = (int*)take((size_t)B * 4);
   w.temp_bytes = sort_temp_bytes((long long)n, B);
   w.temp = take(w.temp_bytes);
-  int ht = 1024; while (ht < A) ht <<= 1;          // hash slots per image: >= the number of candidates, a power of two
-  w.HT = ht;
-  w.hcount = (int*)take((size_t)B * ht * 4); w.hstart = (int*)take((size_t)B * ht * 4);
-  w.und = (int*)take((size_t)B * (NMSG_ITERS + 1) * 4);
+  int ht = 1024; while (ht < A / 2) ht <<= 1;      // hash slots per image (kept boxes are a fraction of the candidates), a power of two
+  w.kg.HT = ht;
+  w.kg.kcount = (int*)take((size_t)B * ht * 4); w.kg.kover_n = (int*)take((size_t)B * 4);
+  w.kg.kcell = (float4*)take((size_t)B * ht * KG_CAP * 16); w.kg.kover = (float4*)take(n * 16);
   return off;
 }
 
@@ -646,35 +566,28 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     return EFFDET_ELAUNCH;
   hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
   EFFDET_CHECK_LAUNCH();
-  static const int use_grid = getenv("EFFDET_NMS_GRID") ? atoi(getenv("EFFDET_NMS_GRID")) : 1;       // A/B switch (0 = rounds of 2048)
-  if (use_grid && iou_threshold >= 0.5f) {
-    NmsG g;
-    g.sbox = w.sbox; g.sidx = w.vals_out; g.nvalid = w.nvalid;
-    g.cellslot = w.dead; g.hcount = w.hcount; g.hstart = w.hstart; g.cbox = w.kbox; g.crank = w.vals_in;
-    g.status = (unsigned char*)w.keys_in;          // (the unsorted keys are dead once the sort has run)
-    g.und = w.und; g.kept = w.kept; g.out_idx = out_idx; g.A = A; g.B = B; g.HT = w.HT; g.thr = iou_threshold;
-    if (hipMemsetAsync(w.hcount, 0, (size_t)B * w.HT * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-    if (hipMemsetAsync(w.und, 0, (size_t)B * (NMSG_ITERS + 1) * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-    hipLaunchKernelGGL(nmsg_cell_kernel, dim3(grid_for(n)), dim3(256), 0, st, g);
-    hipLaunchKernelGGL(nmsg_scan_kernel, dim3(B), dim3(1024), 0, st, g);
-    hipLaunchKernelGGL(nmsg_fill_kernel, dim3(grid_for(n)), dim3(256), 0, st, g);
-    EFFDET_CHECK_LAUNCH();
-    for (int t = 0; t < NMSG_ITERS; ++t) hipLaunchKernelGGL(nmsg_iter_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, t);
-    hipLaunchKernelGGL(nmsg_final_kernel, dim3(B), dim3(1024), 0, st, g);
-    EFFDET_CHECK_LAUNCH();
-    if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
-    return EFFDET_OK;
+  static const int grid_env = getenv("EFFDET_NMS_GRID") ? atoi(getenv("EFFDET_NMS_GRID")) : 1;       // A/B switch (0 = brute-force cross phase)
+  const bool use_grid = grid_env && iou_threshold >= 0.5f;
+  KeptGrid kg = w.kg;
+  if (use_grid) {
+    if (hipMemsetAsync(kg.kcount, 0, (size_t)B * kg.HT * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+    if (hipMemsetAsync(kg.kover_n, 0, (size_t)B * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+  } else {
+    kg.kcount = nullptr;
   }
   const size_t lds = (size_t)16 * NT * 8 + (size_t)(NT + 8) * 16 + (size_t)(NT + 8) * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
   EFFDET_SET_MAX_LDS((nms_round_kernel), lds);
   const int rounds = (int)((A + ROUND - 1) / ROUND);
   for (int r = 0; r < rounds; ++r) {
-    if (r > 0) {
+    if (r > 0 && use_grid) {
+      hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(ROUND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold);
+      EFFDET_CHECK_LAUNCH();
+    } else if (r > 0) {
       constexpr int SPLITS = SUBS >= 8 ? 4 : (SUBS >= 4 ? 8 : 16);      // keep ~1000 workgroups per launch at B = 32
       hipLaunchKernelGGL(nms_cross_kernel, dim3(B, SUBS, SPLITS), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, SPLITS, iou_threshold);
       EFFDET_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(nms_round_kernel, dim3(B), dim3(NT), lds, st, w.sbox, w.vals_out, w.kbox, w.nvalid, w.kept, w.dead, out_idx, A, r, iou_threshold);
+    hipLaunchKernelGGL(nms_round_kernel, dim3(B), dim3(NT), lds, st, w.sbox, w.vals_out, w.kbox, w.nvalid, w.kept, w.dead, out_idx, A, r, iou_threshold, kg);
     EFFDET_CHECK_LAUNCH();
   }
   if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
