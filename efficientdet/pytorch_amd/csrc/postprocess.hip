@@ -12,10 +12,11 @@
 //      are staged through LDS in 1024-box chunks and broadcast-read.
 //   3. Kernel B (one 1024-thread workgroup per image) finishes the round tile by tile: suppress
 //      by boxes kept earlier in this round, compact the survivors with wave ballots + prefix
-//      sums, build their (<=1024)^2 suppression bit-matrix in LDS (word-major, conflict-free) and
-//      resolve greedy order with a parallel fixed point: a survivor is KEPT once no earlier
-//      undecided survivor overlaps it, DEAD once an earlier kept one does -- exactly the
-//      sequential greedy result.  Kept boxes / indices are appended in order.
+//      sums, build their (<=1024)^2 suppression bit-matrix in LDS (word-major; (row, 8-column) work
+//      items dealt to all 1024 threads) and resolve the greedy order with one wave walking the rows
+//      in blocks of 64 (earlier kept words AND-ed against the row, then one ballot per kept box
+//      inside the block) -- exactly the sequential greedy result.  Kept boxes / indices are
+//      appended in order and filed into the kept-box grid.
 //   All loops are bounded by device-side counts; the host launches ceil(A/8192) rounds blindly.
 #include "common.h"
 #include <stdlib.h>
@@ -112,6 +113,8 @@ __device__ __forceinline__ bool suppresses(const float4& a, float aa, const floa
   const float ih = fminf(a.w, b.w) - fmaxf(a.y, b.y);
   if (iw <= 0.f || ih <= 0.f) return false;
   const float inter = iw * ih;
+  // (division-free forms -- bracketing products, or the exact f64 midpoint compare -- measured no faster: the phases that
+  //  call this are LDS/latency-bound, not VALU-bound)
   return inter / (aa + ab - inter) > thr;
 }
 
@@ -376,52 +379,58 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
     PROF_T(1);
     if (S == 0) continue;                                              // uniform
     // ---- suppression bit-matrix among the S survivors (row s, bits j < s), word-major in LDS ----
+    // Work items are (row, 8-column group) pairs dealt round-robin to all 1024 threads and OR-ed into the row's words: with
+    // one thread per ROW the last wave did S/8 steps while 13 of 16 waves idled (typical S ~ 150: 3 busy waves).
     const int nw = (S + 63) >> 6;
-    if (tid < S) {
-      const float4 mb = tb[tid]; const float mba = ta[tid];
-      for (int w = 0; w <= (tid >> 6); ++w) {          // trip count is wave-uniform (a wave = 64 consecutive rows)
-        unsigned long long bits = 0ull;
+    if (tid < S) for (int w = 0; w < nw; ++w) mask[(size_t)w * NT + tid] = 0ull;
+    __syncthreads();
+    {
+      const int G = (S + 7) >> 3;
+      const int items = S * G;
 #pragma unroll 1
-        for (int g8 = 0; g8 < 64; g8 += 8) {           // 8 pipelined LDS fetches + tests per step, no data-dependent exit
-          float4 q[8]; float qa[8];
+      for (int item = tid; item < items; item += NT) {
+        const int r = item / G, c0 = (item - r * G) << 3;
+        if (c0 >= r) continue;                         // only earlier survivors count
+        const float4 mb = tb[r]; const float mba = ta[r];
+        float4 q[8]; float qa[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) { q[u] = tb[w * 64 + g8 + u]; qa[u] = ta[w * 64 + g8 + u]; }
+        for (int u = 0; u < 8; ++u) { q[u] = tb[c0 + u]; qa[u] = ta[c0 + u]; }   // slots >= S (stale) land on bits >= r: dropped below
+        unsigned bits = 0u;
 #pragma unroll
-          for (int u = 0; u < 8; ++u) if (suppresses(mb, mba, q[u], qa[u], thr)) bits |= 1ull << (g8 + u);
-        }
-        // only earlier survivors count: bits j >= tid (incl. stale slots >= S, which lie above every valid row) are dropped
-        if (w == (tid >> 6)) bits &= (1ull << (tid & 63)) - 1ull;
-        mask[(size_t)w * NT + tid] = bits;
+        for (int u = 0; u < 8; ++u) if (suppresses(mb, mba, q[u], qa[u], thr)) bits |= 1u << u;
+        const int lim = r - c0;
+        if (lim < 8) bits &= (1u << lim) - 1u;
+        if (bits) atomicOr(&mask[(size_t)(c0 >> 6) * NT + r], (unsigned long long)bits << (c0 & 63));
       }
     }
     __syncthreads();
     PROF_T(2);
-    // ---- parallel fixed point == sequential greedy ----
-    int status = (tid < S) ? 0 : 2;          // 0 undecided, 1 kept, 2 dead/absent
-    for (int it = 0; it < NT + 1; ++it) {
-      int changed = 0;
-      if (status == 0) {
-        bool hit_kept = false, blocked = false;
-        for (int w = 0; w <= (tid >> 6); ++w) {
-          const unsigned long long m = mask[(size_t)w * NT + tid];
-          if (m & keptb[w]) { hit_kept = true; break; }
-          if (m & ~(keptb[w] | deadb[w])) blocked = true;
+    // ---- greedy order, resolved by ONE wave in blocks of 64 rows (a workgroup-wide fixed point needs ~chain-length
+    //      barrier rounds; here a block costs one pass over the earlier kept words + one ballot per box it keeps) ----
+    if (wave == 0) {
+      unsigned long long Kw[16];
+#pragma unroll
+      for (int blk = 0; blk < 16; ++blk) {
+        Kw[blk] = 0ull;
+        if (blk < nw) {                                  // uniform
+          const int r = blk * 64 + lane;
+          bool gone = r >= S;
+#pragma unroll
+          for (int w = 0; w < blk; ++w) if (mask[(size_t)w * NT + r] & Kw[w]) gone = true;
+          const unsigned long long diag = mask[(size_t)blk * NT + r];
+          unsigned long long cand = __ballot(!gone), keep = 0ull;
+          while (cand) {                                 // uniform
+            const int i = __builtin_ctzll(cand);
+            keep |= 1ull << i;
+            cand &= ~(__ballot((diag >> i) & 1ull) | (1ull << i));   // a row's bits only name earlier rows: lanes > i
+          }
+          Kw[blk] = keep;
+          if (lane == 0) keptb[blk] = keep;
         }
-        if (hit_kept) { status = 2; changed = 1; }
-        else if (!blocked) { status = 1; changed = 1; }
       }
-      __syncthreads();                       // everyone has read the old bit sets
-      if (changed) {
-        if (status == 1) atomicOr(&keptb[tid >> 6], 1ull << (tid & 63));
-        else atomicOr(&deadb[tid >> 6], 1ull << (tid & 63));
-      }
-      const int any_open = __syncthreads_or(status == 0);
-#ifdef EFFDET_NMS_PROF
-      if (tid == 0 && b == 0) nms_prof[7] += 1;
-#endif
-      if (!any_open) break;
-      (void)nw;
     }
+    __syncthreads();
+    const int status = (tid < S && ((keptb[tid >> 6] >> (tid & 63)) & 1ull)) ? 1 : 2;
     PROF_T(3);
 #ifdef EFFDET_NMS_PROF
     if (tid == 0 && b == 0) { nms_prof[5] += S; nms_prof[6] += 1; }

@@ -1,5 +1,5 @@
 export TMPDIR=/tmp; mkdir -p /root/repo/gpurun_out/d4
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/d4/stats -o run -- python /root/repo/tools/infer_bench.py --network efficientdet-d4 --batch 8 --size 1024 --reps 5 > /root/repo/gpurun_out/d4/log.txt 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/gpurun_out/d4/stats -o run -- python /root/repo/tools/infer_bench.py ${NET:---network efficientdet-d4 --batch 8 --size 1024} --reps 5 > /root/repo/gpurun_out/d4/log.txt 2>&1
 cd /root/repo; tail -3 gpurun_out/d4/log.txt; find gpurun_out/d4 -name "*kernel_trace.csv" -delete
 python - <<'PY'
 import csv,re
