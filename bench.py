@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--network', default='efficientdet-d0')
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32', 'f32_bf16x3'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-inference', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -98,12 +98,12 @@ def cpu_baseline(network, size, seconds_budget=25.0):
                       'one warm-up); config0 = B=1 forward, best of 3' % (network, B, size, size)}
 
 
-def build_model(network, dtype, dev, training):
+def build_model(network, dtype, dev, training, f32_arith='f32'):
     from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET
     cfg = EFFICIENTDET[network]
     torch.manual_seed(0)
     m = EfficientDet(num_classes=80, network=network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'], D_class=cfg['D_class'],
-                     is_training=training, compute_dtype=dtype).to(dev)
+                     is_training=training, compute_dtype=dtype, f32_arith=f32_arith).to(dev)
     if training:
         m.train(); m.is_training = True; m.freeze_bn()
     else:
@@ -113,7 +113,8 @@ def build_model(network, dtype, dev, training):
 
 def roofline_of(summ, dtype_name, batch, size):
     """Dominant MFMA kernel of one instrumented step (per-launch HIP events on the launch stream) against the dense peak."""
-    peak = BF16_MFMA_PEAK_TFLOPS if dtype_name == 'bf16' else F32_MFMA_PEAK_TFLOPS
+    # bf16x3: every algorithmic MAC costs three bf16 MFMA MACs -> the dense bf16 peak / 3 in algorithmic FLOP/s
+    peak = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f32': F32_MFMA_PEAK_TFLOPS, 'f32_bf16x3': round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)}[dtype_name]
     hbm = {k: v for k, v in summ.items() if not k.startswith('conv_')}       # byte-counted (HBM-bound) kernels
     mf = {k: v for k, v in summ.items() if k.startswith('conv_')}            # flop-counted MFMA kernels
     name, d = max(mf.items(), key=lambda kv: kv[1]['ms'])
@@ -148,7 +149,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     from efficientdet.pytorch_amd.optim import ClipAdamW
     from efficientdet.pytorch_amd.synthetic import synthetic_batch      # the package's own generator: the GPU legs are oracle-free
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
-    model = build_model(a.network, dtype, dev, True)
+    model = build_model(a.network, dtype, dev, True, 'bf16x3' if dtype_name == 'f32_bf16x3' else 'f32')
     ddp.freeze_dead_parameters(model)
     net = ddp.wrap(model, device_ids=[local]) if world > 1 else model
     params = [p for p in model.parameters() if p.requires_grad]
@@ -298,6 +299,15 @@ def main():
                               'steps': a.parity_steps, 'warmup': a.parity_warmup, 'final_loss': round(ploss, 4),
                               'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / pms, 2) if d0_512 else None,
                               'note': 'same step, fp32 storage + exact-fp32 MFMA: the 1e-3 parity mode', 'roofline': proof}
+        # ... and with fp32 storage + bf16x3 products on the MFMA kernels (operands split into bf16 hi + lo in registers, three
+        # bf16 MFMAs per product, fp32 accumulate): losses / gradient norms inside the same 1e-3 gates, outputs within 3e-4 of
+        # tensor scale of the reference (tests/test_gpu_model.py, mode f32_bf16x3)
+        xv, xms, xloss, xroof, _, _ = train_leg(a, 'f32_bf16x3', a.parity_steps, a.parity_warmup, rank, world, local, dev, not a.no_roofline)
+        out['parity_mode_bf16x3'] = {'dtype': 'f32 storage, bf16x3 MFMA products', 'value': round(xv, 2), 'unit': 'images/sec',
+                                     'ms_per_step': round(xms, 3), 'steps': a.parity_steps, 'warmup': a.parity_warmup,
+                                     'final_loss': round(xloss, 4),
+                                     'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / xms, 2) if d0_512 else None,
+                                     'roofline': xroof}
 
     if rank == 0 and world == 1 and not a.no_inference:
         dtype = torch.bfloat16 if a.dtype == 'bf16' else torch.float32

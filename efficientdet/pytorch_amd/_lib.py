@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
-F32, BF16 = 0, 1
+F32, BF16, F32_BF16X3 = 0, 1, 2      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only)
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
 TUNE_IGEMM_BIG, TUNE_IGEMM_BIG_MIN_M = 0, 1

@@ -73,8 +73,12 @@ template <> struct Mma<float> {
 // The 128x128 tile runs with 8 waves (wave tile 32x64): same 64 KiB of LDS, i.e. still 2 workgroups per CU, but
 // 4 waves per SIMD instead of 2 -- the kernel is latency-bound (PMC: 49 % of wave time in s_waitcnt/barrier at 2
 // waves/SIMD, 0 LDS bank conflicts, MFMA pipe 26 % busy), so thread-level parallelism is the lever.
-template <typename T, int BN, int WAVES_N, int NWAVES>
+// SPLIT (fp32 storage only): "bf16x3" arithmetic -- each fp32 operand value is split in registers into bf16 hi + bf16 lo
+// (x = hi + lo + O(2^-17 |x|)) and a K-step costs 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate)
+// per tile instead of 8 v_mfma_f32_16x16x4_f32: products carry ~16 mantissa bits, the matrix pipe does 3/8 of the passes.
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0>
 __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
+  static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
   constexpr int CE = Elem<T>::CE;
   constexpr int NTHREADS = NWAVES * 64;
   constexpr int WAVES_M = NWAVES / WAVES_N;
@@ -202,27 +206,88 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
       for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
   };
-  uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
-  stage(0);
-  if (nk > 1) stage(1);
-  dma_wait_all();
-  __syncthreads();
-  load(0, 0, wfA, xfA);
-  for (int kt = 0; kt + 1 < nk; ++kt) {  // (last K-step peeled: a conditional barrier block would make hipcc merge the
-    const int cur = kt & 1;              //  LDS counters of both paths and wait for the A fragments before the B MFMAs)
-    load(cur, 1, wfB, xfB);
-    __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads AHEAD of the MFMAs they hide under (hipcc sinks them otherwise)
+  if constexpr (SPLIT) {
+    // one slice per K-step: lane (row, lq) takes chunks lq and 4 + lq = 8 floats -> one 16x16x32 operand (any k <-> lane
+    // assignment works as long as both operands share it).  Register double buffer across K-steps: the reads + splits
+    // of tile t+1 are issued ahead of the MFMAs of tile t; one barrier per K-step as below.
+    struct Frags { uint4 wh[NT], wl[NT], xh[MT], xl[MT]; };
+    auto split8 = [](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+      const unsigned v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+      unsigned h[4], l[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = __uint_as_float(v[2 * i]), b = __uint_as_float(v[2 * i + 1]);
+        h[i] = pack2bf(a, b);                                                      // RNE, one instruction per pair
+        l[i] = pack2bf(a - __uint_as_float(h[i] << 16), b - __uint_as_float(h[i] & 0xffff0000u));   // exact differences
+      }
+      hi = make_uint4(h[0], h[1], h[2], h[3]); lo = make_uint4(l[0], l[1], l[2], l[3]);
+    };
+    auto loadsp = [&](int buf, Frags& f) {
+      // weights arrive pre-split (pack.hip, store_x3): chunk lq = hi, chunk 4 + lq = lo of k = 8*lq .. 8*lq+7 -- so the
+      // activation side takes the same k: chunks 2*lq, 2*lq + 1 (both conflict-free under the (row>>1)&7 swizzle)
+#pragma unroll
+      for (int a = 0; a < NT; ++a) {
+        const int r = buf * WLD + (wn0 + a * 16 + l15) * 8;
+        f.wh[a] = ws[r + (lq ^ lsw)]; f.wl[a] = ws[r + ((4 + lq) ^ lsw)];
+      }
+#pragma unroll
+      for (int b = 0; b < MT; ++b) {
+        const int r = buf * XLD + (wm0 + b * 16 + l15) * 8;
+        split8(xs[r + ((2 * lq) ^ lsw)], xs[r + ((2 * lq + 1) ^ lsw)], f.xh[b], f.xl[b]);
+      }
+    };
+    auto mmasp = [&](const Frags& f) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+          Mma<bf16_t>::run(f.wl[a], f.xh[b], acc[a][b]);
+          Mma<bf16_t>::run(f.wh[a], f.xl[b], acc[a][b]);
+          Mma<bf16_t>::run(f.wh[a], f.xh[b], acc[a][b]);
+        }
+    };
+    Frags fA, fB;
+    auto kstep = [&](int kt, const Frags& cur, Frags& nxt) {
+      const int c = kt & 1;
+      dma_wait_all();                      // tile kt+1 has landed (this wave's pieces, then everyone's) and every wave
+      __syncthreads();                     // holds tile kt in registers: buffer c is free
+      if (kt + 2 < nk) stage(c);
+      loadsp(c ^ 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      mmasp(cur);
+    };
+    stage(0);
+    if (nk > 1) stage(1);
+    dma_wait_all();
+    __syncthreads();
+    loadsp(0, fA);
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) { kstep(kt, fA, fB); kstep(kt + 1, fB, fA); }
+    if (kt + 1 < nk) { kstep(kt, fA, fB); mmasp(fB); } else mmasp(fA);
+  } else {
+    uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
+    stage(0);
+    if (nk > 1) stage(1);
+    dma_wait_all();
+    __syncthreads();
+    load(0, 0, wfA, xfA);
+    for (int kt = 0; kt + 1 < nk; ++kt) {  // (last K-step peeled: a conditional barrier block would make hipcc merge the
+      const int cur = kt & 1;              //  LDS counters of both paths and wait for the A fragments before the B MFMAs)
+      load(cur, 1, wfB, xfB);
+      __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads AHEAD of the MFMAs they hide under (hipcc sinks them otherwise)
+      mma(wfA, xfA);
+      dma_wait_all();                      // this wave's pieces of tile kt+1 have landed ...
+      __syncthreads();                     // ... and everyone's; every wave holds its last fragments of tile kt in registers
+      if (kt + 2 < nk) stage(cur);         // refill the buffer just drained (asm DMA: no compiler-inserted drain)
+      load(cur ^ 1, 0, wfA, xfA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(wfB, xfB);
+    }
+    load((nk - 1) & 1, 1, wfB, xfB);
     mma(wfA, xfA);
-    dma_wait_all();                      // this wave's pieces of tile kt+1 have landed ...
-    __syncthreads();                     // ... and everyone's; every wave holds its last fragments of tile kt in registers
-    if (kt + 2 < nk) stage(cur);         // refill the buffer just drained (asm DMA: no compiler-inserted drain)
-    load(cur ^ 1, 0, wfA, xfA);
-    __builtin_amdgcn_sched_barrier(0);
     mma(wfB, xfB);
+
   }
-  load((nk - 1) & 1, 1, wfB, xfB);
-  mma(wfA, xfA);
-  mma(wfB, xfB);
 
   // ---- epilogue: lane holds channels n0..n0+3 (rows of D) of pixel m (column of D) ----
   // (An LDS-transposed variant with full-row 16-byte stores was measured: no gain -- PMC showed the epilogue of the
@@ -676,26 +741,26 @@ static int big_variant() {
   return g_tuning[EFFDET_TUNE_IGEMM_BIG];
 }
 
-template <typename T, int BN, int WAVES_N, int NWAVES>
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0>
 int launch(const ConvK& k, hipStream_t st) {
   const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);                     // double-buffered operand tiles
   const int grid = k.mtiles * k.ntiles;
-  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES>), lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
+  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT>), lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
-template <typename T>
+template <typename T, int SPLIT = 0>
 int dispatch(ConvK& k, hipStream_t st) {
   int bn;
   if (k.Cout > 64) bn = 128; else if (k.Cout > 32) bn = 64; else if (k.Cout > 16) bn = 32; else bn = 16;
   k.ntiles = (k.Cout + bn - 1) / bn;
   switch (bn) {
-    case 128: return launch<T, 128, 2, 8>(k, st);
-    case 64: return launch<T, 64, 1, 4>(k, st);
-    case 32: return launch<T, 32, 1, 4>(k, st);
-    default: return launch<T, 16, 1, 4>(k, st);
+    case 128: return launch<T, 128, 2, 8, SPLIT>(k, st);
+    case 64: return launch<T, 64, 1, 4, SPLIT>(k, st);
+    case 32: return launch<T, 32, 1, 4, SPLIT>(k, st);
+    default: return launch<T, 16, 1, 4, SPLIT>(k, st);
   }
 }
 
@@ -715,8 +780,8 @@ extern "C" int effdet_tuning_set(int key, int value) {
 static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   if (!p || !p->x || !p->w || !p->y) return EFFDET_EINVAL;
   if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
-  if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
-  const int ce = p->dtype == EFFDET_F32 ? 4 : 8;
+  if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16 && p->dtype != EFFDET_F32_BF16X3) return EFFDET_EINVAL;
+  const int ce = p->dtype == EFFDET_BF16 ? 8 : 4;
   if (p->Cin % ce || p->ldx % ce || p->KH < 1 || p->KW < 1 || p->stride < 1) return EFFDET_EUNSUPPORTED;
   if (p->res_mode != EFFDET_RES_NONE && !p->res) return EFFDET_EINVAL;
   if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
@@ -744,7 +809,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
   k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
   // byte extents actually addressed through each segment's SRD (32-bit offsets): refuse tensors beyond 4 GiB - 64 KiB
-  const long long es = p->dtype == EFFDET_F32 ? 4 : 2;
+  const long long es = p->dtype == EFFDET_BF16 ? 2 : 4;
   for (int s = 0; s < p->nseg; ++s) {
     const effdet_seg_t& g = p->seg[s];
     const long long e = ((long long)(p->B - 1) * g.in_bstride + ((long long)(g.H - 1) * g.W + (g.W - 1)) * p->ldx + p->Cin) * es;
@@ -775,7 +840,9 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       }
     }
   }
-  return k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
+  const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
+  if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
+  return bt;
 }
 
 extern "C" int effdet_conv2d_kernel(const effdet_conv_t* p) {
@@ -797,5 +864,6 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     case 10 + 4230: return launch_pers<4, 2, 3>(k, st);
     default: break;
   }
-  return p->dtype == EFFDET_F32 ? dispatch<float>(k, st) : dispatch<bf16_t>(k, st);
+  if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
+  return p->dtype == EFFDET_BF16 ? dispatch<bf16_t>(k, st) : dispatch<float>(k, st);
 }

@@ -487,7 +487,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
 //   cursor is scalar per wave, border validity an OR of precomputed 64-bit lane masks (same scheme as the bf16 kernel).
 // Eligibility (host, per pyramid level): stride 1, 'same' geometry with taps in [-1, 1], 16-byte aligned rows, and a piece's
 // two pixels in one image row (Wo even) or two whole rows (Wo = 1, Ho even); contiguous pointwise convs = one long row.
-template <int NW>
+// X3 = 1 (EFFDET_F32_BF16X3): the same staging and fragment reads, but a whole 32-pixel stage feeds ONE set of
+// v_mfma_f32_16x16x32_bf16: lane (c, k) gathers its 8 stage pixels 4e + k (e = 0..7, the eight reads the fp32 form issues
+// k-step by k-step; the k-slot <-> pixel map is shared by both operands), splits each value into bf16 hi + lo in registers
+// and the tile costs 3 MFMAs per stage (hi*hi + hi*lo + lo*hi) instead of 8 v_mfma_f32_16x16x4_f32.
+template <int NW, int X3 = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK p) {
   constexpr int WJ = NW / 2;                    // waves along j (2 along n)
   constexpr int WTJ = 128 / WJ, JB = WTJ / 16;  // j per wave (64 | 32), B tiles per wave = floats per lane of the B read (4 | 2)
@@ -574,37 +578,100 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
 
   if (nsteps > 0) {
     stage(0);
-    for (int kt = 0; kt < nsteps; ++kt) {
-      const unsigned cur = (unsigned)(kt & 1) * BUFB;
-      dma_wait_all();
-      __syncthreads();
-      if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
-      // fragments of k-step ks+1 are read BEFORE the 16 MFMAs of k-step ks (register double buffer): the LDS round trip
-      // hides under 512 cycles of matrix work instead of preceding it
-      auto lda = [&](int ks) -> f32x4 { return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(a_addr + cur + (unsigned)ks * 2048u); };
-      auto ldb = [&](int ks) -> f32x4 {
-        if constexpr (JB == 4) return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
-        else {
-          typedef float f32x2l __attribute__((ext_vector_type(2)));
-          const f32x2l t = *(const f32x2l __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
-          return f32x4{t[0], t[1], 0.f, 0.f};
-        }
-      };
-      f32x4 av = lda(0), bv = ldb(0);
+    if constexpr (X3) {
+      typedef float f32x2l __attribute__((ext_vector_type(2)));
+      auto split8 = [](const float (&v)[8], uint4& hi, uint4& lo) {
+        unsigned h[4], l[4];
 #pragma unroll
-      for (int ks = 0; ks < BKM / 4; ++ks) {
-        f32x4 an = av, bn = bv;
-        if (ks + 1 < BKM / 4) { an = lda(ks + 1); bn = ldb(ks + 1); }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 4; ++i) {
+          h[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+          l[i] = pack2bf(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+        }
+        hi = make_uint4(h[0], h[1], h[2], h[3]); lo = make_uint4(l[0], l[1], l[2], l[3]);
+      };
+      auto mm = [](const uint4& a, const uint4& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+      };
+      const uint4 ones = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+      uint4 ah[4], al[4], bh[JB], bl[JB];
+      bool have = false;
+      auto mma_stage = [&]() {
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-          for (int b = 0; b < JB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < JB; ++b) { mm(al[a], bh[b], acc[a][b]); mm(ah[a], bl[b], acc[a][b]); mm(ah[a], bh[b], acc[a][b]); }
         if (want_bias) {
 #pragma unroll
-          for (int a = 0; a < 4; ++a) bsum[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], 1.0f, bsum[a], 0, 0, 0);
+          for (int a = 0; a < 4; ++a) { mm(al[a], ones, bsum[a]); mm(ah[a], ones, bsum[a]); }
         }
-        av = an; bv = bn;
+      };
+      for (int kt = 0; kt < nsteps; ++kt) {
+        const unsigned cur = (unsigned)(kt & 1) * BUFB;
+        dma_wait_all();
+        __syncthreads();
+        if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+        // raw reads of this stage first, the previous stage's MFMAs under their LDS round trip, then the splits
+        f32x4 ra[8]; float rb[8][JB];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ra[e] = *(const f32x4 __attribute__((address_space(3)))*)(size_t)(a_addr + cur + (unsigned)e * 2048u);
+          if constexpr (JB == 4) {
+            const f32x4 t = *(const f32x4 __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)e * 2048u);
+#pragma unroll
+            for (int b = 0; b < JB; ++b) rb[e][b] = t[b];
+          } else {
+            const f32x2l t = *(const f32x2l __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)e * 2048u);
+            rb[e][0] = t[0]; rb[e][1] = t[1];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (have) mma_stage();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const float v[8] = {ra[0][a], ra[1][a], ra[2][a], ra[3][a], ra[4][a], ra[5][a], ra[6][a], ra[7][a]};
+          split8(v, ah[a], al[a]);
+        }
+#pragma unroll
+        for (int b = 0; b < JB; ++b) {
+          const float v[8] = {rb[0][b], rb[1][b], rb[2][b], rb[3][b], rb[4][b], rb[5][b], rb[6][b], rb[7][b]};
+          split8(v, bh[b], bl[b]);
+        }
+        have = true;
+      }
+      mma_stage();
+    } else {
+      for (int kt = 0; kt < nsteps; ++kt) {
+        const unsigned cur = (unsigned)(kt & 1) * BUFB;
+        dma_wait_all();
+        __syncthreads();
+        if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+        // fragments of k-step ks+1 are read BEFORE the 16 MFMAs of k-step ks (register double buffer): the LDS round trip
+        // hides under 512 cycles of matrix work instead of preceding it
+        auto lda = [&](int ks) -> f32x4 { return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(a_addr + cur + (unsigned)ks * 2048u); };
+        auto ldb = [&](int ks) -> f32x4 {
+          if constexpr (JB == 4) return *(const f32x4 __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
+          else {
+            typedef float f32x2l __attribute__((ext_vector_type(2)));
+            const f32x2l t = *(const f32x2l __attribute__((address_space(3)))*)(size_t)(b_addr + cur + (unsigned)ks * 2048u);
+            return f32x4{t[0], t[1], 0.f, 0.f};
+          }
+        };
+        f32x4 av = lda(0), bv = ldb(0);
+  #pragma unroll
+        for (int ks = 0; ks < BKM / 4; ++ks) {
+          f32x4 an = av, bn = bv;
+          if (ks + 1 < BKM / 4) { an = lda(ks + 1); bn = ldb(ks + 1); }
+          __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+          for (int a = 0; a < 4; ++a)
+  #pragma unroll
+            for (int b = 0; b < JB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+          if (want_bias) {
+  #pragma unroll
+            for (int a = 0; a < 4; ++a) bsum[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], 1.0f, bsum[a], 0, 0, 0);
+          }
+          av = an; bv = bn;
+        }
       }
     }
     // D[i][c] of tile (a, b): row i = 4*(l>>4) + reg stands for channel 4i + a, column c = l & 15 for j = JB*c + b
@@ -725,13 +792,19 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
 }
 }  // namespace
 
+// EFFDET_F32_BF16X3 (fp32 storage, split-bf16 products): same storage geometry as EFFDET_F32
+#define WGRAD_NORMALISE_DTYPE(p, q) effdet_wgrad_t q; bool q##_x3 = false; \
+  if (p) { q = *p; if (q.dtype == EFFDET_F32_BF16X3) { q.dtype = EFFDET_F32; q##_x3 = true; } p = &q; } (void)q##_x3
+
 extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p) {
+  WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   if (plan(p, k, splits) != EFFDET_OK) return -1;
   return (long long)splits * p->Cout * k.K * (long long)sizeof(float);
 }
 
 extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
+  WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   if (plan(p, k, splits) != EFFDET_OK) return -1;
   return splits;
@@ -771,11 +844,16 @@ constexpr int TR_NW = EFFDET_WGRAD_TR_WAVES;
 #define EFFDET_WGRAD_F32_WAVES 8
 #endif
 constexpr int F32_NW = EFFDET_WGRAD_F32_WAVES;
+#ifndef EFFDET_WGRAD_X3_WAVES
+#define EFFDET_WGRAD_X3_WAVES 4
+#endif
+constexpr int X3_NW = EFFDET_WGRAD_X3_WAVES;
 }  // namespace
 
 extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
                                    effdet_stream_t stream) {
   if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
+  WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   const int rc = plan(p, k, splits);
   if (rc != EFFDET_OK) return rc;
@@ -806,7 +884,11 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   for (int s = ns; s < EFFDET_MAX_SEG; ++s) { ks.seg[s] = ks.seg[0]; ks.seg[s].split_start = 0x7fffffff; }
   kf.nseg = nf; ks.nseg = ns;
   ks.slab = k.slab + (long long)sf * n;
-  if (nf > 0 && p->dtype == EFFDET_F32) {
+  if (nf > 0 && p->dtype == EFFDET_F32 && pn_x3) {
+    EFFDET_SET_MAX_LDS((conv_wgrad_f32dma_kernel<X3_NW, 1>), lds);
+    hipLaunchKernelGGL((conv_wgrad_f32dma_kernel<X3_NW, 1>), dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(X3_NW * 64), lds, st, kf);
+    EFFDET_CHECK_LAUNCH();
+  } else if (nf > 0 && p->dtype == EFFDET_F32) {
     EFFDET_SET_MAX_LDS((conv_wgrad_f32dma_kernel<F32_NW>), lds);
     hipLaunchKernelGGL(conv_wgrad_f32dma_kernel<F32_NW>, dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(F32_NW * 64), lds, st, kf);
     EFFDET_CHECK_LAUNCH();

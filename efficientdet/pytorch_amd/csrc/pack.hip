@@ -20,9 +20,20 @@ __device__ __forceinline__ float pack_elem(const float* __restrict__ w, long lon
   return v;
 }
 
+// EFFDET_F32_BF16X3 operand layout: the packed row (K = taps * Kpad fp32 slots, K % 32 == 0) keeps its byte size, but every
+// 128-byte group of 32 values holds [32 x bf16 hi | 32 x bf16 lo] (v = hi + lo + O(2^-17 |v|)): the implicit-GEMM K-step is
+// one such group, so a lane's two 16-byte fragment reads ARE the hi and lo operands of k = 8*lq .. 8*lq+7 -- the weight side
+// of the bf16x3 kernel needs no splitting VALU.
+__device__ __forceinline__ void store_x3(void* out, long long i, long long K, float v) {
+  const long long row = i / K, k = i - row * K;
+  const bf16_t hi = f2bf(v), lo = f2bf(v - bf2f(hi));
+  bf16_t* o = (bf16_t*)out + row * 2 * K + (k >> 5) * 64 + (k & 31);
+  o[0] = hi; o[32] = lo;
+}
+
 // mode 0: out[co][tap][ci]            = w[co][ci][kh][kw] * scale[co]
 // mode 1: out[ci][tap flipped][co]    = w[co][ci][KH-1-kh][KW-1-kw] * scale[co]   (data-gradient operand)
-template <typename T>
+template <typename T, bool X3 = false>
 __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restrict__ scale, T* __restrict__ out,
                               int mode, int Cout, int Cin, int KH, int KW, int Cin_pad) {
   const int taps = KH * KW;
@@ -30,7 +41,9 @@ __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restri
   const long long total = mode == 0 ? (long long)Cout * Cin_pad * taps : (long long)Cin * Cin_pad * taps;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     // i indexes the OUTPUT (coalesced writes); padding entries are zero
-    Elem<T>::st(out + i, pack_elem(w, i, mode, Cout, Cin, KH, KW, Cin_pad, scale, nullptr, nullptr, 0.f));
+    const float v = pack_elem(w, i, mode, Cout, Cin, KH, KW, Cin_pad, scale, nullptr, nullptr, 0.f);
+    if constexpr (X3) store_x3(out, i, (long long)Cin_pad * taps, v);
+    else Elem<T>::st(out + i, v);
   }
 }
 
@@ -46,7 +59,9 @@ __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_j
     const long long total = (long long)(mode == 0 ? jb.n0 : jb.n1) * jb.n4 * jb.n2 * jb.n3;
     if (i >= total) return;
     const float v = pack_elem(jb.a, i, mode, jb.n0, jb.n1, jb.n2, jb.n3, jb.n4, nullptr, jb.b, jb.c, jb.eps);
-    if (jb.dtype == EFFDET_F32) ((float*)jb.out)[i] = v; else ((bf16_t*)jb.out)[i] = f2bf(v);
+    if (jb.dtype == EFFDET_F32) ((float*)jb.out)[i] = v;
+    else if (jb.dtype == EFFDET_F32_BF16X3) store_x3(jb.out, i, (long long)jb.n4 * jb.n2 * jb.n3, v);
+    else ((bf16_t*)jb.out)[i] = f2bf(v);
   } else if (jb.kind == EFFDET_PREP_BNFOLD) {
     if (i >= jb.n0) return;
     const float is = 1.0f / sqrtf(jb.d[i] + jb.eps);
@@ -210,7 +225,10 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
     hipLaunchKernelGGL(pack_w_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
   else if (dtype == EFFDET_BF16)
     hipLaunchKernelGGL(pack_w_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, w, scale, (bf16_t*)out, mode, Cout, Cin, KH, KW, Cin_pad);
-  else return EFFDET_EINVAL;
+  else if (dtype == EFFDET_F32_BF16X3) {
+    if (((long long)Cin_pad * KH * KW) % 32) return EFFDET_EUNSUPPORTED;
+    hipLaunchKernelGGL((pack_w_kernel<float, true>), dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
+  } else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -308,7 +308,7 @@ class _HeadLossFn(torch.autograd.Function):
 # --------------------------------------------------------------------------- the model
 class EfficientDet(nn.Module):
     def __init__(self, num_classes, network='efficientdet-d0', D_bifpn=3, W_bifpn=88, D_class=3, is_training=True,
-                 threshold=0.01, iou_threshold=0.5, compute_dtype=torch.float32):
+                 threshold=0.01, iou_threshold=0.5, compute_dtype=torch.float32, f32_arith='f32'):
         super().__init__()
         self.backbone = _Backbone(MODEL_MAP[network])          # KeyError on a bad name, like the reference
         self.is_training = is_training
@@ -319,6 +319,10 @@ class EfficientDet(nn.Module):
         self.iou_threshold = iou_threshold
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
+        # MFMA arithmetic on fp32 storage: 'f32' = exact fp32 products (v_mfma_f32_16x16x4_f32), 'bf16x3' = operands split into
+        # bf16 hi + lo, three bf16 MFMAs per product (~16 mantissa bits; ~2x the fp32 matrix-pipe rate).  Ignored for bf16.
+        assert f32_arith in ('f32', 'bf16x3')
+        self.f32_arith = f32_arith
         self._prep = {}                                         # (compute dtype, device) -> ops.ParamPrep (batched per-step repacks)
         self._dc = {}                                           # drop_connect generator state (seed, step counter, per-device keep table)
         self.batched_prep = True                                # False: every repack is its own launch (debug / A-B)
@@ -401,12 +405,13 @@ class EfficientDet(nn.Module):
     def _backbone(self, img):
         bb, dt = self.backbone, self.compute_dtype
         # every forward path starts here: replay (or start recording) this model's batched parameter preparation
-        key = (dt, img.device)
+        key = (dt, img.device, self.f32_arith)
+        ops.set_f32_arith(self.f32_arith)
         if not self.batched_prep:
             ops.set_prep(None)
         else:
             if key not in self._prep:
-                self._prep[key] = ops.ParamPrep()
+                self._prep[key] = ops.ParamPrep(self.f32_arith)
             ops.set_prep(self._prep[key])
             self._prep[key].begin_step(img.device)
         bn = bb._bn0

@@ -41,12 +41,40 @@ def _timed(name, flops, fn, note=''):
     return r
 
 
+# Arithmetic of the MFMA kernels on fp32 STORAGE (process-wide; EfficientDet(..., f32_arith=...) sets it):
+#   'f32'    v_mfma_f32_16x16x4_f32 -- exact fp32 products (the strict parity mode)
+#   'bf16x3' operands split into bf16 hi + lo in registers, 3 bf16 MFMAs per product (~16 mantissa bits), fp32 accumulate
+F32_ARITH = 'f32'
+
+
+def set_f32_arith(mode):
+    global F32_ARITH
+    if mode not in ('f32', 'bf16x3'):
+        raise ValueError("f32_arith must be 'f32' or 'bf16x3'")
+    old, F32_ARITH = F32_ARITH, mode
+    return old
+
+
+def _mma_dtype_code(dtype, K=None, N=None):
+    """dtype code of an MFMA launch.  For the dense conv (K, N given) the bf16x3 form also needs weights packed in its
+    pre-split layout, so the SAME rule decides the pack (pack_weight) and the launch (conv2d): reduction length a
+    multiple of 32 and long enough for the matrix pipe to be the bound."""
+    code = L.dtype_code(dtype)
+    if code != L.F32 or F32_ARITH != 'bf16x3':
+        return code
+    if K is not None and (K % 32 or K < 256 or N < 32):
+        return code
+    return L.F32_BF16X3
+
+
 def _igemm_symbol(dtype, desc):
     """Kernel symbol the library will launch for this descriptor (profiling attribution only)."""
     kid = int(L.lib().effdet_conv2d_kernel(C.byref(desc)))
     if kid >= 10:
         v = str(kid - 10)
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % (v[0], v[1], v[2])
+    if 4 <= kid < 8:
+        return 'conv_igemm_kernel<f32,%d,bf16x3>' % (128, 64, 32, 16)[kid - 4]
     return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', (128, 64, 32, 16)[max(kid, 0)])
 
 
@@ -108,7 +136,8 @@ class ParamPrep:
     must be stable (it is under in-place optimizers, load_state_dict and DDP); the owner drops the table when the
     module is moved (nn.Module._apply).  A lookup miss falls back to the single launch and re-records."""
 
-    def __init__(self):
+    def __init__(self, f32_arith='f32'):
+        self.f32_arith = f32_arith          # arithmetic of the owner's MFMA launches on fp32 storage (see set_f32_arith)
         self.jobs, self.outs, self.bn_src = {}, {}, {}
         self.table, self.dirty, self.replay = None, False, False
         self.zbuf, self.zpos, self.zreq, self.zsize = None, 0, 0, 0
@@ -142,9 +171,9 @@ class ParamPrep:
     def lookup(self, key):
         return self.outs.get(key) if self.replay else None
 
-    def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0):
+    def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0, code=None):
         if key not in self.jobs:
-            self.jobs[key] = (kind, srcs, dims, dtype, shape, eps)
+            self.jobs[key] = (kind, srcs, dims, dtype, shape, eps, L.dtype_code(dtype) if code is None else code)
             self.dirty = True
 
     def _build(self):
@@ -153,7 +182,7 @@ class ParamPrep:
         dev = self.jobs[keys[0]][1][0].device
         offs, total = [], 0
         for k in keys:
-            kind, srcs, dims, dtype, shape, eps = self.jobs[k]
+            kind, srcs, dims, dtype, shape, eps, _ = self.jobs[k]
             n = 1
             for d in shape:
                 n *= d
@@ -163,13 +192,13 @@ class ParamPrep:
         block_job, block_first, nb = [], [], 0
         self.outs, self.bn_src = {}, {}      # (drop the pointers of record-time temporaries)
         for i, k in enumerate(keys):
-            kind, srcs, dims, dtype, shape, eps = self.jobs[k]
+            kind, srcs, dims, dtype, shape, eps, code = self.jobs[k]
             off, n = offs[i]
             out = arena[off:off + n * (2 if dtype == torch.bfloat16 else 4)].view(dtype).view(shape)
             j = arr[i]
             ptrs = [t.data_ptr() if t is not None else None for t in srcs] + [None] * (4 - len(srcs))
             j.a, j.b, j.c, j.d = ptrs[:4]
-            j.out, j.kind, j.dtype, j.eps = out.data_ptr(), kind, L.dtype_code(dtype), eps
+            j.out, j.kind, j.dtype, j.eps = out.data_ptr(), kind, code, eps
             j.n0, j.n1, j.n2, j.n3, j.n4 = (list(dims) + [0] * 5)[:5]
             blocks = (n + 255) // 256
             block_first.append(nb); block_job += [i] * blocks; nb += blocks
@@ -187,6 +216,8 @@ _tls = threading.local()     # .prep: the ParamPrep of the model whose forward /
 
 def set_prep(p):
     _tls.prep = p
+    if p is not None:
+        set_f32_arith(p.f32_arith)          # forward and (through ctx.prep) backward of a model run in ITS arithmetic
 
 
 def get_prep():
@@ -213,18 +244,19 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
     if cin_pad is None:
         cin_pad = Cin if mode == 0 else Cout
     shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, cin_pad)
+    code = _mma_dtype_code(dtype, KH * KW * cin_pad, shape[0])
     PREP = get_prep()
     if PREP is not None:
         bn = PREP.bn_src.get(scale.data_ptr()) if scale is not None else None
         if scale is None or bn is not None:
-            key = ('pack', w.data_ptr(), mode, dtype, cin_pad, scale is not None)
+            key = ('pack', w.data_ptr(), mode, dtype, cin_pad, scale is not None, code)
             hit = PREP.lookup(key)
             if hit is not None:
                 return hit
             PREP.record(key, PREP_PACK1 if mode else PREP_PACK0, (w, bn[0] if bn else None, bn[1] if bn else None),
-                        (Cout, Cin, KH, KW, cin_pad), dtype, shape, bn[2] if bn else 0.0)
+                        (Cout, Cin, KH, KW, cin_pad), dtype, shape, bn[2] if bn else 0.0, code)
     out = torch.empty(shape, dtype=dtype, device=w.device)
-    L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), L.dtype_code(dtype), mode,
+    L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), code, mode,
                                             Cout, Cin, KH, KW, cin_pad, L.stream_ptr()), 'effdet_pack_conv_weight')
     return out
 
@@ -255,7 +287,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
             assert (r.addr() - br) * isy == (y.addr() - base_y) * r.t.element_size() and r.ld == y.ld and r.bstride == y.bstride
         d.res = br
     d.scale, d.shift, d.rowscale = (t.data_ptr() if t is not None else None for t in (scale, shift, rowscale))
-    d.dtype, d.out_f32 = L.dtype_code(x0.dtype), int(out_f32)
+    d.dtype, d.out_f32 = _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout), int(out_f32)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.ldy = x0.ld, y0.ld
@@ -281,7 +313,7 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     d.x, d.dz = base_x, base_z
     d.dw = dw.data_ptr() if dw is not None else None
     d.dbias = dbias.data_ptr() if dbias is not None else None
-    d.dtype = L.dtype_code(x0.dtype)
+    d.dtype = _mma_dtype_code(x0.dtype)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.lddz = x0.ld, z0.ld
@@ -293,7 +325,8 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     slabs = torch.empty((splits, Cout, KH * KW, Cin), dtype=torch.float32, device=x0.t.device)
     nbytes = slabs.numel() * 4
     # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
-    _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else 'conv_wgrad_f32dma_kernel<8>', flops,
+    _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else
+           ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>'), flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(slabs), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))

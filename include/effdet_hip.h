@@ -24,7 +24,13 @@ extern "C" {
 typedef void* effdet_stream_t; /* hipStream_t */
 
 enum { EFFDET_OK = 0, EFFDET_EINVAL = -1, EFFDET_ELAUNCH = -2, EFFDET_EUNSUPPORTED = -3 };
-enum { EFFDET_F32 = 0, EFFDET_BF16 = 1 };
+enum { EFFDET_F32 = 0, EFFDET_BF16 = 1,
+       /* effdet_conv2d / effdet_conv2d_wgrad only: fp32 STORAGE (every pointer as for EFFDET_F32), products formed as
+        * bf16x3 -- each operand value split in registers into bf16 hi + bf16 lo, hi*hi + hi*lo + lo*hi on
+        * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per product; 3/8 of the matrix-pipe passes
+        * of v_mfma_f32_16x16x4_f32).  effdet_conv2d: KH*KW*Cin % 32 == 0 and w packed by effdet_pack_conv_weight /
+        * EFFDET_PREP_PACK* with this same dtype (pre-split [32 x hi | 32 x lo] groups, same byte size as fp32). */
+       EFFDET_F32_BF16X3 = 2 };
 enum { EFFDET_ACT_NONE = 0, EFFDET_ACT_RELU = 1, EFFDET_ACT_SWISH = 2, EFFDET_ACT_SIGMOID = 3 };
 /* what the `res` tensor of a conv does in the epilogue */
 enum { EFFDET_RES_NONE = 0, EFFDET_RES_ADD = 1, EFFDET_RES_RELU_MASK = 2, EFFDET_RES_SWISH_GRAD = 3 };

@@ -16,8 +16,10 @@ ap.add_argument('--dtype', default='bf16')
 ap.add_argument('--cin', type=int, default=256)
 ap.add_argument('--cout', type=int, default=256)
 ap.add_argument('--which', default='fwd,wgrad')
+ap.add_argument('--arith', default='f32', help="fp32 storage: 'f32' or 'bf16x3' products")
 a = ap.parse_args()
 dt = torch.bfloat16 if a.dtype == 'bf16' else torch.float32
+ops.set_f32_arith(a.arith)
 dev = 'cuda'
 sizes = [(int(v), int(v)) for v in os.environ.get('KB_SIZES', '64,32,16,8,4').split(',')]
 _, x = Fn.pyramid_alloc(a.B, sizes, a.cin, dt, dev)

@@ -16,9 +16,12 @@ ap.add_argument('--reps', type=int, default=20)
 ap.add_argument('--variants', default='0,442,242')
 ap.add_argument('--kord', type=int, default=0)
 ap.add_argument('--only', type=int, default=-1, help='run only shape #i')
+ap.add_argument('--f32', default='', help="fp32 storage: 'f32' or 'bf16x3' arithmetic")
 ap.add_argument('--zeros', action='store_true', help='zero-filled operands (DVFS / data-toggling probe)')
 a = ap.parse_args()
-dt, dev = torch.bfloat16, 'cuda'
+dt, dev = (torch.float32 if a.f32 else torch.bfloat16), 'cuda'
+if a.f32:
+    ops.set_f32_arith(a.f32)
 ops.tuning_set(3, a.kord)
 sizes = [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)]
 M = sum(a.B * h * w for h, w in sizes)
