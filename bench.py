@@ -226,10 +226,10 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img, graphed is not None
 
 
-def inference_leg(network, dtype, dev, img, reps=5, graph=True):
+def inference_leg(network, dtype, dev, img, reps=5, graph=True, f32_arith='f32'):
     """eval forward + decode + per-image NMS (thr 0.01, IoU 0.5) on RANDOM-INIT weights: every anchor passes the threshold = the
     NMS worst case.  -> (ms/img end to end, ms/img forward only, kept boxes of image 0)."""
-    model = build_model(network, dtype, dev, False)
+    model = build_model(network, dtype, dev, False, f32_arith)
     B = img.shape[0]
     with torch.no_grad():
         for _ in range(2):
@@ -318,6 +318,8 @@ def main():
         if a.dtype == 'bf16' and not a.no_parity_mode:
             ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3, graph=not a.no_graph)
             out['inference']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+            ti, tf, kept = inference_leg(a.network, torch.float32, dev, img, reps=3, graph=not a.no_graph, f32_arith='bf16x3')
+            out['inference']['parity_mode_bf16x3'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
         del img
         torch.cuda.empty_cache()
         if not a.no_d4:
@@ -330,6 +332,8 @@ def main():
             if a.dtype == 'bf16' and not a.no_parity_mode:
                 ti, tf, kept = inference_leg('efficientdet-d4', torch.float32, dev, img4, reps=2, graph=not a.no_graph)
                 out['inference_d4']['parity_mode_f32'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+                ti, tf, kept = inference_leg('efficientdet-d4', torch.float32, dev, img4, reps=2, graph=not a.no_graph, f32_arith='bf16x3')
+                out['inference_d4']['parity_mode_bf16x3'] = {'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a.network, a.size)

@@ -208,8 +208,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   };
   if constexpr (SPLIT) {
     // one slice per K-step: lane (row, lq) takes chunks lq and 4 + lq = 8 floats -> one 16x16x32 operand (any k <-> lane
-    // assignment works as long as both operands share it).  Register double buffer across K-steps: the reads + splits
-    // of tile t+1 are issued ahead of the MFMAs of tile t; one barrier per K-step as below.
+    // assignment works as long as both operands share it); one barrier per K-step as below.
     struct Frags { uint4 wh[NT], wl[NT], xh[MT], xl[MT]; };
     auto split8 = [](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
       const unsigned v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
@@ -237,33 +236,33 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
       }
     };
     auto mmasp = [&](const Frags& f) {
+      // term-major: consecutive MFMAs go to different accumulators (the small cross terms first, the main term last)
 #pragma unroll
-      for (int a = 0; a < NT; ++a)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int b = 0; b < MT; ++b) {
-          Mma<bf16_t>::run(f.wl[a], f.xh[b], acc[a][b]);
-          Mma<bf16_t>::run(f.wh[a], f.xl[b], acc[a][b]);
-          Mma<bf16_t>::run(f.wh[a], f.xh[b], acc[a][b]);
-        }
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int b = 0; b < MT; ++b) Mma<bf16_t>::run(t == 0 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
     };
-    Frags fA, fB;
-    auto kstep = [&](int kt, const Frags& cur, Frags& nxt) {
-      const int c = kt & 1;
-      dma_wait_all();                      // tile kt+1 has landed (this wave's pieces, then everyone's) and every wave
-      __syncthreads();                     // holds tile kt in registers: buffer c is free
-      if (kt + 2 < nk) stage(c);
-      loadsp(c ^ 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      mmasp(cur);
-    };
+    // ONE register set: 110 VGPRs = 4 waves / SIMD (two workgroups per CU).  An A/B register double buffer across K-steps
+    // (184 VGPRs, 2 waves / SIMD) measured 232-286 TFLOP/s on the head shapes against 278-348 for this form -- the other
+    // workgroup's waves cover the LDS round trip + split better than software pipelining inside one wave does.  The same
+    // loop on v_mfma_f32_32x32x16_bf16 tiles (higher instruction ceiling) measured 267-327: the matrix pipe is not the limiter.
+    Frags f;
     stage(0);
     if (nk > 1) stage(1);
     dma_wait_all();
     __syncthreads();
-    loadsp(0, fA);
-    int kt = 0;
-    for (; kt + 2 < nk; kt += 2) { kstep(kt, fA, fB); kstep(kt + 1, fB, fA); }
-    if (kt + 1 < nk) { kstep(kt, fA, fB); mmasp(fB); } else mmasp(fA);
+    for (int kt = 0; kt < nk; ++kt) {
+      const int c = kt & 1;
+      loadsp(c, f);
+      mmasp(f);
+      if (kt + 1 < nk) {
+        dma_wait_all();                    // tile kt+1 has landed (issued one whole K-step ago) ...
+        __syncthreads();                   // ... for everyone, and every wave has read tile kt out of buffer c
+        if (kt + 2 < nk) stage(c);
+      }
+    }
   } else {
     uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
     stage(0);

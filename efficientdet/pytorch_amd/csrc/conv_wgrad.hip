@@ -597,9 +597,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
       bool have = false;
       auto mma_stage = [&]() {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int t = 0; t < 3; ++t)          // term-major: consecutive MFMAs go to different accumulators
 #pragma unroll
-          for (int b = 0; b < JB; ++b) { mm(al[a], bh[b], acc[a][b]); mm(ah[a], bl[b], acc[a][b]); mm(ah[a], bh[b], acc[a][b]); }
+          for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < JB; ++b) mm(t == 0 ? al[a] : ah[a], t == 1 ? bl[b] : bh[b], acc[a][b]);
         if (want_bias) {
 #pragma unroll
           for (int a = 0; a < 4; ++a) { mm(al[a], ones, bsum[a]); mm(ah[a], ones, bsum[a]); }

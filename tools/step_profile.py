@@ -6,11 +6,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, ops, ddp  # noqa: E402
-from oracle.effdet_oracle import synthetic_batch  # noqa: E402
+from efficientdet.pytorch_amd.synthetic import synthetic_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+MODE = sys.argv[2] if len(sys.argv) > 2 else 'bf16'          # bf16 | f32 | f32_bf16x3
 cfg = EFFICIENTDET['efficientdet-d0']
-m = EfficientDet(80, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'], compute_dtype=torch.bfloat16).cuda()
+m = EfficientDet(80, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'], compute_dtype=torch.bfloat16 if MODE == 'bf16' else torch.float32,
+                 f32_arith='bf16x3' if MODE == 'f32_bf16x3' else 'f32').cuda()
 m.train(); ddp.freeze_dead_parameters(m)
 img, ann = synthetic_batch(B, 512, seed=1)
 img, ann = img.cuda(), ann.cuda()
