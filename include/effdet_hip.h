@@ -72,7 +72,8 @@ typedef struct {
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
 /* Which kernel effdet_conv2d would launch for this descriptor (no device work): a negative EFFDET_E* code, 0..3 = the
- * implicit-GEMM kernel with a 128 / 64 / 32 / 16-channel block tile, >= 10 = 10 + the persistent big-tile variant. */
+ * implicit-GEMM kernel with a 128 / 64 / 32 / 16-channel block tile, 4..7 = the same tiles in the bf16x3 form
+ * (EFFDET_F32_BF16X3), >= 10 = 10 + the persistent big-tile variant. */
 int effdet_conv2d_kernel(const effdet_conv_t* p);
 
 /* Kernel-selection knobs (speed only -- every setting computes the same values; process-wide, meant for A/B runs and
@@ -88,7 +89,9 @@ int effdet_tuning_set(int key, int value);
 /* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]
  * (fp32, packed [Cout][KH*KW][Cin]; split-K partial slabs + a reduce pass, so levels / K-splits add up),
  * and optionally dbias[n] += sum_m dz[m][n].  Replaces autograd of F.conv2d w.r.t. weight/bias.
- * Segment geometry: in_* addresses x, out_* addresses dz (Ho,Wo rows). */
+ * Segment geometry: in_* addresses x, out_* addresses dz (Ho,Wo rows).
+ * dtype EFFDET_F32_BF16X3: fp32 x / dz; the pyramid levels the DMA-staged kernel can take (stride 1, 'same' taps, even
+ * row pairs) form their products as bf16x3 (both operands split in registers), the others use the exact fp32 kernel. */
 typedef struct {
   const void* x; const void* dz; float* dw; float* dbias;
   int dtype;

@@ -1,4 +1,6 @@
 """CPU tier: architecture arithmetic, state_dict layout (checkpoint ABI) and the no-CPU-fallback contract."""
+import os
+
 import pytest
 import torch
 
@@ -106,3 +108,34 @@ def test_conv_kernel_selection_rule():
     assert kid(L.BF16, 2, 256, 256) == 0                              # small launches: not enough tiles
     assert kid(L.BF16, 32, 224, 224) == 0                             # D4 head: Cin % 64 != 0
     assert kid(7, 32, 256, 256) == -1                                 # EFFDET_EINVAL
+    # fp32 storage with bf16x3 products: its own kernels (ids 4..7), K % 32 == 0 required
+    assert kid(L.F32_BF16X3, 32, 256, 256) == 4 and kid(L.F32_BF16X3, 32, 256, 64) == 5 and kid(L.F32_BF16X3, 32, 256, 36) == 5
+    assert kid(L.F32_BF16X3, 32, 64, 32) == 6
+    assert kid(L.F32_BF16X3, 32, 36, 256) == -3                       # K = 324: EFFDET_EUNSUPPORTED (the caller's rule never asks)
+    assert kid(L.F32_BF16X3, 32, 256, 16) == 7                        # works; the Python rule just never asks (HBM-bound)
+
+
+def test_bf16x3_rule_and_enum_values_match_header():
+    """ops._mma_dtype_code decides the weight pack AND the launch, so one rule; the enum values are the header's."""
+    import re
+    import torch
+    from efficientdet.pytorch_amd import _lib as L, ops
+    h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'effdet_hip.h')).read()
+    h = re.sub(r'/\*.*?\*/', '', h, flags=re.S)
+    vals = {k: int(v) for k, v in re.findall(r'(EFFDET_(?:F32|BF16|F32_BF16X3))\s*=\s*(\d+)', h)}
+    assert vals == {'EFFDET_F32': L.F32, 'EFFDET_BF16': L.BF16, 'EFFDET_F32_BF16X3': L.F32_BF16X3}
+    old = ops.set_f32_arith('bf16x3')
+    try:
+        f, b = torch.float32, torch.bfloat16
+        assert ops._mma_dtype_code(f, 2304, 256) == L.F32_BF16X3 and ops._mma_dtype_code(f, 576, 64) == L.F32_BF16X3
+        assert ops._mma_dtype_code(f, 324, 256) == L.F32          # K % 32 != 0
+        assert ops._mma_dtype_code(f, 96, 576) == L.F32           # short K: HBM-bound pointwise conv keeps the plain kernel
+        assert ops._mma_dtype_code(f, 2304, 16) == L.F32
+        assert ops._mma_dtype_code(b, 2304, 256) == L.BF16
+        assert ops._mma_dtype_code(f) == L.F32_BF16X3             # weight gradient: no packed operand, no K rule
+    finally:
+        ops.set_f32_arith(old)
+    assert ops._mma_dtype_code(torch.float32, 2304, 256) == L.F32
+    import pytest
+    with pytest.raises(ValueError):
+        ops.set_f32_arith('fp8')
