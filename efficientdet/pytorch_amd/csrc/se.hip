@@ -51,6 +51,55 @@ __global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restri
   }
 }
 
+// ---- the same gate, S workgroups per image, one launch per layer (effdet_se_gate_fwd_split) ----
+// One workgroup per image pulls W1 and W2 (2 x 1.2 MB fp32 for D4's widest block) through a single CU: 34 us per block at
+// B = 8 @1024 (9 % of the D4 forward).  With few images the two layers run as two launches of S workgroups per image -- layer 1:
+// a slice of the squeezed channels (one wave per channel), layer 2: a slice of the C gates.  (A single launch with a per-image
+// arrival counter between the layers was measured too: the device-scope release fence writes back the whole XCD L2, which made
+// the D0 B = 32 train step 7 % SLOWER; the kernel boundary is the cheaper fence.)
+template <int PHASE>
+__global__ __launch_bounds__(256) void se_gate_fwd_split_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+                                                                const float* __restrict__ b1, const float* __restrict__ w2,
+                                                                const float* __restrict__ b2, float* __restrict__ gate,
+                                                                float* __restrict__ mid, float* __restrict__ ws_sw, int C, int Cse,
+                                                                float inv_hw) {
+  extern __shared__ float sm[];          // PHASE 1: mean[C];  PHASE 2: sw[Cse]
+  const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if constexpr (PHASE == 1) {
+    float* mean = sm;
+    for (int c = tid; c < C; c += 256) mean[c] = pool[(long long)b * C + c] * inv_hw;
+    __syncthreads();
+    for (int j = sl + S * wave; j < Cse; j += S * 4) {
+      float s0 = 0.f, s1 = 0.f;
+      const float* row = w1 + (long long)j * C;
+      int c = lane;
+      for (; c + 64 < C; c += 128) { s0 = fmaf(row[c], mean[c], s0); s1 = fmaf(row[c + 64], mean[c + 64], s1); }
+      if (c < C) s0 = fmaf(row[c], mean[c], s0);
+      const float t = wave_sum(s0 + s1);
+      if (lane == 0) {
+        const float m = t + b1[j];
+        if (mid) mid[(long long)b * Cse + j] = m;
+        ws_sw[(long long)b * Cse + j] = swishf_(m);
+      }
+    }
+  } else {
+    float* sw = sm;
+    for (int j = tid; j < Cse; j += 256) sw[j] = ws_sw[(long long)b * Cse + j];
+    __syncthreads();
+    const int per = (C + S - 1) / S, c1 = min(C, (sl + 1) * per);
+    for (int c = sl * per + tid; c < c1; c += 256) {
+      const float* row = w2 + (long long)c * Cse;
+      float s0 = b2[c], s1 = 0.f;
+      int j = 0;
+#pragma unroll 4
+      for (; j + 1 < Cse; j += 2) { s0 = fmaf(row[j], sw[j], s0); s1 = fmaf(row[j + 1], sw[j + 1], s1); }
+      if (j < Cse) s0 = fmaf(row[j], sw[j], s0);
+      gate[(long long)b * C + c] = sigmoidf_(s0 + s1);
+    }
+  }
+}
+
 // ---- backward of the gate MLP, phase A: one workgroup per image -> du, dmid, sw (workspace) and dpool ----
 //   du[c]   = dgate[c]*g(1-g)                       (through the sigmoid)
 //   dmid[j] = swish'(mid[j]) * sum_c w2[c][j]*du[c]
@@ -316,6 +365,21 @@ extern "C" int effdet_se_gate_fwd(const float* pool, const float* w1, const floa
   const size_t lds = (size_t)(C + Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
   hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(SE_T), lds, ST, pool, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_se_gate_fwd_split(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
+                                        float* gate, float* mid, float* ws_sw, int B, int C, int Cse, float inv_hw,
+                                        effdet_stream_t stream) {
+  if (!pool || !w1 || !b1 || !w2 || !b2 || !gate || !ws_sw || B < 1) return EFFDET_EINVAL;
+  // many images already fill the GPU with one workgroup each, and a second launch costs more than it saves (D0 B = 32: 14 us)
+  if (B > 16 || Cse < 8) return effdet_se_gate_fwd(pool, w1, b1, w2, b2, gate, mid, B, C, Cse, inv_hw, stream);
+  const size_t lds = (size_t)(C > Cse ? C : Cse) * sizeof(float);
+  if (lds > 60000) return EFFDET_EUNSUPPORTED;
+  const int S = 8;
+  hipLaunchKernelGGL(se_gate_fwd_split_kernel<1>, dim3(S, B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_fwd_split_kernel<2>, dim3(S, B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

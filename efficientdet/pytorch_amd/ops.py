@@ -140,6 +140,7 @@ class ParamPrep:
         self.f32_arith = f32_arith          # arithmetic of the owner's MFMA launches on fp32 storage (see set_f32_arith)
         self.jobs, self.outs, self.bn_src = {}, {}, {}
         self.table, self.dirty, self.replay = None, False, False
+        self._fresh = None                  # (source version sum, stream) the arena was last refreshed for -- inference only
         self.zbuf, self.zpos, self.zreq, self.zsize = None, 0, 0, 0
 
     # -- zero-initialised scratch of one step (SE pools, bias / BN / fusion-weight accumulators): ONE memset per step
@@ -165,8 +166,20 @@ class ParamPrep:
             self._build()
         self.replay = self.table is not None
         if self.replay:
+            # Inference: the packed copies in the arena stay valid while no source tensor was written (optimizer step,
+            # load_state_dict, .copy_ all bump Tensor._version): skip the launch (0.05 ms of a 5 ms D0 forward, 0.2 of 12 for D4).
+            # Never under graph capture (a captured forward must refresh them on every replay) nor with autograd on.
+            fp = None
+            if not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+                fp = (self._version_sum(), torch.cuda.current_stream().cuda_stream)
+                if fp == self._fresh:
+                    return
             jobs, bj, bf, nblocks, _ = self.table
             L.check(L.lib().effdet_prepare_params(L.ptr(jobs), L.ptr(bj), L.ptr(bf), nblocks, L.stream_ptr()), 'effdet_prepare_params')
+            self._fresh = fp
+
+    def _version_sum(self):
+        return sum(t._version for job in self.jobs.values() for t in job[1] if t is not None)
 
     def lookup(self, key):
         return self.outs.get(key) if self.replay else None
@@ -208,7 +221,7 @@ class ParamPrep:
         jobs_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         bj = torch.from_numpy(np.asarray(block_job, dtype=np.int32)).to(dev)
         bf = torch.from_numpy(np.asarray(block_first, dtype=np.int32)).to(dev)
-        self.table, self.dirty = (jobs_dev, bj, bf, nb, arena), False
+        self.table, self.dirty, self._fresh = (jobs_dev, bj, bf, nb, arena), False, None
 
 
 _tls = threading.local()     # .prep: the ParamPrep of the model whose forward / backward runs on this thread
@@ -475,8 +488,10 @@ def se_gate_fwd(pool, w1, b1, w2, b2, inv_hw, save_mid=False):
     Cse = w1.shape[0]
     gate = torch.empty((B, Cc), dtype=torch.float32, device=pool.device)
     mid = torch.empty((B, Cse), dtype=torch.float32, device=pool.device) if save_mid else None
-    L.check(L.lib().effdet_se_gate_fwd(L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()), L.ptr(w2.detach()), L.ptr(b2.detach()),
-                                       L.ptr(gate), L.ptr(mid), B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_fwd')
+    ws = torch.empty((B, Cse), dtype=torch.float32, device=pool.device)
+    L.check(L.lib().effdet_se_gate_fwd_split(L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()), L.ptr(w2.detach()), L.ptr(b2.detach()),
+                                             L.ptr(gate), L.ptr(mid), L.ptr(ws), B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()),
+            'effdet_se_gate_fwd_split')
     return gate, mid
 
 

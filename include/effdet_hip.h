@@ -200,6 +200,12 @@ int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale, const floa
 int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2,
                        const float* b2, float* gate, float* mid, int B, int C, int Cse, float inv_hw,
                        effdet_stream_t stream);
+/* The same gate for small batches (B <= 16): 8 workgroups per image, one launch per layer (a single workgroup per image is
+ * bound by what one CU can pull: 34 us per block for D4 at B = 8).  ws_sw: [B][Cse] floats of scratch.  B > 16 forwards to
+ * effdet_se_gate_fwd. */
+int effdet_se_gate_fwd_split(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
+                             float* gate, float* mid, float* ws_sw, int B, int C, int Cse, float inv_hw,
+                             effdet_stream_t stream);
 /* y = act(x) * gate[b][c]  (models/efficientnet.py:98).  act = EFFDET_ACT_NONE: x is the depthwise OUTPUT;
  * act = EFFDET_ACT_SWISH: x is the depthwise PRE-activation z (training stores z only -- the step is bound by HBM
  * write bandwidth -- and every consumer recomputes Swish from the stored value). */

@@ -167,3 +167,20 @@ def test_elementwise_helpers(dtype):
     assert_close(m.tensor()[..., :3].float().cpu().permute(0, 3, 1, 2), q(x), 1e-6, 'nchw->nhwc')
     assert float(m.tensor()[..., 3:].float().abs().max()) == 0.0
     assert_close(ops.nhwc_to_nchw(nhwc(x, dtype)).cpu(), q(x), 1e-6, 'nhwc->nchw')
+
+
+@pytest.mark.parametrize('B,C,Cse', [(3, 96, 4), (8, 2688, 112), (16, 672, 28), (20, 144, 6), (40, 1152, 48)])
+def test_se_gate_both_forms(B, C, Cse):
+    """Small batches take the 8-workgroups-per-image, launch-per-layer form (Cse >= 8), the rest one workgroup per image:
+    both == the torch MLP, incl. the saved pre-Swish squeeze activations."""
+    from efficientdet.pytorch_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    pool = torch.randn(B, C, generator=g) * 50.0
+    w1 = torch.randn(Cse, C, generator=g) / C ** 0.5; b1 = torch.randn(Cse, generator=g) * 0.1
+    w2 = torch.randn(C, Cse, generator=g) / Cse ** 0.5; b2 = torch.randn(C, generator=g) * 0.1
+    inv = 1.0 / 49.0
+    mid = (pool * inv) @ w1.t() + b1
+    gate = torch.sigmoid((mid * torch.sigmoid(mid)) @ w2.t() + b2)
+    gd, midd = ops.se_gate_fwd(pool.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), inv, save_mid=True)
+    torch.cuda.synchronize()
+    assert_close(midd.cpu(), mid, 1e-4, 'se mid'); assert_close(gd.cpu(), gate, 1e-4, 'se gate')

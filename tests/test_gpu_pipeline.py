@@ -343,3 +343,36 @@ def test_graphed_detect_matches_eager():
     got2 = gd()
     e2 = m.detect(img2.cuda())
     assert abs(len(got2[0][0]) - len(e2[0][0])) <= max(2, len(e2[0][0]) // 100) and not torch.equal(got2[0][0][:5], eager[0][0][:5])
+
+
+def test_inference_skips_param_prep_only_while_weights_are_unchanged():
+    """Eval forwards reuse the packed parameter copies while no source tensor was written (Tensor._version); any in-place
+    update (optimizer step, load_state_dict, .mul_) must show up in the very next forward."""
+    m = _model('efficientdet-d0', 20, torch.float32, is_training=False)
+    m.eval(); m.is_training = False
+    img = O.synthetic_batch(2, 128, seed=3, num_classes=20)[0].cuda()
+    with torch.no_grad():
+        c0, r0, _ = m.forward_raw(img)             # records
+        c1, r1, _ = m.forward_raw(img)             # first replay (launch)
+        prep = next(iter(m._prep.values()))
+        assert prep.replay and prep._fresh is not None
+        fresh = prep._fresh
+        c2, r2, _ = m.forward_raw(img)             # skipped launch
+        assert prep._fresh == fresh
+        assert_close(c2.cpu(), c1.cpu(), 1e-3, 'skip == replay (cls)'); assert_close(r2.cpu(), r1.cpu(), 1e-3, 'skip == replay (reg)')   # (SE pool atomics: not bitwise)
+        assert_close(c1.cpu(), c0.cpu(), 1e-3, 'replay == record')
+        m.bbox_head.retina_reg.weight.mul_(2.0); m.bbox_head.retina_reg.bias.mul_(2.0)
+        c3, r3, _ = m.forward_raw(img)
+        assert prep._fresh != fresh
+        assert_close(c3.cpu(), c1.cpu(), 1e-3, 'cls untouched')
+        assert_close(r3.cpu(), (2.0 * r1).cpu(), 1e-3, 'reg doubled')
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        sd['bbox_head.retina_reg.weight'] *= 0.5; sd['bbox_head.retina_reg.bias'] *= 0.5
+        m.load_state_dict(sd)
+        c4, r4, _ = m.forward_raw(img)
+        assert_close(r4.cpu(), r1.cpu(), 1e-3, 'load_state_dict seen')
+    # a training-mode forward in between always refreshes and resets the marker
+    m.train(); m.is_training = True; m.freeze_bn()
+    ann = O.synthetic_batch(2, 128, seed=3, num_classes=20)[1].cuda()
+    cl, rl = m([img, ann]); (cl.mean() + rl.mean()).backward()
+    assert prep._fresh is None
