@@ -47,14 +47,15 @@ def main():
     tcl, trl = twin([img.cuda(), ann.cuda()])
     (tcl.mean() + trl.mean()).backward()
     torch.cuda.synchronize()
-    worst, nchk = 0.0, 0
+    worst, worst_l2, nchk = 0.0, 0.0, 0
     for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
         if q.grad is None:
             assert p.grad is None or not p.requires_grad, k
             continue
         scale = float(q.grad.abs().max()) + 1e-12
         worst = max(worst, float((p.grad - q.grad).abs().max()) / scale); nchk += 1
-    res.update(grad_worst_rel=worst, grad_tensors=nchk, loss=float(cl) + float(rl))
+        worst_l2 = max(worst_l2, float((p.grad.double() - q.grad.double()).norm()) / (float(q.grad.double().norm()) + 1e-12))
+    res.update(grad_worst_rel=worst, grad_worst_l2=worst_l2, grad_tensors=nchk, loss=float(cl) + float(rl))
     # ---- 3 optimizer steps over bucket views, never synchronising in between; replicas must stay bit-identical
     opt.step()
     for it in range(2):

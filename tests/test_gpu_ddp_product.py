@@ -33,6 +33,9 @@ def test_two_rank_ddp_hip_model(tmp_path, dtype):
         json.dump(res, open(os.path.join(log_dir, 'ddp_product_%s.json' % dtype), 'w'))
     assert res['world'] == 2 and res['grad_tensors'] > 250
     # DDP average of the two shard gradients == full-batch gradient (fp32: summation-order noise only)
-    assert res['grad_worst_rel'] <= (2e-3 if dtype == 'f32' else 0.1), res
+    # fp32 measured 1.2e-6; the gates leave room for one ReLU / smooth-L1 tie falling the other way between the two runs (seen in
+    # single-process twin comparisons: single entries up to 7e-3 of a head tensor's scale, whole tensors < 5e-3)
+    assert res['grad_worst_rel'] <= (2e-2 if dtype == 'f32' else 0.1), res
+    assert res['grad_worst_l2'] <= (5e-3 if dtype == 'f32' else 0.1), res
     assert res['finite'] and res['prep_replay']
     assert res['param_checksums'][0] == res['param_checksums'][1], res       # replicas bit-identical after 3 ClipAdamW steps
