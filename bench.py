@@ -216,8 +216,13 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
         step()
         torch.cuda.synchronize()
         if rank == 0:
-            summ = ops.PROFILE.summary(); ops.PROFILE = None
+            summ = ops.PROFILE.summary()
             roof = roofline_of(summ, dtype_name, a.batch, a.size)
+            # the dominant symbol's launches by shape: its MFMA-bound head shapes apart from the HBM-bound backbone ones
+            roof['dominant_by_shape'] = ops.PROFILE.by_shape(roof['kernel'])
+            roof['other_mfma_by_shape'] = {k: ops.PROFILE.by_shape(k, top=3) for k, v in summ.items()
+                                           if k.startswith('conv_') and k != roof['kernel'] and v['ms'] >= 1.0}
+            ops.PROFILE = None
         if world > 1:
             dist.barrier()
     final = float(loss.item())

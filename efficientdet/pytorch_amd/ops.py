@@ -28,6 +28,19 @@ class LaunchProfile:
             d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1)
         return out
 
+    def by_shape(self, name, top=4):
+        """The launches of one kernel symbol grouped by shape note, heaviest first (a symbol mixes MFMA-bound head shapes with
+        HBM-bound backbone ones; this shows them apart)."""
+        torch.cuda.synchronize()
+        agg = {}
+        for n, flops, e0, e1, note in self.records:
+            if n == name:
+                d = agg.setdefault(note, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
+                d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1)
+        rows = sorted(agg.items(), key=lambda kv: -kv[1]['ms'])[:top]
+        return {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 1)}
+                for k, v in rows}
+
 
 PROFILE = None     # set to a LaunchProfile() to time every conv launch
 
