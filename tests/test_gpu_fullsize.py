@@ -161,3 +161,36 @@ def test_nms_satisfies_the_greedy_definition_at_benchmark_size(net, B, S):
         assert count2.tolist() == counts
         for b in (0, B - 1):
             assert torch.equal(idx2[b, :counts[b]].long(), torch.arange(counts[b], device=idx2.device))
+
+
+def test_graph_replayed_step_tracks_eager_at_benchmark_size():
+    """configs[2] as bench.py times it (bf16, B=32 @512, drop_connect off for comparability): three replays of the captured
+    step == three eager steps from the same weights -- losses and the updated parameters."""
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    from efficientdet.pytorch_amd.graph import GraphedTrainStep
+    img, ann = O.synthetic_batch(32, 512, seed=1, num_classes=80)
+    img, ann = img.cuda(), ann.cuda()
+
+    def make():
+        m = _model('efficientdet-d0', 80, torch.bfloat16, True)
+        ps = [p for p in m.live_parameters()]
+        return m, ps, ClipAdamW(ps, lr=1e-4, max_norm=0.1)
+    me, pe, oe = make()
+    eager = []
+    for _ in range(3):                       # (GraphedTrainStep's 2 warm-up steps are steps 1-2 of the twin; capture itself runs nothing)
+        oe.zero_grad(set_to_none=True)
+        cl, rl = me([img, ann]); loss = cl.mean() + rl.mean(); loss.backward(); oe.step()
+        eager.append(float(loss.detach()))
+    mg, pg, og = make()
+    step = GraphedTrainStep(mg, og, img, ann, warmup=2)
+    outs = step()
+    torch.cuda.synchronize()
+    lg = float((outs[0].mean() + outs[1].mean()).detach())
+    # the first replay is the 3rd optimizer step of the twin: compare like with like
+    assert abs(lg - eager[2]) <= 2e-2 * abs(eager[2]), (lg, eager)
+    worst, worst_abs = 0.0, 0.0
+    for a, b in zip(pe, pg):
+        d = float((a.detach() - b.detach()).abs().max())
+        worst = max(worst, d / (float(a.detach().abs().max()) + 1e-12)); worst_abs = max(worst_abs, d)
+    print('graph replay loss %.5f vs eager %.5f (eager history %s); worst parameter deviation after 3 steps %.2e of scale' % (lg, eager[2], eager, worst))
+    assert worst_abs <= 3 * 2 * 1e-4 + 1e-6, (worst_abs, worst)          # AdamW moves a weight by <= lr per step: sign noise <= 2 lr per step
