@@ -194,3 +194,20 @@ def test_graph_replayed_step_tracks_eager_at_benchmark_size():
         worst = max(worst, d / (float(a.detach().abs().max()) + 1e-12)); worst_abs = max(worst_abs, d)
     print('graph replay loss %.5f vs eager %.5f (eager history %s); worst parameter deviation after 3 steps %.2e of scale' % (lg, eager[2], eager, worst))
     assert worst_abs <= 3 * 2 * 1e-4 + 1e-6, (worst_abs, worst)          # AdamW moves a weight by <= lr per step: sign noise <= 2 lr per step
+
+
+def test_decode_score_at_benchmark_size():
+    """BBoxTransform + ClipBoxes + class max / first-arg-max over all 32 x 49 104 anchors == the oracle's formulas evaluated with
+    torch ops on the device (the oracle function itself is dtype / device generic)."""
+    from efficientdet.pytorch_amd import ops
+    m = _model('efficientdet-d0', 80, torch.float32, False)
+    img = O.synthetic_batch(32, 512, seed=4, num_classes=80)[0].cuda()
+    with torch.no_grad():
+        cls, reg, anc = m.forward_raw(img)
+        boxes, score, label = ops.decode_score(anc, reg, cls, 512, 512)
+        ref = O.decode_clip(anc.cpu(), reg.cpu(), 512, 512)
+        smax, amax = cls.max(dim=2)
+    torch.cuda.synchronize()
+    assert float((boxes.cpu() - ref).abs().max()) <= 2e-3                  # pixels, on boxes up to 512 wide (exp is v_exp_f32 here)
+    assert torch.equal(score, smax)
+    assert torch.equal(label.long(), amax)                                 # (torch.max returns the first maximal index on ties too)
