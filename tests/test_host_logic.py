@@ -108,6 +108,9 @@ def test_conv_kernel_selection_rule():
     assert kid(L.BF16, 2, 256, 256) == 0                              # small launches: not enough tiles
     assert kid(L.BF16, 32, 224, 224) == 0                             # D4 head: Cin % 64 != 0
     assert kid(7, 32, 256, 256) == -1                                 # EFFDET_EINVAL
+    # maximum sizes: a tensor the 32-bit buffer offsets cannot span is refused loudly (EFFDET_EUNSUPPORTED), never wrapped
+    assert kid(L.F32, 64, 144, 24, sizes=((512, 512),), k=1) == -3     # 64 x 512 x 512 x 144 fp32 = 9.7 GB input
+    assert kid(L.BF16, 16, 144, 24, sizes=((512, 512),), k=1) >= 0     # 1.2 GB: fine
     # fp32 storage with bf16x3 products: its own kernels (ids 4..7), K % 32 == 0 required
     assert kid(L.F32_BF16X3, 32, 256, 256) == 4 and kid(L.F32_BF16X3, 32, 256, 64) == 5 and kid(L.F32_BF16X3, 32, 256, 36) == 5
     assert kid(L.F32_BF16X3, 32, 64, 32) == 6
