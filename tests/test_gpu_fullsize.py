@@ -18,11 +18,11 @@ from oracle import effdet_oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _model(net, nc, dtype, training, seed=0):
+def _model(net, nc, dtype, training, seed=0, f32_arith='f32'):
     from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET
     c = EFFICIENTDET[net]
     m = EfficientDet(nc, network=net, W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'], is_training=training,
-                     compute_dtype=dtype, threshold=0.01, iou_threshold=0.5)
+                     compute_dtype=dtype, threshold=0.01, iou_threshold=0.5, f32_arith=f32_arith)
     m.load_state_dict(O.make_state_dict(net, nc, seed=seed))
     m.backbone.drop_connect_rate = 0.0
     m = m.cuda()
@@ -37,8 +37,16 @@ def _scale_err(a, b):
     return float((a.float() - b.float()).abs().max()) / (float(b.float().abs().max()) + 1e-30)
 
 
+@pytest.fixture(autouse=True)
+def _restore_arith():
+    from efficientdet.pytorch_amd import ops
+    yield
+    ops.set_f32_arith('f32')
+
+
 @pytest.mark.parametrize('net,B,S,dtype,tol', [
     ('efficientdet-d0', 32, 512, torch.float32, 1e-4),        # configs[1] / [2] geometry
+    ('efficientdet-d0', 32, 512, 'f32_bf16x3', 3e-4),         # fp32 storage, bf16x3 products (B = 1 and B = 32 take other tilings)
     ('efficientdet-d0', 32, 512, torch.bfloat16, 2e-2),
     ('efficientdet-d4', 8, 1024, torch.bfloat16, 0.10),       # configs[4] geometry (the D4 bf16 gate of the golden tests:
                                                               #  B = 1 takes the 16x16x32 head kernel, B = 8 the persistent 32x32x16
@@ -47,7 +55,7 @@ def _scale_err(a, b):
 def test_batch_independence_at_benchmark_size(net, B, S, dtype, tol):
     """fp32: identical K-reduction order per output element, so only the SE-pool atomics' order differs (1e-6); bf16: that
     noise flips bf16 roundings which the network amplifies like any storage rounding (gate: the golden tests' tolerance)."""
-    m = _model(net, 80, dtype, False)
+    m = _model(net, 80, torch.float32, False, f32_arith='bf16x3') if dtype == 'f32_bf16x3' else _model(net, 80, dtype, False)
     img = O.synthetic_batch(B, S, seed=5, num_classes=80)[0].cuda()
     with torch.no_grad():
         cls, reg, anc = m.forward_raw(img)
