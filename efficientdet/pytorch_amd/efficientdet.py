@@ -150,7 +150,7 @@ def _t(m):
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train):
-        ctx.prep = ops.get_prep()
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         if isinstance(img, PackedImages) and (img.map.dtype != dtype or img.map.C != Fn.chunk_elems(dtype)):
             raise RuntimeError('PackedImages were packed for %s / %d channels, the model computes in %s'
                                % (img.map.dtype, img.map.C, dtype))
@@ -160,7 +160,7 @@ class _StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_prep(ctx.prep)
+        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()))
         ctx.saved = None
         return None, dw, dg, db, None, None, None, None, None
@@ -173,7 +173,7 @@ _MB_KEYS = ('expand.weight', 'bn0.weight', 'bn0.bias', 'dw.weight', 'bn1.weight'
 class _MBConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, dtype, rowscale, buffers, train, *params):
-        ctx.prep = ops.get_prep()
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         P = dict(buffers)
         keys = [k for k in _MB_KEYS if not (blk.expand == 1 and k in ('expand.weight', 'bn0.weight', 'bn0.bias'))]
         P.update(dict(zip(keys, params)))
@@ -183,7 +183,7 @@ class _MBConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_prep(ctx.prep)
+        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
             ops.add_inplace(dx, Map.of(dy.contiguous()))
@@ -197,7 +197,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, nlev, stack, train, *args):
-        ctx.prep = ops.get_prep()
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         feats = [Map.of(t) for t in args[:nlev]]
         rest = args[nlev:]
         lw, lb = rest[0:nlev], rest[nlev:2 * nlev]
@@ -216,7 +216,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        ops.set_prep(ctx.prep)
+        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         feats, lw, saved_mods, dtype, nlev, stack = ctx.saved
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
@@ -242,7 +242,7 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, num_classes, train, *args):
-        ctx.prep = ops.get_prep()
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
@@ -251,7 +251,7 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        ops.set_prep(ctx.prep)
+        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         saved, cls, dtype = ctx.saved
         dlogit, dr = ops.head_out_bwd(dcls.contiguous().float(), cls, dreg.contiguous().float(), dtype)
         dp, g = Fn.head_bwd(saved, dlogit, dr, dtype)
@@ -268,7 +268,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, num_classes, anchors, annots, train, *args):
-        ctx.prep = ops.get_prep()
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
@@ -286,7 +286,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gcls, greg):
-        ops.set_prep(ctx.prep)
+        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         saved, cls, reg, anchors, annots, ws, dtype, dpix, dld = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
         if dpix is not None:

@@ -376,3 +376,42 @@ def test_inference_skips_param_prep_only_while_weights_are_unchanged():
     ann = O.synthetic_batch(2, 128, seed=3, num_classes=20)[1].cuda()
     cl, rl = m([img, ann]); (cl.mean() + rl.mean()).backward()
     assert prep._fresh is None
+
+
+def test_interleaved_models_keep_their_own_f32_arithmetic():
+    """f32_arith is process-wide state inside ops; every forward sets it and every backward node restores the value its
+    forward ran with -- so two models with different arithmetic can interleave forward and backward passes (batched
+    parameter prep on or off).  Checked on the kernels actually launched (the launch profile names them)."""
+    from efficientdet.pytorch_amd import ops
+    img, ann = O.synthetic_batch(2, 128, seed=13, num_classes=8)
+    img, ann = img.cuda(), ann.cuda()
+
+    def make(arith, batched):
+        m = _model('efficientdet-d0', 8, torch.float32, f32_arith=arith)
+        m.backbone.drop_connect_rate = 0.0
+        m.batched_prep = batched
+        m.train(); m.is_training = True; m.freeze_bn()
+        return m
+
+    def profiled(fn):
+        ops.PROFILE = ops.LaunchProfile()
+        try:
+            fn(); torch.cuda.synchronize()
+            return [r[0] for r in ops.PROFILE.records if r[0].startswith('conv_')]
+        finally:
+            ops.PROFILE = None
+    try:
+        for batched in (True, False):
+            ma, mb = make('bf16x3', batched), make('f32', batched)
+            la = ma([img, ann]); lb = mb([img, ann])                 # forward A, forward B: the global is now 'f32' ...
+            assert ops.F32_ARITH == 'f32'
+            ka = profiled(lambda: (la[0].mean() + la[1].mean()).backward())      # ... backward A must still run bf16x3 kernels
+            assert ops.F32_ARITH == 'bf16x3'
+            kb = profiled(lambda: (lb[0].mean() + lb[1].mean()).backward())
+            assert ops.F32_ARITH == 'f32'
+            assert sum('bf16x3' in k for k in ka) >= 30, ka          # head / BiFPN data gradients + every DMA-eligible weight gradient
+            assert not any('bf16x3' in k for k in kb), kb
+            for p in list(ma.parameters()) + list(mb.parameters()):
+                assert p.grad is None or bool(torch.isfinite(p.grad).all())
+    finally:
+        ops.set_f32_arith('f32')
