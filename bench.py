@@ -123,7 +123,7 @@ def roofline_of(summ, dtype_name, batch, size):
     # process; the values are those measured by separate `rocprofv3 --pmc` passes on this same command and committed
     # under profiles/ (null when no such file / another dtype or shape)
     traffic = util = src = None
-    for fn in ('r02_pmc.json', 'r01_hbm_traffic.json'):
+    for fn in ('r02_pmc.json', 'r02_pmc_f32.json', 'r02_pmc_bf16x3.json', 'r01_hbm_traffic.json'):
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', fn)))
             if tj.get('dtype', 'bf16') == dtype_name and batch == 32 and size == 512:

@@ -21,6 +21,8 @@ for s in $STEPS; do
             rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;
     pmcf32) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$OUT/pmcf_SQ -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcf_SQ.log 2>&1); echo "pmcf32 rc=$?" | tee -a $OUT/rc.txt
             python tools/pmc_summary.py $OUT/pmc_f32.json f32 $OUT/none $OUT/none $OUT/pmcf_SQ > $OUT/pmcf_summary.log 2>&1; cat $OUT/pmcf_summary.log; rm -rf $OUT/pmcf_SQ ;;
+    pmcx3)  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$OUT/pmcx_SQ -o run -- python /root/repo/bench.py --dtype f32_bf16x3 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcx_SQ.log 2>&1); echo "pmcx3 rc=$?" | tee -a $OUT/rc.txt
+            python tools/pmc_summary.py $OUT/pmc_bf16x3.json f32_bf16x3 $OUT/none $OUT/none $OUT/pmcx_SQ > $OUT/pmcx_summary.log 2>&1; cat $OUT/pmcx_summary.log; rm -rf $OUT/pmcx_SQ ;;
     statsx3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_x3 -o run -- python /root/repo/bench.py --dtype f32_bf16x3 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 6 --warmup 2 > /root/repo/$OUT/stats_x3.log 2>&1); echo "stats_x3 rc=$?" | tee -a $OUT/rc.txt ;;
     statsinf) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_infer -o run -- python /root/repo/tools/infer_bench.py --network efficientdet-d0 --batch 32 --size 512 --reps 5 > /root/repo/$OUT/stats_infer.log 2>&1); echo "stats_infer rc=$?" | tee -a $OUT/rc.txt ;;
     bw)     timeout 300 python tools/bw_calib.py > $OUT/bw_calib.txt 2>&1; cat $OUT/bw_calib.txt

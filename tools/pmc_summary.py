@@ -37,9 +37,13 @@ def short(name):
     m = re.search(r'conv_igemm_pers_kernel<(\d+), (\d+), (\d+)>', name)
     if m:
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % m.groups()
-    m = re.search(r'conv_igemm_kernel<(unsigned short|float), (\d+)', name)
+    m = re.search(r'conv_igemm_kernel<(unsigned short|float), (\d+)(?:, \d+, \d+, (\d+))?', name)
     if m:
-        return 'conv_igemm_kernel<%s,%s>' % ('bf16' if m.group(1) == 'unsigned short' else 'f32', m.group(2))
+        return 'conv_igemm_kernel<%s,%s%s>' % ('bf16' if m.group(1) == 'unsigned short' else 'f32', m.group(2),
+                                                ',bf16x3' if m.group(3) == '1' else '')
+    m = re.search(r'conv_wgrad_f32dma_kernel<(\d+), (\d+)>', name)
+    if m:
+        return 'conv_wgrad_f32dma_kernel<%s%s>' % (m.group(1), ',bf16x3' if m.group(2) == '1' else '')
     m = re.search(r'(conv_wgrad\w*_kernel<[^>(]*>|dw_\w+_kernel|unpack_wgrad\w*_kernel|wgrad_\w+_kernel|loss_\w+_kernel|se_\w+_kernel|'
                   r'channel_scale_kernel|fuse_\w+_kernel|opt_\w+_kernel|act_bwd_kernel|prepare_params_kernel|nms_\w+_kernel|decode_score_kernel)', name)
     return m.group(1).replace('unsigned short', 'bf16').replace('float', 'f32') if m else None
