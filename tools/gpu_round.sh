@@ -21,6 +21,14 @@ for s in $STEPS; do
             rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES ;;
     pmcf32) (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$OUT/pmcf_SQ -o run -- python /root/repo/bench.py --dtype f32 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcf_SQ.log 2>&1); echo "pmcf32 rc=$?" | tee -a $OUT/rc.txt
             python tools/pmc_summary.py $OUT/pmc_f32.json f32 $OUT/none $OUT/none $OUT/pmcf_SQ > $OUT/pmcf_summary.log 2>&1; cat $OUT/pmcf_summary.log; rm -rf $OUT/pmcf_SQ ;;
+    pmcmodes) for dt in f32 f32_bf16x3; do
+              for pp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+                n=$(echo $pp | cut -d' ' -f1)
+                (cd /tmp && timeout 600 rocprofv3 --pmc $pp --output-format csv -d /root/repo/$OUT/pm_${dt}_$n -o run -- python /root/repo/bench.py --dtype $dt --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pm_${dt}_$n.log 2>&1); echo "pmc $dt $n rc=$?" | tee -a $OUT/rc.txt
+              done
+              python tools/pmc_summary.py $OUT/pmc_$dt.json $dt $OUT/pm_${dt}_FETCH_SIZE $OUT/pm_${dt}_WRITE_SIZE $OUT/pm_${dt}_SQ_VALU_MFMA_BUSY_CYCLES > $OUT/pmc_${dt}_summary.log 2>&1; cat $OUT/pmc_${dt}_summary.log
+              rm -rf $OUT/pm_${dt}_FETCH_SIZE $OUT/pm_${dt}_WRITE_SIZE $OUT/pm_${dt}_SQ_VALU_MFMA_BUSY_CYCLES
+            done ;;
     pmcx3)  (cd /tmp && timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /root/repo/$OUT/pmcx_SQ -o run -- python /root/repo/bench.py --dtype f32_bf16x3 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 1 --warmup 1 > /root/repo/$OUT/pmcx_SQ.log 2>&1); echo "pmcx3 rc=$?" | tee -a $OUT/rc.txt
             python tools/pmc_summary.py $OUT/pmc_bf16x3.json f32_bf16x3 $OUT/none $OUT/none $OUT/pmcx_SQ > $OUT/pmcx_summary.log 2>&1; cat $OUT/pmcx_summary.log; rm -rf $OUT/pmcx_SQ ;;
     statsx3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_x3 -o run -- python /root/repo/bench.py --dtype f32_bf16x3 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 6 --warmup 2 > /root/repo/$OUT/stats_x3.log 2>&1); echo "stats_x3 rc=$?" | tee -a $OUT/rc.txt ;;
