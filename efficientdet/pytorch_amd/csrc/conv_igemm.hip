@@ -76,9 +76,14 @@ template <> struct Mma<float> {
 // SPLIT (fp32 storage only): "bf16x3" arithmetic -- each fp32 operand value is split in registers into bf16 hi + bf16 lo
 // (x = hi + lo + O(2^-17 |x|)) and a K-step costs 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate)
 // per tile instead of 8 v_mfma_f32_16x16x4_f32: products carry ~16 mantissa bits, the matrix pipe does 3/8 of the passes.
-template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0>
+// NS: LDS stages of the K loop.  2 is right when two workgroups share a CU (the other one's MFMAs cover this one's DMA latency);
+// launches too small for that (<= 1 tile per CU: BiFPN convs on the coarse levels, the late backbone 1x1 convs) run ONE
+// workgroup per CU and were bound by the DMA round trip (1.27 us per K-step for 0.35 us of MFMA work): NS = 4 keeps three
+// tiles in flight (s_waitcnt vmcnt = pieces of the tiles issued after the one needed).
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2>
 __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
   static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
+  static_assert(NS == 2 || !SPLIT, "deep staging is implemented for the plain loop");
   constexpr int CE = Elem<T>::CE;
   constexpr int NTHREADS = NWAVES * 64;
   constexpr int WAVES_M = NWAVES / WAVES_N;
@@ -91,8 +96,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   constexpr int WROWS = (BN + RSTEP - 1) / RSTEP;     // weight pieces per thread per K-step
 
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-  uint4* xs = smem;                // [2][BM*8]
-  uint4* ws = smem + 2 * XLD;      // [2][BN*8]
+  uint4* xs = smem;                // [NS][BM*8]
+  uint4* ws = smem + NS * XLD;     // [NS][BN*8]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -265,27 +270,35 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     }
   } else {
     uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
-    stage(0);
-    if (nk > 1) stage(1);
-    dma_wait_all();
+    constexpr int PPS = XROWS + WROWS;       // DMA instructions per wave and stage (uniform: NS > 2 is only built for BN >= RSTEP)
+    auto wait_tile = [&](int ahead) {        // `ahead` tiles were issued after the one needed: only their pieces may be in flight
+      if constexpr (NS == 2) { (void)ahead; dma_wait_all(); }
+      else {
+        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPS) : "memory");
+        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPS) : "memory");
+        else dma_wait_all();
+      }
+    };
+    int issued = 0;
+    for (; issued < NS && issued < nk; ++issued) stage(issued);
+    wait_tile(issued - 1);
     __syncthreads();
     load(0, 0, wfA, xfA);
     for (int kt = 0; kt + 1 < nk; ++kt) {  // (last K-step peeled: a conditional barrier block would make hipcc merge the
-      const int cur = kt & 1;              //  LDS counters of both paths and wait for the A fragments before the B MFMAs)
+      const int cur = kt % NS, nxt = (kt + 1) % NS;    //  LDS counters of both paths and wait for the A fragments before the B MFMAs)
       load(cur, 1, wfB, xfB);
       __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads AHEAD of the MFMAs they hide under (hipcc sinks them otherwise)
       mma(wfA, xfA);
-      dma_wait_all();                      // this wave's pieces of tile kt+1 have landed ...
+      wait_tile(issued - (kt + 2));        // this wave's pieces of tile kt+1 have landed ...
       __syncthreads();                     // ... and everyone's; every wave holds its last fragments of tile kt in registers
-      if (kt + 2 < nk) stage(cur);         // refill the buffer just drained (asm DMA: no compiler-inserted drain)
-      load(cur ^ 1, 0, wfA, xfA);
+      if (issued < nk) { stage(cur); ++issued; }   // tile kt+NS refills the buffer just drained (asm DMA: no compiler-inserted drain)
+      load(nxt, 0, wfA, xfA);
       __builtin_amdgcn_sched_barrier(0);
       mma(wfB, xfB);
     }
-    load((nk - 1) & 1, 1, wfB, xfB);
+    load((nk - 1) % NS, 1, wfB, xfB);
     mma(wfA, xfA);
     mma(wfB, xfB);
-
   }
 
   // ---- epilogue: lane holds channels n0..n0+3 (rows of D) of pixel m (column of D) ----
@@ -740,12 +753,12 @@ static int big_variant() {
   return g_tuning[EFFDET_TUNE_IGEMM_BIG];
 }
 
-template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0>
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2>
 int launch(const ConvK& k, hipStream_t st) {
-  const size_t lds = (size_t)2 * (BM + BN) * 8 * sizeof(uint4);                     // double-buffered operand tiles
+  const size_t lds = (size_t)NS * (BM + BN) * 8 * sizeof(uint4);                    // NS-stage operand tiles
   const int grid = k.mtiles * k.ntiles;
-  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT>), lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
+  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS>), lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -755,6 +768,14 @@ int dispatch(ConvK& k, hipStream_t st) {
   int bn;
   if (k.Cout > 64) bn = 128; else if (k.Cout > 32) bn = 64; else if (k.Cout > 16) bn = 32; else bn = 16;
   k.ntiles = (k.Cout + bn - 1) / bn;
+  if constexpr (!SPLIT) {
+    // at most one tile per CU and a K loop worth pipelining: deep staging (see the kernel's NS note)
+    static const int deep_env = getenv("EFFDET_IGEMM_DEEP") ? atoi(getenv("EFFDET_IGEMM_DEEP")) : 1;      // A/B switch
+    if (deep_env && (long long)k.mtiles * k.ntiles <= 256 && k.Kc >= 6 * 8) {
+      if (bn == 128) return launch<T, 128, 2, 8, 0, 4>(k, st);
+      if (bn == 64) return launch<T, 64, 1, 4, 0, 4>(k, st);
+    }
+  }
   switch (bn) {
     case 128: return launch<T, 128, 2, 8, SPLIT>(k, st);
     case 64: return launch<T, 64, 1, 4, SPLIT>(k, st);
