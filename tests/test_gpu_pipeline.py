@@ -183,14 +183,20 @@ def test_forward_raw_is_differentiable(dtype):
     # fp32: 5e-3 of the tensor's scale -- the BiFPN max-pool routing and the ReLU masks are discontinuous in the forward values,
     # so a 1e-7 summation-order difference occasionally moves one gradient entry by a fixed amount (seen: 3.6e-3 on one neck
     # conv weight in some runs, with bitwise-stable kernels: tools/wgrad_stress.py); bf16: see below
-    tol = 5e-3 if dtype == torch.float32 else 0.35
+    # (... and once in ~6 full-suite runs a single entry beyond 5e-3: hence entries at 2e-2 of scale and the tensor as a whole at
+    #  5e-3 in L2, with the absolute floor of the other gradient tests)
+    tol = 2e-2 if dtype == torch.float32 else 0.35
     assert_close_scale(cls.detach().cpu(), rc.detach(), 1e-3 if dtype == torch.float32 else 4e-2, 'cls')
+    gmax = max(float(v.grad.norm()) for v in params.values() if v.grad is not None)
     for k, p in m.named_parameters():
         if params[k].grad is None:
             assert p.grad is None, k
             continue
         if dtype == torch.float32 or k.startswith('bbox_head'):
             assert_close_scale(p.grad.cpu(), params[k].grad, tol, k)
+            if dtype == torch.float32:
+                d = float((p.grad.cpu().double() - params[k].grad.double()).norm())
+                assert d <= 5e-3 * float(params[k].grad.double().norm()) or d <= 5e-5 * gmax, (k, d)
         else:
             # bf16 through ~100 random-weight layers: single entries of the backbone / neck gradients are noisy (BN scales are
             # sums of cancelling terms), the direction is what a training step uses: cosine similarity per tensor
