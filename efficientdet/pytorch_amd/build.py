@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libeffdet_hip.so')
 PER_FILE = {'postprocess.hip': ['-ffp-contract=off']}
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall',
          '-Wno-unused-function'] + os.environ.get('EFFDET_HIPCC_EXTRA', '').split()     # e.g. -DEFFDET_WGRAD_TR_WAVES=4 for A/B runs
 
 

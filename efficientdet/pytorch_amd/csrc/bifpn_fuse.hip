@@ -9,10 +9,10 @@
 // HBM-bound: one pass, 16-byte channel chunks, the resample (nearest x2 / 2x2 max-pool) is folded
 // into the load so no resampled tensor is ever materialised.  Backward walks the COARSE grid so
 // that each thread owns a 2x2 patch: the up-sample gradient (sum over the patch) and the
-// max-pool gradient (route to the arg-max) need no atomics; only the 2-3 weight gradients are
-// reduced: wave shuffles -> LDS -> ONE fp32 atomic set per workgroup, spread over EFFDET_FUSE_SLOTS
-// 256-byte slots.  (Same-cache-line atomics serialise at ~8 ns each on gfx950: one atomic per wave into a
-// single [wrows][wcols] array cost 100 us of a 140 us launch.)
+// max-pool gradient (route to the arg-max) need no atomics; the 2-3 weight gradients are reduced
+// wave shuffles -> LDS -> ONE plain store of the workgroup's partial triple into its own row of `dn`; the
+// weight-gradient kernel adds a node's rows in a fixed order.  (No float atomics: bitwise reproducible.  The first
+// version's one atomic per wave into a single [wrows][wcols] array also cost 100 us of a 140 us launch.)
 #include "common.h"
 
 namespace {
@@ -181,22 +181,34 @@ __global__ __launch_bounds__(256) void fuse_bwd_kernel(const FuseK p) {
   g0 = wave_sum(g0); g1 = wave_sum(g1); g2 = wave_sum(g2);
   if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = g0; red[1][threadIdx.x >> 6] = g1; red[2][threadIdx.x >> 6] = g2; }
   __syncthreads();
-  if (threadIdx.x < 3 && (threadIdx.x < 2 || p.mode == 1)) {
+  float* colbase = p.dn + (long long)p.col * EFFDET_FUSE_COL_FLOATS;
+  if (threadIdx.x < 3) {
     const int r = threadIdx.x;
-    float* slot = p.dn + (blockIdx.x % EFFDET_FUSE_SLOTS) * EFFDET_FUSE_SLOT_FLOATS;
-    atomicAdd(slot + r * p.wcols + p.col, red[r][0] + red[r][1] + red[r][2] + red[r][3]);
+    colbase[4 + 3 * blockIdx.x + r] = (r < 2 || p.mode == 1) ? (red[r][0] + red[r][1]) + (red[r][2] + red[r][3]) : 0.f;
   }
+  if (blockIdx.x == 0 && threadIdx.x == 0) colbase[0] = (float)gridDim.x;
 }
 
-// dn [wrows][wcols] (grads wrt the once-normalised weights) -> dwraw (+=):
+// per-workgroup partial rows of dn (grads wrt the once-normalised weights) -> dwraw (+=):
 //   dw_r = relu'(w_r)/(T+eps) * (dn_r - sum_q dn_q n_q)
-__global__ void fuse_weight_bwd_kernel(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols) {
-  const int col = blockIdx.x * blockDim.x + threadIdx.x;
-  if (col >= wcols) return;
+// One 256-thread workgroup per weight column: thread t adds rows t, t+256, ... of the column's launch, then the fixed
+// shuffle tree and the 4 waves in order.
+__global__ __launch_bounds__(256) void fuse_weight_bwd_kernel(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols) {
+  __shared__ float red[3][4];
+  const int col = blockIdx.x;
+  const float* colbase = dn + (long long)col * EFFDET_FUSE_COL_FLOATS;
+  int nwg = (int)colbase[0];
+  if (nwg > EFFDET_FUSE_MAX_WG) nwg = EFFDET_FUSE_MAX_WG;
+  float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+  for (int w = threadIdx.x; w < nwg; w += 256) { d0 += colbase[4 + 3 * w]; d1 += colbase[4 + 3 * w + 1]; d2 += colbase[4 + 3 * w + 2]; }
+  d0 = wave_sum(d0); d1 = wave_sum(d1); d2 = wave_sum(d2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = d0; red[1][threadIdx.x >> 6] = d1; red[2][threadIdx.x >> 6] = d2; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float r[3] = {0, 0, 0}, d[3] = {0, 0, 0}, T = 0.f;
   for (int i = 0; i < wrows; ++i) {
     r[i] = fmaxf(wraw[i * wcols + col], 0.f); T += r[i];
-    for (int s = 0; s < EFFDET_FUSE_SLOTS; ++s) d[i] += dn[s * EFFDET_FUSE_SLOT_FLOATS + i * wcols + col];
+    d[i] = (red[i][0] + red[i][1]) + (red[i][2] + red[i][3]);
   }
   const float ti = 1.0f / (T + FEPS);
   float dot = 0.f;
@@ -237,14 +249,14 @@ extern "C" int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void
   if (!dout || !a || !b || !da || !db || !wraw || !dn || mode < 0 || mode > 2 || C % ce) return EFFDET_EINVAL;
   if (mode == 1 && (!c || !dc)) return EFFDET_EINVAL;
   if (mode == 0 && ((H | W) & 1)) return EFFDET_EUNSUPPORTED;
-  if (wrows * wcols > EFFDET_FUSE_SLOT_FLOATS) return EFFDET_EUNSUPPORTED;
+  if (col < 0 || col >= wcols) return EFFDET_EINVAL;
   FuseK k{}; k.a = a; k.b = b; k.c = c; k.dout = dout; k.da = da; k.db = db; k.dc = dc; k.wraw = wraw; k.dn = dn;
   k.wrows = wrows; k.wcols = wcols; k.col = col; k.mode = mode; k.B = B; k.H = H; k.W = W; k.C = C;
   k.da_acc = da_accum; k.db_acc = db_accum; k.dc_acc = dc_accum;
   const long long n = (long long)B * (mode == 0 ? (H / 2) * (W / 2) : H * W) * (C / ce);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(grid_for(n, 2048)), dim3(256), 0, st, k);
-  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(fuse_bwd_kernel<bf16_t>, dim3(grid_for(n, 2048)), dim3(256), 0, st, k);
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(fuse_bwd_kernel<float>, dim3(grid_for(n, EFFDET_FUSE_MAX_WG)), dim3(256), 0, st, k);
+  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(fuse_bwd_kernel<bf16_t>, dim3(grid_for(n, EFFDET_FUSE_MAX_WG)), dim3(256), 0, st, k);
   else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
@@ -253,8 +265,7 @@ extern "C" int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void
 extern "C" int effdet_bifpn_weight_bwd(const float* wraw, const float* dn, float* dwraw, int wrows, int wcols,
                                        effdet_stream_t stream) {
   if (!wraw || !dn || !dwraw || wrows < 2 || wrows > 3) return EFFDET_EINVAL;
-  if (wrows * wcols > EFFDET_FUSE_SLOT_FLOATS) return EFFDET_EUNSUPPORTED;
-  hipLaunchKernelGGL(fuse_weight_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wraw, dn, dwraw, wrows, wcols);
+  hipLaunchKernelGGL(fuse_weight_bwd_kernel, dim3(wcols), dim3(256), 0, (hipStream_t)stream, wraw, dn, dwraw, wrows, wcols);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

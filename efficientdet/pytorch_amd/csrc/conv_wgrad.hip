@@ -19,7 +19,8 @@
 //     coalesced stores and a vectorised reduce kernel sums the slabs into dw (cross-XCD float atomics
 //     from all splits serialise at the memory side: measured 10x the MFMA time).
 //   * the bias gradient rides along as one extra MFMA per dz fragment against an all-ones
-//     operand (blocks of j-tile 0 only).
+//     operand (blocks of j-tile 0 only); every split stores its partial row [Cout] next to its slab, and the
+//     consumer sums the rows in slab order -- no float atomics anywhere: two runs are bitwise equal.
 #include "common.h"
 #include <stdlib.h>
 
@@ -36,6 +37,7 @@ struct WSeg {
 };
 struct WgradK {
   const void* x; const void* dz; float* dw; float* dbias; float* slab;
+  float* dbp;       // bias-gradient partials [split][Cout] (one plain store per (split, channel): summed in slab order downstream)
   int Cin, Cout, KW, stride, pad_t, pad_l;
   int ldx, lddz;
   int B;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_bias = (p.dbias != nullptr) && (jt == 0) && (wj0 == 0);
+  const bool want_bias = (p.dbp != nullptr) && (jt == 0) && (wj0 == 0);
   const uint4 ones = WMma<T>::ones();
 
   if (nsteps > 0) {
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
           const int j = jt * 128 + wj0 + b * 16 + l15;
           if (j < p.K) slab[(long long)n * p.K + j] = acc[a][b][r];
         }
-        if (want_bias && l15 == 0) atomicAdd(p.dbias + n, bsum[a][r]);
+        if (want_bias && l15 == 0) p.dbp[(long long)split * p.Cout + n] = bsum[a][r];      // (no atomics: bitwise reproducible)
       }
     }
   } else {
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradK p) {
       const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
       if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
     }
+    if (p.dbp && jt == 0 && tid < 128 && nt * 128 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 128 + tid] = 0.f;
   }
 }
 
@@ -418,7 +421,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
 #pragma unroll
     for (int b = 0; b < JT; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_bias = (p.dbias != nullptr) && (jt == 0) && (wj0 == 0);
+  const bool want_bias = (p.dbp != nullptr) && (jt == 0) && (wj0 == 0);
   const uint4 ones = WMma<bf16_t>::ones();
   const int l15 = lane & 15, lq = lane >> 4;
   float* slab = p.slab + (long long)split * p.Cout * p.K;
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
           const int j = jt * 128 + wj0 + b * 16 + l15;
           if (j < p.K) slab[(long long)n * p.K + j] = acc[a][b][rr];
         }
-        if (want_bias && l15 == 0) atomicAdd(p.dbias + n, bsum[a][rr]);
+        if (want_bias && l15 == 0) p.dbp[(long long)split * p.Cout + n] = bsum[a][rr];
       }
     }
   } else {
@@ -466,6 +469,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
       const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
       if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
     }
+    if (p.dbp && jt == 0 && tid < 128 && nt * 128 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 128 + tid] = 0.f;
   }
 }
 
@@ -573,7 +577,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
 #pragma unroll
     for (int b = 0; b < JB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  const bool want_bias = (p.dbias != nullptr) && (jt == 0) && (wj0 == 0);
+  const bool want_bias = (p.dbp != nullptr) && (jt == 0) && (wj0 == 0);
   float* slab = p.slab + (long long)split * p.Cout * p.K;
 
   if (nsteps > 0) {
@@ -692,7 +696,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
 #pragma unroll
           for (int b = 0; b < JB; ++b) if (j0 + b < p.K) dst[b] = acc[a][b][reg];
         }
-        if (want_bias && c15 == 0) atomicAdd(p.dbias + nn, bsum[a][reg]);
+        if (want_bias && c15 == 0) p.dbp[(long long)split * p.Cout + nn] = bsum[a][reg];
       }
     }
   } else {
@@ -700,6 +704,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
       const int nn = nt * 128 + i / 128, j = jt * 128 + (i & 127);
       if (nn < p.Cout && j < p.K) slab[(long long)nn * p.K + j] = 0.f;
     }
+    if (p.dbp && jt == 0 && tid < 128 && nt * 128 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 128 + tid] = 0.f;
   }
 }
 
@@ -719,6 +724,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+// dbias[c] += sum_s part[s][c] in slab order (one thread per channel: a few hundred loads, 4 chains in flight)
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ part, float* __restrict__ dbias, int Cout, int splits) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cout) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  for (; k + 3 < splits; k += 4) {
+    s0 += part[(long long)k * Cout + c]; s1 += part[(long long)(k + 1) * Cout + c];
+    s2 += part[(long long)(k + 2) * Cout + c]; s3 += part[(long long)(k + 3) * Cout + c];
+  }
+  for (; k < splits; ++k) s0 += part[(long long)k * Cout + c];
+  dbias[c] += (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace
 
 namespace {
@@ -727,7 +746,7 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
   if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
   const int ce = p->dtype == EFFDET_F32 ? 4 : 8;
   if (p->Cin % ce || p->ldx % ce) return EFFDET_EUNSUPPORTED;
-  k.x = p->x; k.dz = p->dz; k.dw = p->dw; k.dbias = p->dbias; k.slab = nullptr;
+  k.x = p->x; k.dz = p->dz; k.dw = p->dw; k.dbias = p->dbias; k.slab = nullptr; k.dbp = nullptr;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
   k.ldx = p->ldx; k.lddz = p->lddz; k.B = p->B;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt; k.K = p->KH * p->KW * p->Cin;
@@ -802,7 +821,7 @@ extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   if (plan(p, k, splits) != EFFDET_OK) return -1;
-  return (long long)splits * p->Cout * k.K * (long long)sizeof(float);
+  return (long long)splits * p->Cout * (k.K + 1) * (long long)sizeof(float);      // slabs + the [splits][Cout] bias partials
 }
 
 extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
@@ -860,8 +879,9 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   const int rc = plan(p, k, splits);
   if (rc != EFFDET_OK) return rc;
   const long long n = (long long)p->Cout * k.K;
-  if (workspace_bytes < (long long)splits * n * (long long)sizeof(float)) return EFFDET_EINVAL;
+  if (workspace_bytes < (long long)splits * (n + p->Cout) * (long long)sizeof(float)) return EFFDET_EINVAL;
   k.slab = (float*)workspace;
+  k.dbp = p->dbias ? (float*)workspace + (long long)splits * n : nullptr;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
   // Partition the pyramid levels between the two kernels; each launch numbers its own splits from 0 and owns a
@@ -886,6 +906,7 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   for (int s = ns; s < EFFDET_MAX_SEG; ++s) { ks.seg[s] = ks.seg[0]; ks.seg[s].split_start = 0x7fffffff; }
   kf.nseg = nf; ks.nseg = ns;
   ks.slab = k.slab + (long long)sf * n;
+  if (k.dbp) ks.dbp = k.dbp + (long long)sf * p->Cout;
   if (nf > 0 && p->dtype == EFFDET_F32 && pn_x3) {
     EFFDET_SET_MAX_LDS((conv_wgrad_f32dma_kernel<X3_NW, 1>), lds);
     hipLaunchKernelGGL((conv_wgrad_f32dma_kernel<X3_NW, 1>), dim3((unsigned)(k.ntiles * k.jtiles * sf)), dim3(X3_NW * 64), lds, st, kf);
@@ -914,6 +935,11 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
     long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
     EFFDET_CHECK_LAUNCH();
+    if (p->dbias) {
+      hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((p->Cout + 255) / 256)), dim3(256), 0, st, (const float*)k.dbp, p->dbias,
+                         p->Cout, splits);
+      EFFDET_CHECK_LAUNCH();
+    }
   }
   return EFFDET_OK;
 }

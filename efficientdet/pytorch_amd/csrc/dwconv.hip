@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
       const int l = tid / CE, e = tid - l * CE;
       const float v = red[0][l * 8 + e] + red[1][l * 8 + e] + red[2][l * 8 + e] + red[3][l * 8 + e];
       const int cch = (chunk0 + l) * CE + e;
-      if (cch < p.C) atomicAdd(p.pool + (long long)b * p.C + cch, v);
+      // one plain store per (image, tile group, channel): the squeeze-excite gate kernel adds the tile groups of an image in
+      // a fixed order (an fp32 atomicAdd here made the pooled sum -- and everything downstream -- differ from run to run)
+      if (cch < p.C) p.pool[((long long)b * groups + (bs.x - b * groups)) * p.C + cch] = v;
     }
   }
 }
@@ -537,15 +539,15 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
     }
   }
   __syncthreads();
-  // One wave-wide fp32 atomic per (row, 64 channels): 64 consecutive addresses = two cache-line transactions, a few
-  // hundred per line over the whole launch (the same-line serialisation that hurts is ONE lane per instruction onto a
-  // shared line).  g / dsum are zeroed by the caller; this replaces the per-workgroup slabs + reduce launch.
-  float* gout = (float*)p.y;                              // [K*K][C]
+  // One plain store per (workgroup, row, channel) into this workgroup's slab row; dw_wgrad_reduce_kernel adds the rows of
+  // all (image, tile group) workgroups in a fixed order.  (The previous form added them with wave-wide fp32 atomics onto
+  // g / dsum: one launch fewer, but the summation order -- hence the low bits -- changed from run to run.)
+  float* slab = (float*)p.y + (long long)bs.x * ROWS * p.C;          // [tile group over all images][ROWS][C]
   for (int i = tid; i < ROWS * SLABC; i += 256) {
     const int t = i / SLABC, c = i - t * SLABC;
     const int ch = chunk0 * CE + c;
-    const float v = red[i] + red[ROWS * SLABC + i] + red[2 * ROWS * SLABC + i] + red[3 * ROWS * SLABC + i];
-    if (ch < p.C) atomicAdd(t < K * K ? gout + (long long)t * p.C + ch : p.pool + ch, v);     // p.pool carries dsum here
+    const float v = (red[i] + red[ROWS * SLABC + i]) + (red[2 * ROWS * SLABC + i] + red[3 * ROWS * SLABC + i]);
+    if (ch < p.C) slab[(long long)t * p.C + ch] = v;
   }
 }
 
@@ -624,14 +626,22 @@ inline int tiles_per_wg(long long total_tiles) {
   long long ppt = total_tiles / 2048;
   return ppt < 1 ? 1 : (ppt > 16 ? 16 : (int)ppt);
 }
+// tiles per workgroup / tile groups per image of the forward launch (shared by the launcher and effdet_dwconv_fwd_pool_groups)
+inline int fwd_tiles(int B, int nch, int stride, int Ho, int Wo, int& ppt) {
+  const int th = stride == 1 ? 16 : 8, tw = 8;               // DwTile<K, S>::TH / TW
+  const int cq = slab_chunks(nch), nslab = (nch + cq - 1) / cq;
+  const int tpi = ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
+  ppt = tiles_per_wg((long long)tpi * B * nslab);
+  if (ppt > tpi) ppt = tpi;
+  return (tpi + ppt - 1) / ppt;
+}
 template <typename T, int K, int S, int CQ>
 int launch_fwd_lds(const DwK& a0, hipStream_t st) {
   typedef DwTile<K, S> TL;
   DwK a = a0;
   const size_t tile = (size_t)TL::npiece(64 / CQ) * 1024, wb = (size_t)K * K * CQ * Elem<T>::CE * 4;
   const int tpi = ((a.Ho + TL::TH - 1) / TL::TH) * ((a.Wo + TL::TW - 1) / TL::TW), nslab = (a.nch + CQ - 1) / CQ;
-  a.ppt = tiles_per_wg((long long)tpi * a.B * nslab);
-  if (a.ppt > tpi) a.ppt = tpi;
+  (void)fwd_tiles(a.B, a.nch, S, a.Ho, a.Wo, a.ppt);
   static const int nb_env = getenv("EFFDET_DW_NBUF") ? atoi(getenv("EFFDET_DW_NBUF")) : 0;    // A/B switch
   a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024 && nb_env != 1) ? 2 : 1;                  // keep >= 2 workgroups per CU
   const size_t lds = a.nbuf * tile + wb;
@@ -685,6 +695,13 @@ int launch_wgrad_lds(const DwK& a0, hipStream_t st) {
     else DW_DISPATCH_Q(FN, bf16_t, k, s, a, st);                                               \
   } while (0)
 }  // namespace
+
+extern "C" int effdet_dwconv_fwd_pool_groups(int dtype, int B, int C, int stride, int Ho, int Wo) {
+  if ((dtype != EFFDET_F32 && dtype != EFFDET_BF16) || B < 1 || C < 1 || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
+  const int ce = dtype == EFFDET_F32 ? 4 : 8;
+  int ppt;
+  return fwd_tiles(B, C / ce, stride, Ho, Wo, ppt);
+}
 
 extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* scale, const float* shift, void* y,
                                  void* z, float* pool, int dtype, int B, int H, int W, int C, int k, int stride,
@@ -753,8 +770,7 @@ extern "C" long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H
                                                           int pad_l, int Ho, int Wo) {
   DwK a{}; dim3 grid;
   if (wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo)) return -1;
-  if (!wgrad_direct(Ho, Wo)) return 256;                   // LDS-tiled path accumulates straight into g / dsum
-  return (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float);
+  return (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float);     // one slab row set per workgroup (both kernels)
 }
 
 extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, float* dsum, void* workspace,
@@ -764,7 +780,7 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
   DwK a{}; dim3 grid;
   int rc = wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
-  if (wgrad_direct(Ho, Wo) && workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
+  if (workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
   a.x = x; a.aux = dz; a.y = workspace;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -777,14 +793,13 @@ extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, floa
       if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 3>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((dw_wgrad_kernel<bf16_t, 5>), grid, dim3(256), 0, st, a);
     }
-    EFFDET_CHECK_LAUNCH();
-    const int rows = k * k + 1;
-    hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum,
-                       (int)grid.x, rows, C);
   } else {
-    a.y = g; a.pool = dsum;                               // accumulated in place (zeroed by the caller)
-    DW_DISPATCH(launch_wgrad_lds, dtype, k, stride, a, st);
+    DW_DISPATCH(launch_wgrad_lds, dtype, k, stride, a, st);  // a.y = the slabs: [grid.x = B * tile groups][k*k + 1][C]
   }
+  EFFDET_CHECK_LAUNCH();
+  const int rows = k * k + 1;
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum,
+                     (int)grid.x, rows, C);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

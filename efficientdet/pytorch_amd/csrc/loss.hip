@@ -3,12 +3,14 @@
 //
 //   kernel 1 (assign): one thread per (image, anchor): IoU against the image's valid annotations
 //            (pad rows label == -1 skipped), max / first-argmax, state = positive (IoU >= 0.5) /
-//            negative (< 0.4) / ignored, smooth-L1 on the positives, block-reduced into
-//            stat[b] = {cls_sum, reg_sum, num_pos, num_valid_annotations} (one 128-byte line per image:
-//            same-line fp32 atomics serialise at ~8 ns each on gfx950).
+//            negative (< 0.4) / ignored, smooth-L1 on the positives; stat[b] = {cls_sum, reg_sum, num_pos,
+//            num_valid_annotations} (one 128-byte line per image).  num_pos is an INTEGER count (int atomics: exact whatever
+//            the order); the smooth-L1 partial of every workgroup goes to its own slot part_reg[b][block].
 //   kernel 2 (cls):    one thread per 4 class probabilities (16-byte loads): focal BCE with the
-//            reference's clamp to [1e-4, 1-1e-4], summed into stat[b].cls_sum.
-//   kernel 3 (final):  losses[0] = mean_b cls_sum/max(npos,1), losses[1] = mean_b reg_sum/(4*npos).
+//            reference's clamp to [1e-4, 1-1e-4], one partial per workgroup in part_cls[b][block].
+//   kernel 3 (final):  adds every image's partials in a fixed pattern (one wave per image), then
+//            losses[0] = mean_b cls_sum/max(npos,1), losses[1] = mean_b reg_sum/(4*npos).
+//   No float atomics on anything but exact integer counts: two runs give bitwise-equal losses.
 //   backward: d/d(logit) of the class term (through clamp and sigmoid) and d/d(reg), scaled by
 //            the upstream scalar grads, written in the activation dtype that the head's
 //            data-gradient convs consume.
@@ -24,10 +26,14 @@ constexpr int CLS_IT = 8;     // 4-element groups per thread in the class pass (
 struct LossK {
   const float* cls; const float* reg; const float* anchors; const float* annots; const float* gscale;
   float* losses; int* assign; float* stat;           // stat[b][SS]
+  float* part_reg; float* part_cls; int na, ncb;     // per-workgroup partial sums [B][na] / [B][ncb] (na, ncb: workgroups per image)
   void* dcls; void* dreg;
   int B, nc, N; long long A;
   int dld;           // channel pitch of the pixel-major dcls layout (0 = [B][A][nc])
 };
+
+// stat[b][2] holds the number of positive anchors as an int32 bit pattern (integer atomics: exact, order-independent)
+__device__ __forceinline__ float npos(const float* st) { return (float)__float_as_int(st[2]); }
 
 __global__ __launch_bounds__(256) void loss_assign_kernel(const LossK p) {
   const int b = blockIdx.y;
@@ -91,8 +97,8 @@ __global__ __launch_bounds__(256) void loss_assign_kernel(const LossK p) {
   if (lane == 0) { red[0][wave] = regl; red[1][wave] = pos; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(p.stat + b * SS + 1, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-    atomicAdd(p.stat + b * SS + 2, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+    p.part_reg[(long long)b * p.na + blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    atomicAdd((int*)(p.stat + b * SS + 2), (int)(red[1][0] + red[1][1] + red[1][2] + red[1][3]));    // num_pos is kept as an INTEGER (npos())
     if (blockIdx.x == 0) p.stat[b * SS + 3] = (float)total_valid;
   }
 }
@@ -145,17 +151,27 @@ __global__ __launch_bounds__(256) void loss_cls_kernel(const LossK p) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(p.stat + b * SS + 0, t); }
+  if (threadIdx.x == 0) p.part_cls[(long long)b * p.ncb + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void loss_final_kernel(const LossK p) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// one workgroup: wave w adds the partials of images w, w + 16, ... (lane-strided, then the fixed shuffle tree), thread 0 the images
+__global__ __launch_bounds__(1024) void loss_final_kernel(const LossK p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < p.B; b += 16) {
+    float c = 0.f, r = 0.f;
+    for (int i = lane; i < p.ncb; i += 64) c += p.part_cls[(long long)b * p.ncb + i];
+    for (int i = lane; i < p.na; i += 64) r += p.part_reg[(long long)b * p.na + i];
+    c = wave_sum(c); r = wave_sum(r);
+    if (lane == 0) { p.stat[b * SS + 0] = c; p.stat[b * SS + 1] = r; }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   float cl = 0.f, rl = 0.f;
   for (int b = 0; b < p.B; ++b) {
     const float* s = p.stat + b * SS;
     if (s[3] > 0.f) {
-      cl += s[0] / fmaxf(s[2], 1.0f);
-      if (s[2] > 0.f) rl += s[1] / (s[2] * 4.0f);
+      cl += s[0] / fmaxf(npos(s), 1.0f);
+      if (npos(s) > 0.f) rl += s[1] / (npos(s) * 4.0f);
     }
   }
   p.losses[0] = cl / (float)p.B; p.losses[1] = rl / (float)p.B;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(256) void loss_bwd_cls_kernel(const LossK p) {
   if (e0 >= per) return;
   const float* st = p.stat + b * SS;
   const bool active = st[3] > 0.f;
-  const float gs = active ? p.gscale[0] / ((float)p.B * fmaxf(st[2], 1.0f)) : 0.f;
+  const float gs = active ? p.gscale[0] / ((float)p.B * fmaxf(npos(st), 1.0f)) : 0.f;
   const float* c = p.cls + (long long)b * per;
   const int* asg = p.assign + (long long)b * p.A;
   T* out = (T*)p.dcls + (long long)b * per;
@@ -210,7 +226,7 @@ __global__ __launch_bounds__(256) void loss_bwd_cls_pix_kernel(const LossK p) {
     const int an = ch / p.nc, k = ch - an * p.nc, a = pix * 9 + an;
     const int code = p.assign[(long long)b * p.A + a];
     if (code != -2) {
-      const float gs = p.gscale[0] / ((float)p.B * fmaxf(st[2], 1.0f));
+      const float gs = p.gscale[0] / ((float)p.B * fmaxf(npos(st), 1.0f));
       const int lab = code >= 0 ? (int)p.annots[((long long)b * p.N + code) * 5 + 4] : -1;
       const f32x4 v = *(const f32x4*)(p.cls + (long long)b * p.A * p.nc + (long long)pix * cmax + ch);
 #pragma unroll
@@ -227,7 +243,7 @@ __global__ __launch_bounds__(256) void loss_bwd_cls_pix_kernel(const LossK p) {
 // loss_cls_kernel, and d(loss)/d(logit) for an upstream gradient of 1 is written in the pixel-major padded layout above.
 // The upstream scalar is applied downstream (it multiplies a LINEAR chain: the head's data-gradient conv takes it as its
 // per-image output scale, the retina_cls parameter gradients are scaled after unpacking), so backward never re-reads
-// the 15.7 MB/image of probabilities.  FG_IT 4-element groups per thread keep the same-line atomics per image few.
+// the 15.7 MB/image of probabilities.  FG_IT 4-element groups per thread keep the per-workgroup partials (summed by loss_final_kernel) few.
 constexpr int FG_IT = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void loss_cls_grad_pix_kernel(const LossK p) {
@@ -235,7 +251,7 @@ __global__ __launch_bounds__(256) void loss_cls_grad_pix_kernel(const LossK p) {
   const int apix = (int)(p.A / 9), perp = apix * p.dld, cmax = 9 * p.nc;
   const float* st = p.stat + b * SS;
   const bool active = st[3] > 0.f;
-  const float gs = 1.0f / ((float)p.B * fmaxf(st[2], 1.0f));
+  const float gs = 1.0f / ((float)p.B * fmaxf(npos(st), 1.0f));
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < FG_IT; ++it) {
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256) void loss_cls_grad_pix_kernel(const LossK p) {
   s = wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) { const float t = red[0] + red[1] + red[2] + red[3]; if (t != 0.f) atomicAdd(p.stat + b * SS + 0, t); }
+  if (threadIdx.x == 0) p.part_cls[(long long)b * p.ncb + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 template <typename T>
@@ -273,8 +289,8 @@ __global__ void loss_bwd_reg_kernel(const LossK p) {
     const int code = p.assign[i];
     const float* st = p.stat + b * SS;
     f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (code >= 0 && st[3] > 0.f && st[2] > 0.f) {
-      const float gs = p.gscale[1] / ((float)p.B * st[2] * 4.0f);
+    if (code >= 0 && st[3] > 0.f && npos(st) > 0.f) {
+      const float gs = p.gscale[1] / ((float)p.B * npos(st) * 4.0f);
       const float4 an = ((const float4*)p.anchors)[a];
       const float* gt = p.annots + (b * p.N + code) * 5;
       const float aw = an.z - an.x, ah = an.w - an.y, acx = an.x + 0.5f * aw, acy = an.y + 0.5f * ah;
@@ -300,32 +316,42 @@ inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" long long effdet_loss_workspace_bytes(int B, long long A) {
-  return (long long)(al((size_t)B * A * 4) + al((size_t)B * SS * 4));
+// workgroups per image of the assign pass / upper bound of the class pass (either kernel: dld <= 9*nc + 63)
+static inline long long assign_blocks(long long A) { return (A + 255) / 256; }
+static inline long long cls_blocks_max(long long A, int nc) { return ((A * nc + 3) / 4 + (A / 9 + 1) * 16 + 1023) / 1024 + 1; }
+
+extern "C" long long effdet_loss_workspace_bytes(int B, long long A, int num_classes) {
+  return (long long)(al((size_t)B * A * 4) + al((size_t)B * SS * 4) + al((size_t)B * assign_blocks(A) * 4) +
+                     al((size_t)B * cls_blocks_max(A, num_classes) * 4));
 }
 
 static void carve_loss(LossK& k, void* ws, int B, long long A) {
   k.assign = (int*)ws;
   k.stat = (float*)((char*)ws + al((size_t)B * A * 4));
+  k.part_reg = (float*)((char*)k.stat + al((size_t)B * SS * 4));
+  k.part_cls = (float*)((char*)k.part_reg + al((size_t)B * assign_blocks(A) * 4));
+  k.na = (int)assign_blocks(A);
 }
 
 extern "C" int effdet_focal_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* annots,
                                      float* losses, void* workspace, long long workspace_bytes, int B, long long A,
                                      int num_classes, int N, effdet_stream_t stream) {
   if (!cls || !reg || !anchors || !annots || !losses || !workspace) return EFFDET_EINVAL;
-  if (workspace_bytes < effdet_loss_workspace_bytes(B, A) || B > 65535 || N < 1) return EFFDET_EINVAL;
+  if (workspace_bytes < effdet_loss_workspace_bytes(B, A, num_classes) || B > 65535 || N < 1) return EFFDET_EINVAL;
   if (A * num_classes >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
   LossK k{}; k.cls = cls; k.reg = reg; k.anchors = anchors; k.annots = annots; k.losses = losses;
   k.B = B; k.nc = num_classes; k.N = N; k.A = A;
   carve_loss(k, workspace, B, A);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(k.stat, 0, (size_t)B * SS * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-  hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)((A + 255) / 256), B), dim3(256), 0, st, k);
+  hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)k.na, B), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   const long long groups = (A * num_classes + 3) / 4;
-  hipLaunchKernelGGL(loss_cls_kernel, dim3((unsigned)((groups + 256 * CLS_IT - 1) / (256 * CLS_IT)), B), dim3(256), 0, st, k);
+  k.ncb = (int)((groups + 256 * CLS_IT - 1) / (256 * CLS_IT));
+  if (k.ncb > cls_blocks_max(A, num_classes)) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(loss_cls_kernel, dim3((unsigned)k.ncb, B), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, k);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -373,7 +399,7 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
                                           float* losses, void* workspace, long long workspace_bytes, void* dcls_pix, int dld,
                                           int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream) {
   if (!cls || !reg || !anchors || !annots || !losses || !workspace || !dcls_pix) return EFFDET_EINVAL;
-  if (workspace_bytes < effdet_loss_workspace_bytes(B, A) || B > 65535 || N < 1) return EFFDET_EINVAL;
+  if (workspace_bytes < effdet_loss_workspace_bytes(B, A, num_classes) || B > 65535 || N < 1) return EFFDET_EINVAL;
   if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
   if (dld <= 0 || A % 9 || num_classes % 4 || dld % 4 || dld < 9 * num_classes) return EFFDET_EINVAL;
   if (A * num_classes >= 0x7fffffffLL || (A / 9) * dld >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
@@ -382,14 +408,16 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
   carve_loss(k, workspace, B, A);
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(k.stat, 0, (size_t)B * SS * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-  hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)((A + 255) / 256), B), dim3(256), 0, st, k);
+  hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)k.na, B), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   const long long groups = (A / 9) * dld / 4;
-  dim3 g1((unsigned)((groups + 256 * FG_IT - 1) / (256 * FG_IT)), B);
+  k.ncb = (int)((groups + 256 * FG_IT - 1) / (256 * FG_IT));
+  if (k.ncb > cls_blocks_max(A, num_classes)) return EFFDET_EINVAL;
+  dim3 g1((unsigned)k.ncb, B);
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(loss_cls_grad_pix_kernel<float>, g1, dim3(256), 0, st, k);
   else hipLaunchKernelGGL(loss_cls_grad_pix_kernel<bf16_t>, g1, dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, k);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -18,7 +18,15 @@ struct OptK {
   float* partial; float* norm; int* steps;
   float max_norm, lr, beta1, beta2, eps, wd;
   int nblocks, ntensors, write_grad;
+  const float* hyper;      // optional DEVICE copy of {max_norm, lr, beta1, beta2, eps, wd}: read at run time, so a captured
+                           // step (hipGraph replay) follows a learning-rate schedule instead of the values frozen at capture
 };
+
+struct Hyper { float max_norm, lr, beta1, beta2, eps, wd; };
+__device__ __forceinline__ Hyper hyper_of(const OptK& k) {
+  if (k.hyper) return Hyper{k.hyper[0], k.hyper[1], k.hyper[2], k.hyper[3], k.hyper[4], k.hyper[5]};
+  return Hyper{k.max_norm, k.lr, k.beta1, k.beta2, k.eps, k.wd};
+}
 
 __device__ __forceinline__ float block_sum(float s) {
   __shared__ float red[4];
@@ -62,22 +70,23 @@ __global__ __launch_bounds__(1024) void opt_norm_final_kernel(const float* __res
   if (threadIdx.x == 0) { float t = 0.f; for (int i = 0; i < 16; ++i) t += red[i]; norm[0] = sqrtf(t); }
 }
 
-__device__ __forceinline__ void adamw1(float& p, float& m, float& v, float g, const OptK& k, float step_size, float bc2_sqrt) {
+__device__ __forceinline__ void adamw1(float& p, float& m, float& v, float g, const Hyper& k, float step_size, float bc2_sqrt) {
   p -= k.lr * k.wd * p;
   m = k.beta1 * m + (1.f - k.beta1) * g;
   v = k.beta2 * v + (1.f - k.beta2) * g * g;
   p -= step_size * m / (sqrtf(v) / bc2_sqrt + k.eps);
 }
 
-__global__ __launch_bounds__(256) void opt_adamw_kernel(const OptK k) {
-  const int ti = k.block_tensor[blockIdx.x];
-  float* g = (float*)k.g[ti];
+__global__ __launch_bounds__(256) void opt_adamw_kernel(const OptK kk) {
+  const Hyper k = hyper_of(kk);
+  const int ti = kk.block_tensor[blockIdx.x];
+  float* g = (float*)kk.g[ti];
   if (!g) return;
-  float* p = (float*)k.p[ti]; float* m = (float*)k.m[ti]; float* v = (float*)k.v[ti];
-  const float coef = k.max_norm > 0.f ? fminf(1.0f, k.max_norm / (k.norm[0] + 1e-6f)) : 1.0f;
-  const float t = (float)k.steps[ti];                       // already advanced by opt_norm_final_kernel
+  float* p = (float*)kk.p[ti]; float* m = (float*)kk.m[ti]; float* v = (float*)kk.v[ti];
+  const float coef = k.max_norm > 0.f ? fminf(1.0f, k.max_norm / (kk.norm[0] + 1e-6f)) : 1.0f;
+  const float t = (float)kk.steps[ti];                       // already advanced by opt_norm_final_kernel
   const float step_size = k.lr / (1.0f - powf(k.beta1, t)), bc2_sqrt = sqrtf(1.0f - powf(k.beta2, t));
-  const long long n = k.n[ti], off = (long long)(blockIdx.x - k.block_first[ti]) * OPT_CHUNK;
+  const long long n = kk.n[ti], off = (long long)(blockIdx.x - kk.block_first[ti]) * OPT_CHUNK;
   const long long end = off + OPT_CHUNK < n ? off + OPT_CHUNK : n;
   const bool al = ((((unsigned long long)(g + off)) | ((unsigned long long)(p + off)) | ((unsigned long long)(m + off)) |
                     ((unsigned long long)(v + off))) & 15ull) == 0;
@@ -93,13 +102,13 @@ __global__ __launch_bounds__(256) void opt_adamw_kernel(const OptK k) {
           pv[e] = pe; mv[e] = me; vv[e] = ve; gv[e] = ge;
         }
         *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
-        if (k.write_grad) *(f32x4*)(g + i) = gv;
+        if (kk.write_grad) *(f32x4*)(g + i) = gv;
       } else {
-        for (long long j = i; j < end; ++j) { const float gj = g[j] * coef; adamw1(p[j], m[j], v[j], gj, k, step_size, bc2_sqrt); if (k.write_grad) g[j] = gj; }
+        for (long long j = i; j < end; ++j) { const float gj = g[j] * coef; adamw1(p[j], m[j], v[j], gj, k, step_size, bc2_sqrt); if (kk.write_grad) g[j] = gj; }
       }
     }
   } else {
-    for (long long i = off + threadIdx.x; i < end; i += 256) { const float gi = g[i] * coef; adamw1(p[i], m[i], v[i], gi, k, step_size, bc2_sqrt); if (k.write_grad) g[i] = gi; }
+    for (long long i = off + threadIdx.x; i < end; i += 256) { const float gi = g[i] * coef; adamw1(p[i], m[i], v[i], gi, k, step_size, bc2_sqrt); if (kk.write_grad) g[i] = gi; }
   }
 }
 
@@ -109,7 +118,7 @@ extern "C" int effdet_clip_adamw_step(const unsigned long long* params, const un
                                       const unsigned long long* exp_avg_sq, const long long* numel, const int* block_tensor,
                                       const int* block_first, int ntensors, int nblocks, float* scratch, int* steps, float max_norm,
                                       float lr, float beta1, float beta2, float eps, float weight_decay, int write_grad,
-                                      effdet_stream_t stream) {
+                                      const float* hyper_dev, effdet_stream_t stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !block_tensor || !block_first || !scratch || !steps || nblocks < 1 ||
       ntensors < 1)
     return EFFDET_EINVAL;
@@ -117,7 +126,7 @@ extern "C" int effdet_clip_adamw_step(const unsigned long long* params, const un
   k.p = params; k.g = grads; k.m = exp_avg; k.v = exp_avg_sq; k.n = numel; k.block_tensor = block_tensor; k.block_first = block_first;
   k.norm = scratch; k.partial = scratch + 64;                       // scratch: 64 + nblocks floats
   k.max_norm = max_norm; k.lr = lr; k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.wd = weight_decay;
-  k.steps = steps; k.nblocks = nblocks; k.ntensors = ntensors; k.write_grad = write_grad;
+  k.steps = steps; k.nblocks = nblocks; k.ntensors = ntensors; k.write_grad = write_grad; k.hyper = hyper_dev;
   hipStream_t st = (hipStream_t)stream;
   if (max_norm > 0.f) {
     hipLaunchKernelGGL(opt_norm_kernel, dim3(nblocks), dim3(256), 0, st, k);

@@ -83,11 +83,20 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
                                                            const float* __restrict__ w, float* __restrict__ dw,
                                                            float* __restrict__ wsum, int accumulate, int Cin, int KH, int KW,
                                                            int Cin_pad, int nslabs, long long slab_stride,
-                                                           const float* __restrict__ dsum, const float* __restrict__ mean,
+                                                           const float* __restrict__ dsum_part, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dbias_out) {
   const int co = blockIdx.x, taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
+  // sum_m dz[m][co]: the weight-gradient launch left one partial per split-K slab ([nslabs][Cout]); wave 0 adds them in a fixed
+  // pattern (lane-strided, then the shuffle tree): no float atomics upstream or here, so the result is bitwise reproducible
+  __shared__ float dsum_sh;
+  if (dsum_part && blockIdx.y == 0 && threadIdx.x < 64) {
+    float t = 0.f;
+    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * gridDim.x + co];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) { dsum_sh = t; if (dbias_out) dbias_out[co] = t; }
+  }
   const float* grow = g + (long long)co * np;
   float part = 0.f;
   auto emit = [&](int pidx, const f32x4& gv) {          // 4 consecutive packed elements (same tap, 4 channels) -> OIHW
@@ -149,8 +158,8 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
       const float ws = red[0] + red[1] + red[2] + red[3];
       if (wsum) wsum[co] = ws;
       if (dgamma) {            // frozen-BN parameter gradients (same arithmetic as bn_param_grad_kernel), no extra launch
-        dgamma[co] = invstd[co] * (ws - mean[co] * dsum[co]);
-        dbeta[co] = dsum[co];
+        dgamma[co] = invstd[co] * (ws - mean[co] * dsum_sh);       // (dsum_sh: written by this thread above)
+        dbeta[co] = dsum_sh;
       }
     }
   }
@@ -235,24 +244,24 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
 
 extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w, float* dw, float* wsum,
                                         int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
-                                        effdet_stream_t stream) {
-  if (!g || !dw || (wsum && !w) || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
+                                        const float* dbias_part, float* dbias_out, effdet_stream_t stream) {
+  if (!g || !dw || (wsum && !w) || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3) || (!dbias_part != !dbias_out)) return EFFDET_EINVAL;
   const int np = KH * KW * Cin_pad;
   const int gy = wsum ? 1 : (np / 4 + 255) / 256;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, gy), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW,
-                     Cin_pad, nslabs, (long long)Cout * np, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr);
+                     Cin_pad, nslabs, (long long)Cout * np, dbias_part, (const float*)nullptr, (const float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, dbias_out);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
-extern "C" int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w, float* dw, const float* dsum,
+extern "C" int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w, float* dw, const float* dsum_part,
                                            const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout,
                                            int Cin, int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream) {
-  if (!g || !dw || !w || !dsum || !mean || !invstd || !dgamma || !dbeta || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
+  if (!g || !dw || !w || !dsum_part || !mean || !invstd || !dgamma || !dbeta || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
   const int np = KH * KW * Cin_pad;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, 1), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, (float*)nullptr, 0, Cin, KH,
-                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum, mean, invstd, dgamma, dbeta);
+                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum_part, mean, invstd, dgamma, dbeta, (float*)nullptr);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

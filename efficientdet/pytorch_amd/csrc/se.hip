@@ -13,15 +13,47 @@ inline int grid_for(long long n, int block = 256) {
 // Latency-bound (a few KB of data per image): the win is the LENGTH OF THE DEPENDENT CHAIN, so every stage
 // issues all of its loads before the first use (16 waves, squeezed channels unrolled x3).
 constexpr int SE_T = 1024;
-__global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+
+// mean[c] = inv_hw * sum_g part[g][c]  for one image: the depthwise forward leaves ONE partial sum per (tile group, channel)
+// -- plain stores, no float atomics -- and this adds them in a fixed pattern: thread (channel lane, slice) walks its slice of the
+// tile groups with four chains, the NT/64 slices meet in LDS and are added in slice order.  Bitwise reproducible.
+template <int NT>
+__device__ __forceinline__ void pool_reduce(const float* __restrict__ part, int G, int C, float inv_hw, float* mean,
+                                            float* scratch, float* __restrict__ pool_out) {
+  constexpr int NSL = NT / 64;
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int per = (G + NSL - 1) / NSL, g0 = min(G, sl * per), g1 = min(G, g0 + per);
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+      const float* q = part + (long long)g0 * C + c;
+      int g = g0;
+      for (; g + 3 < g1; g += 4, q += 4 * (long long)C) { s0 += q[0]; s1 += q[C]; s2 += q[2 * (long long)C]; s3 += q[3 * (long long)C]; }
+      for (; g < g1; ++g, q += C) s0 += q[0];
+    }
+    scratch[threadIdx.x] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && c < C) {
+      float t = scratch[cl];
+#pragma unroll
+      for (int k = 1; k < NSL; ++k) t += scratch[k * 64 + cl];
+      mean[c] = t * inv_hw;
+      if (pool_out) pool_out[c] = t;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restrict__ pool, int G, float* __restrict__ pool_out,
+                                                           const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ w2,
                                                            const float* __restrict__ b2, float* __restrict__ gate,
                                                            float* __restrict__ mid, int C, int Cse, float inv_hw) {
-  extern __shared__ float sm[];          // mean[C] | sw[Cse]
+  extern __shared__ float sm[];          // mean[C] | sw[Cse] | scratch[SE_T]
   float* mean = sm; float* sw = sm + C;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c < C; c += SE_T) mean[c] = pool[(long long)b * C + c] * inv_hw;
-  __syncthreads();
+  pool_reduce<SE_T>(pool + (long long)b * G * C, G, C, inv_hw, mean, sm + C + Cse, pool_out ? pool_out + (long long)b * C : nullptr);
   for (int j0 = wave; j0 < Cse; j0 += 48) {          // one wave per squeezed channel, 3 channels in flight per wave
     float s[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -58,18 +90,19 @@ __global__ __launch_bounds__(SE_T) void se_gate_fwd_kernel(const float* __restri
 // arrival counter between the layers was measured too: the device-scope release fence writes back the whole XCD L2, which made
 // the D0 B = 32 train step 7 % SLOWER; the kernel boundary is the cheaper fence.)
 template <int PHASE>
-__global__ __launch_bounds__(256) void se_gate_fwd_split_kernel(const float* __restrict__ pool, const float* __restrict__ w1,
+__global__ __launch_bounds__(256) void se_gate_fwd_split_kernel(const float* __restrict__ pool, int G, float* __restrict__ pool_out,
+                                                                const float* __restrict__ w1,
                                                                 const float* __restrict__ b1, const float* __restrict__ w2,
                                                                 const float* __restrict__ b2, float* __restrict__ gate,
                                                                 float* __restrict__ mid, float* __restrict__ ws_sw, int C, int Cse,
                                                                 float inv_hw) {
-  extern __shared__ float sm[];          // PHASE 1: mean[C];  PHASE 2: sw[Cse]
+  extern __shared__ float sm[];          // PHASE 1: mean[C] | scratch[256];  PHASE 2: sw[Cse]
   const int sl = blockIdx.x, S = gridDim.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if constexpr (PHASE == 1) {
     float* mean = sm;
-    for (int c = tid; c < C; c += 256) mean[c] = pool[(long long)b * C + c] * inv_hw;
-    __syncthreads();
+    // (every slice workgroup of the image reduces the same partials the same way; slice 0 also publishes the pooled sum)
+    pool_reduce<256>(pool + (long long)b * G * C, G, C, inv_hw, mean, sm + C, (pool_out && sl == 0) ? pool_out + (long long)b * C : nullptr);
     for (int j = sl + S * wave; j < Cse; j += S * 4) {
       float s0 = 0.f, s1 = 0.f;
       const float* row = w1 + (long long)j * C;
@@ -104,7 +137,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_split_kernel(const float* __r
 //   du[c]   = dgate[c]*g(1-g)                       (through the sigmoid)
 //   dmid[j] = swish'(mid[j]) * sum_c w2[c][j]*du[c]
 //   dpool[c]= inv_hw * sum_j w1[j][c]*dmid[j]       (gradient wrt the pooled SUM)
-__global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __restrict__ dgate, const float* __restrict__ gate,
+__global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __restrict__ dgate, int slabs, const float* __restrict__ gate,
                                                              const float* __restrict__ mid, const float* __restrict__ w1,
                                                              const float* __restrict__ w2, float* __restrict__ dpool,
                                                              float* __restrict__ ws_du, float* __restrict__ ws_dmid,
@@ -114,7 +147,12 @@ __global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __rest
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int c = tid; c < C; c += SE_T) {
     const float g = gate[(long long)b * C + c];
-    const float d = dgate[(long long)b * C + c] * g * (1.f - g);
+    const float* dq = dgate + (long long)b * slabs * C + c;          // [slabs][C] partial rows of se_dgate, added in slab order
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    int sl = 0;
+    for (; sl + 3 < slabs; sl += 4) { t0 += dq[(long long)sl * C]; t1 += dq[(long long)(sl + 1) * C]; t2 += dq[(long long)(sl + 2) * C]; t3 += dq[(long long)(sl + 3) * C]; }
+    for (; sl < slabs; ++sl) t0 += dq[(long long)sl * C];
+    const float d = ((t0 + t1) + (t2 + t3)) * g * (1.f - g);
     du[c] = d; ws_du[(long long)b * C + c] = d;
   }
   __syncthreads();
@@ -211,17 +249,19 @@ __global__ void channel_scale_kernel(const T* __restrict__ x, const float* __res
   }
 }
 
-// ---- dgate[b][c] += sum_hw dy*x ; block = (image, pixel slab); LDS accumulate, one global atomic per channel ----
+// ---- dgate_part[b][slab][c] = sum over the slab's pixels of dy*act(x); block = (image, pixel slab) ----
+// No atomics: the row groups of a workgroup meet in LDS and are added in row-group order, every workgroup stores its own
+// partial row, and the gate backward kernel adds the slabs of an image in slab order (bitwise reproducible).
+inline int se_dgate_slabs(long long HW) { long long s = (HW + 15) / 16; return (int)(s > 64 ? 64 : (s < 1 ? 1 : s)); }    // >= 16 pixels per workgroup
+
 template <typename T>
 __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy, const T* __restrict__ x,
-                                                       float* __restrict__ dgate, long long HW, int C, int slabs, int act) {
+                                                       float* __restrict__ dgate_part, long long HW, int C, int slabs, int act) {
   constexpr int CE = Elem<T>::CE;
-  extern __shared__ float accs[];                 // [C]
+  extern __shared__ float accs[];                 // [rpp][C]
   const int cpr = C / CE;
   const int b = blockIdx.x / slabs, slab = blockIdx.x - b * slabs;
   const long long p0 = HW * slab / slabs, p1 = HW * (slab + 1) / slabs;
-  for (int c = threadIdx.x; c < C; c += 256) accs[c] = 0.f;
-  __syncthreads();
   const int tcols = cpr < 256 ? cpr : 256;
   const int rpp = 256 / tcols;                       // rows per pass
   const int cc0 = threadIdx.x % tcols, r0 = threadIdx.x / tcols;
@@ -243,11 +283,16 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy,
         for (int e = 0; e < CE; ++e) s[e] = fmaf(a[e], q[e], s[e]);
       }
 #pragma unroll
-      for (int e = 0; e < CE; ++e) atomicAdd(&accs[cc * CE + e], s[e]);
+      for (int e = 0; e < CE; ++e) accs[r0 * C + cc * CE + e] = s[e];
     }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dgate + (long long)b * C + c, accs[c]);
+  float* out = dgate_part + ((long long)b * slabs + slab) * C;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = accs[c];
+    for (int r = 1; r < rpp; ++r) t += accs[r * C + c];
+    out[c] = t;
+  }
 }
 
 // ---- dz = (dy*gate + dpool) * swish'(z) ----
@@ -300,21 +345,21 @@ __global__ void add_inplace_kernel(T* __restrict__ y, const T* __restrict__ x, l
   }
 }
 
-// ---- out[c] += sum_rows x[row][c] ----
+// ---- out[c] += sum_rows x[row][c] ----   (utility; one workgroup per 64 columns, no atomics: bitwise reproducible)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long rows, int C,
                                                      int ldx) {
-  // block handles a slab of rows; thread -> channel (strided), rows strided
-  const int tcols = C < 256 ? C : 256;
-  const int rpp = 256 / tcols;
-  const int c0 = threadIdx.x % tcols, r0 = threadIdx.x / tcols;
-  if (r0 >= rpp) return;
-  const long long p0 = rows * blockIdx.x / gridDim.x, p1 = rows * (blockIdx.x + 1) / gridDim.x;
-  for (int c = c0; c < C; c += tcols) {
-    float s = 0.f;
-    for (long long p = p0 + r0; p < p1; p += rpp) s += Elem<T>::ld(x + p * ldx + c);
-    atomicAdd(out + c, s);
+  __shared__ float part[4][64];
+  const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6, c = blockIdx.x * 64 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    long long p = sl;
+    for (; p + 4 < rows; p += 8) { s0 += Elem<T>::ld(x + p * ldx + c); s1 += Elem<T>::ld(x + (p + 4) * ldx + c); }
+    if (p < rows) s0 += Elem<T>::ld(x + p * ldx + c);
   }
+  part[sl][cl] = s0 + s1;
+  __syncthreads();
+  if (sl == 0 && c < C) out[c] += (part[0][cl] + part[1][cl]) + (part[2][cl] + part[3][cl]);
 }
 
 // ---- frozen BatchNorm folding and parameter gradients (per-channel vectors) ----
@@ -359,44 +404,45 @@ __global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const 
 
 #define ST ((hipStream_t)stream)
 
-extern "C" int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
-                                  float* gate, float* mid, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
-  if (!pool || !w1 || !b1 || !w2 || !b2 || !gate) return EFFDET_EINVAL;
-  const size_t lds = (size_t)(C + Cse) * sizeof(float);
+extern "C" int effdet_se_gate_fwd(const float* pool_part, int G, float* pool_out, const float* w1, const float* b1, const float* w2,
+                                  const float* b2, float* gate, float* mid, int B, int C, int Cse, float inv_hw,
+                                  effdet_stream_t stream) {
+  if (!pool_part || G < 1 || !w1 || !b1 || !w2 || !b2 || !gate) return EFFDET_EINVAL;
+  const size_t lds = (size_t)(C + Cse + SE_T) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
-  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(SE_T), lds, ST, pool, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(SE_T), lds, ST, pool_part, G, pool_out, w1, b1, w2, b2, gate, mid, C, Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
-extern "C" int effdet_se_gate_fwd_split(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
-                                        float* gate, float* mid, float* ws_sw, int B, int C, int Cse, float inv_hw,
-                                        effdet_stream_t stream) {
-  if (!pool || !w1 || !b1 || !w2 || !b2 || !gate || !ws_sw || B < 1) return EFFDET_EINVAL;
+extern "C" int effdet_se_gate_fwd_split(const float* pool_part, int G, float* pool_out, const float* w1, const float* b1,
+                                        const float* w2, const float* b2, float* gate, float* mid, float* ws_sw, int B, int C,
+                                        int Cse, float inv_hw, effdet_stream_t stream) {
+  if (!pool_part || G < 1 || !w1 || !b1 || !w2 || !b2 || !gate || !ws_sw || B < 1) return EFFDET_EINVAL;
   // many images already fill the GPU with one workgroup each, and a second launch costs more than it saves (D0 B = 32: 14 us)
-  if (B > 16 || Cse < 8) return effdet_se_gate_fwd(pool, w1, b1, w2, b2, gate, mid, B, C, Cse, inv_hw, stream);
-  const size_t lds = (size_t)(C > Cse ? C : Cse) * sizeof(float);
+  if (B > 16 || Cse < 8) return effdet_se_gate_fwd(pool_part, G, pool_out, w1, b1, w2, b2, gate, mid, B, C, Cse, inv_hw, stream);
+  const size_t lds = (size_t)((C + 256) > Cse ? (C + 256) : Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
   const int S = 8;
-  hipLaunchKernelGGL(se_gate_fwd_split_kernel<1>, dim3(S, B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
-  hipLaunchKernelGGL(se_gate_fwd_split_kernel<2>, dim3(S, B), dim3(256), lds, ST, pool, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_fwd_split_kernel<1>, dim3(S, B), dim3(256), lds, ST, pool_part, G, pool_out, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_fwd_split_kernel<2>, dim3(S, B), dim3(256), lds, ST, pool_part, G, pool_out, w1, b1, w2, b2, gate, mid, ws_sw, C, Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
 extern "C" long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse) { return (long long)B * (C + 2 * Cse); }
 
-extern "C" int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool, const float* w1,
+extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, const float* gate, const float* mid, const float* pool, const float* w1,
                                   const float* b1, const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                                   float* workspace, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
   (void)b1;
-  if (!dgate || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2 || !workspace) return EFFDET_EINVAL;
+  if (!dgate || dgate_slabs < 1 || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2 || !workspace) return EFFDET_EINVAL;
   if (Cse < 1 || Cse > SE_T) return EFFDET_EUNSUPPORTED;
   const int R = SE_T / Cse;
   const size_t lds = (size_t)(C + Cse + R * Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
   float* ws_du = workspace; float* ws_dmid = ws_du + (size_t)B * C; float* ws_sw = ws_dmid + (size_t)B * Cse;
-  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
+  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, dgate_slabs, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
                      Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   const long long n = 2LL * C * Cse + C + Cse;
@@ -426,14 +472,19 @@ extern "C" int effdet_channel_scale(const void* x, const float* gate, void* y, i
   return EFFDET_OK;
 }
 
-extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate, int act, int dtype, int B, long long HW, int C,
+extern "C" int effdet_se_dgate_slabs(long long HW) { return se_dgate_slabs(HW); }
+
+extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, int dtype, int B, long long HW, int C,
                                effdet_stream_t stream) {
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
-  if (!dy || !x || !dgate || C % ce) return EFFDET_EINVAL;
+  if (!dy || !x || !dgate_part || C % ce) return EFFDET_EINVAL;
   if (act != EFFDET_ACT_NONE && act != EFFDET_ACT_SWISH) return EFFDET_EUNSUPPORTED;
-  int slabs = (int)((HW + 15) / 16); if (slabs > 64) slabs = 64; if (slabs < 1) slabs = 1;     // >= 16 pixels per workgroup
-  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const float*)dy, (const float*)x, dgate, HW, C, slabs, act);
-  else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), (size_t)C * 4, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate, HW, C, slabs, act);
+  const int slabs = se_dgate_slabs(HW);
+  const int cpr = C / ce, tcols = cpr < 256 ? cpr : 256, rpp = 256 / tcols;
+  const size_t lds = (size_t)rpp * C * 4;
+  if (lds > 60000) return EFFDET_EUNSUPPORTED;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(se_dgate_kernel<float>, dim3(B * slabs), dim3(256), lds, ST, (const float*)dy, (const float*)x, dgate_part, HW, C, slabs, act);
+  else hipLaunchKernelGGL(se_dgate_kernel<bf16_t>, dim3(B * slabs), dim3(256), lds, ST, (const bf16_t*)dy, (const bf16_t*)x, dgate_part, HW, C, slabs, act);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -472,7 +523,7 @@ extern "C" int effdet_add_inplace(void* y, const void* x, int dtype, long long n
 
 extern "C" int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, int ldx, effdet_stream_t stream) {
   if (!x || !out) return EFFDET_EINVAL;
-  int g = (int)((rows + 63) / 64); if (g > 1024) g = 1024; if (g < 1) g = 1;
+  const int g = (C + 63) / 64;
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(g), dim3(256), 0, ST, (const float*)x, out, rows, C, ldx);
   else hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(g), dim3(256), 0, ST, (const bf16_t*)x, out, rows, C, ldx);
   EFFDET_CHECK_LAUNCH();

@@ -407,7 +407,8 @@ class EfficientDet(nn.Module):
         # every forward path starts here: replay (or start recording) this model's batched parameter preparation
         key = (dt, img.device, self.f32_arith)
         ops.set_f32_arith(self.f32_arith)
-        if not self.batched_prep:
+        if not self.batched_prep or getattr(self, '_is_replica', False):
+            # (replicas of nn.DataParallel are rebuilt every forward with fresh parameter tensors: nothing to record against)
             ops.set_prep(None)
         else:
             if key not in self._prep:

@@ -19,21 +19,33 @@ def postprocess(model, cls, reg, anc, H, W):
     return s, l, b, count
 
 
-def finalize(s, l, b, count, scales, score_threshold=0.05, max_detections=100, xywh=False):
-    """eval.py:104-117 / :279-292 for the batch on the device -> (dets [B,max_detections,6], counts [B]) on the HOST."""
+def default_max_detections(xywh, A, num_classes=None):
+    """eval.py:104-117 (_get_detections, the VOC path) keeps the 100 best detections per image; eval.py:279-306 (evaluate_coco)
+    emits EVERY detection scoring >= the threshold and leaves the capping to COCOeval (maxDets per image AND category).  The
+    xywh / COCO path therefore defaults to 100 per category (bounded by the NMS output size), not 100 per image."""
+    if not xywh:
+        return 100
+    return int(min(A, 100 * num_classes)) if num_classes else int(A)
+
+
+def finalize(s, l, b, count, scales, score_threshold=0.05, max_detections=None, xywh=False, num_classes=None):
+    """eval.py:104-117 / :279-292 for the batch on the device -> (dets [B,max_detections,6], counts [B]) on the HOST.
+    max_detections=None: default_max_detections (100 per image for the VOC rows, 100 per category for the COCO rows)."""
+    if max_detections is None:
+        max_detections = default_max_detections(xywh, s.shape[1], num_classes)
     sc = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else scales,
                          dtype=torch.float32, device=s.device).contiguous()
     out, oc = ops.finalize_dets(s, l, b, count, sc, score_threshold, max_detections, xywh)
     return out.cpu().numpy(), oc.cpu().numpy()             # the one device->host transfer of the batch
 
 
-def detections_batched(model, images, scales, score_threshold=0.05, max_detections=100, xywh=False):
+def detections_batched(model, images, scales, score_threshold=0.05, max_detections=None, xywh=False):
     """-> (dets [B, max_detections, 6] fp32 on the HOST: x1,y1,x2,y2 (or x,y,w,h), score, label; counts [B] ints).
     images: NCHW fp32 batch or PackedImages; scales: [B] resize factors (tensor, array or list)."""
     with torch.no_grad():
         cls, reg, anc = model.forward_raw(images)
         s, l, b, count = postprocess(model, cls, reg, anc, int(images.shape[2]), int(images.shape[3]))
-        return finalize(s, l, b, count, scales, score_threshold, max_detections, xywh)
+        return finalize(s, l, b, count, scales, score_threshold, max_detections, xywh, getattr(model, 'num_classes', None))
 
 
 def all_detections_rows(dets, counts, num_classes):

@@ -73,9 +73,7 @@ def stem_bwd(saved, dy):
     x, z, s, inv, mean, w, pad = saved
     Cout, ce = w.shape[0], x.C
     dz = ops.act_bwd(dy, z, ACT_SWISH)
-    ar = ZeroArena(ZeroArena.need(Cout), w.device)
-    dsum = ar.take(Cout)
-    G = ops.conv2d_wgrad(x, dz, None, dsum, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
+    G, dsum = ops.conv2d_wgrad(x, dz, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
     dw, dg, db = ops.unpack_wgrad_bn(G, w, s, dsum, mean, inv, cin_pad=ce)     # + frozen-BN gamma/beta grads, one launch
     return dw, dg, db
 
@@ -99,15 +97,14 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
     wk = ops.dw_pack_weight(P['dw.weight'])
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
-    pool = ops.zeros((B, blk.cexp), dev)
     # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):
     # the gate multiply and the backward of the gate recompute Swish from it
     z_only = train and not DW_SAVE_Y
-    xd, zd = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=pool,
-                            save_y=not z_only)
+    xd, zd, pool_part = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=True,
+                                       save_y=not z_only)
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
-    gate, mid = ops.se_gate_fwd(pool, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
+    gate, mid, pool = ops.se_gate_fwd(pool_part, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
     xs = ops.channel_scale(zd, gate, ACT_SWISH) if z_only else ops.channel_scale(xd, gate)
     s2, t2, i2 = ops.bn_fold(P['bn2.weight'], P['bn2.bias'], P['bn2.running_mean'], P['bn2.running_var'], BN_EPS)
     y = Map.new(B, Ho, Wo, blk.cout, dtype, dev)
@@ -127,12 +124,10 @@ def mbconv_bwd(sv, dy):
     B, H, W = x.B, x.H, x.W
     g = {}
     Ce, Co, Ci, Cs, kk = blk.cexp, blk.cout, blk.cin, blk.cse, blk.k * blk.k
-    ar = ZeroArena(ZeroArena.need(Co, Ce), dev)
     # ---- project conv (+ drop_connect scale on the branch) ----
     rs = sv['rowscale'] if blk.skip else None
     dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
-    dsum2 = ar.take(Co)
-    G2 = ops.conv2d_wgrad(sv['xs'], dz2, None, dsum2, Cin=Ce, Cout=Co, KH=1, KW=1)
+    G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dz2, Cin=Ce, Cout=Co, KH=1, KW=1)
     wp = P['project.weight']
     g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'])
     dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
@@ -154,8 +149,7 @@ def mbconv_bwd(sv, dy):
     if blk.expand == 1:
         return dze, g           # block 0: depthwise acts on the block input directly, no skip
     # ---- expand conv; the identity-skip gradient is added in the data-gradient epilogue ----
-    dsum0 = ar.take(Ce)
-    G0 = ops.conv2d_wgrad(x, dze, None, dsum0, Cin=Ci, Cout=Ce, KH=1, KW=1)
+    G0, dsum0 = ops.conv2d_wgrad(x, dze, Cin=Ci, Cout=Ce, KH=1, KW=1)
     we = P['expand.weight']
     g['expand.weight'], g['bn0.weight'], g['bn0.bias'] = ops.unpack_wgrad_bn(G0, we, sv['s0'], dsum0, P['bn0.running_mean'], sv['i0'])
     dx = Map.new(B, H, W, Ci, dtype, dev)
@@ -179,10 +173,9 @@ def lateral_bwd(feats, weights, douts, dtype):
     dfs, dws, dbs = [], [], []
     for f, w, dy in zip(feats, weights, douts):
         W, Cin = w.shape[0], w.shape[1]
-        db = ops.zeros(W, w.device)
-        G = ops.conv2d_wgrad(f, dy, None, db, Cin=Cin, Cout=W, KH=1, KW=1)
+        G, dbp = ops.conv2d_wgrad(f, dy, Cin=Cin, Cout=W, KH=1, KW=1)
         dw = torch.empty_like(w)
-        ops.unpack_wgrad(G, dw)
+        db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
         df = Map.new(f.B, f.H, f.W, Cin, dtype, w.device)
         ops.conv2d(dy, ops.pack_weight(w, dtype, mode=1), df, Cin=W, Cout=Cin, KH=1, KW=1)
         dfs.append(df); dws.append(dw); dbs.append(db)
@@ -234,8 +227,9 @@ def bifpn_module_bwd(saved, douts, dtype):
     grads = {}                                   # tensor name -> Map (private, safe to accumulate into)
     for n, d in zip(out_names, douts):
         grads[n] = Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
-    ar = ZeroArena(ZeroArena.need(*([Wc] * 8), ops.FUSE_DN_FLOATS, ops.FUSE_DN_FLOATS), dev)
-    dn1, dn2 = ar.take(ops.FUSE_DN_FLOATS), ar.take(ops.FUSE_DN_FLOATS)
+    n1, n2 = ops.fuse_dn_floats(w1.shape[1]), ops.fuse_dn_floats(w2.shape[1])
+    ar = ZeroArena(ZeroArena.need(n1, n2), dev)
+    dn1, dn2 = ar.take(n1), ar.take(n2)     # per-workgroup partial rows of d loss / d n_r (zeroed: a column without a launch adds nothing)
     dcw, dcb = [None] * 8, [None] * 8
 
     def target(name):
@@ -247,9 +241,8 @@ def bifpn_module_bwd(saved, douts, dtype):
 
     for (mode, col, wsel, a_n, b_n, c_n, out_n, f, ci) in reversed(nodes):
         dz = grads[out_n]                                            # conv has bias only: dz = dy
-        db = ar.take(Wc)
-        G = ops.conv2d_wgrad(f, dz, None, db, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
-        dw = torch.empty_like(cw[ci]); ops.unpack_wgrad(G, dw)
+        G, dbp = ops.conv2d_wgrad(f, dz, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+        dw = torch.empty_like(cw[ci]); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
         dcw[ci], dcb[ci] = dw, db
         df = Map.new(f.B, f.H, f.W, Wc, dtype, dev)
         ops.conv2d(dz, ops.pack_weight(cw[ci], dtype, mode=1), df, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
@@ -329,7 +322,6 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     g = {}
-    ar = ZeroArena(ZeroArena.need(*[w.shape[0] for name, w in HP.items() if name.endswith('weight')]), dev)
     dp_maps = None
     for tower, dout, per in (('cls', dcls_logit, nc), ('reg', dreg, 4)):
         fin = f'retina_{tower}'
@@ -346,9 +338,8 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
             Cfp = (Cf + ce - 1) // ce * ce
             if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
                 dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
-        db = ar.take(Cf)
-        G = ops.conv2d_wgrad(acts[tower][3], dzmaps, None, db, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
-        dw = torch.empty_like(wf); ops.unpack_wgrad(G, dw)
+        G, dbp = ops.conv2d_wgrad(acts[tower][3], dzmaps, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
+        dw = torch.empty_like(wf); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
         rows = None
         if tower == 'cls' and cls_gscale is not None:
             dw = dw * cls_gscale; db = db * cls_gscale
@@ -362,9 +353,8 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
             w = HP[f'{tower}_convs.{t}.weight']
             xin = acts[tower][t - 1] if t > 0 else p
             Cin = w.shape[1]
-            db = ar.take(256)
-            G = ops.conv2d_wgrad(xin, dz, None, db, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
-            dw = torch.empty_like(w); ops.unpack_wgrad(G, dw)
+            G, dbp = ops.conv2d_wgrad(xin, dz, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
+            dw = torch.empty_like(w); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
             g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
             wd = ops.pack_weight(w, dtype, mode=1)
             if t > 0:

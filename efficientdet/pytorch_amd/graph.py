@@ -4,7 +4,9 @@ backward -> clip -> optimizer.step) for fixed batch shapes.
 The eager step issues ~560 launches through Python + ctypes (host floor ~12 ms on D0 B=32); a captured step is ONE
 hipGraphLaunch.  Everything the step does is already capture-safe by construction: kernels never allocate or synchronise
 (include/effdet_hip.h), the per-step parameter repacks replay a recorded table, the drop_connect step counter and the AdamW
-step counters live on the device, and the gradient-pointer table is static inside the graph's private memory pool.
+step counters live on the device, and the gradient-pointer table is static inside the graph's private memory pool.  The optimizer's hyper-parameters (lr, betas,
+eps, weight_decay, max_norm) are read by the update kernel from a device buffer that __call__ refreshes from
+optimizer.param_groups before every replay, so lr schedulers keep working; only switching clipping on/off needs a re-capture.
 
     step = GraphedTrainStep(model, optimizer, images, annotations)       # warm-up + capture
     for batch in loader:
@@ -15,6 +17,8 @@ Single-process, single-GPU (DDP's bucket hooks are left to eager mode).  Drop ev
 before constructing this (a live loss keeps that step's autograd graph and its default-stream AccumulateGrad nodes alive, which
 a capture on another stream must not touch)."""
 import torch
+
+from . import ops
 
 
 class GraphedTrainStep:
@@ -35,6 +39,8 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph):
             self.losses = self._step()
         torch.cuda.synchronize()
+        self._hyper0 = self._hyper_sig()
+        ops.bump_param_generation()
 
     def _step(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -46,8 +52,20 @@ class GraphedTrainStep:
         return cl, rl
 
     def __call__(self):
+        # hyper-parameters (lr schedule, train.py:133,269) live in a device buffer the captured update kernel reads: refresh
+        # it from param_groups before the replay; stock optimizers (by-value kernel scalars) cannot follow -> fail loudly
+        sync = getattr(self.optimizer, 'sync_hyper', None)
+        if sync is not None:
+            sync()
+        elif self._hyper_sig() != self._hyper0:
+            raise RuntimeError('GraphedTrainStep: optimizer hyper-parameters changed after capture and %s bakes them into the '
+                               'captured kernels; use optim.ClipAdamW or re-capture the step' % type(self.optimizer).__name__)
         self.graph.replay()
+        ops.bump_param_generation()             # the replay rewrote the parameters through raw pointers (no Tensor._version bump)
         return self.losses
+
+    def _hyper_sig(self):
+        return [sorted((k, repr(v)) for k, v in g.items() if k != 'params') for g in self.optimizer.param_groups]
 
 
 class GraphedDetect:

@@ -139,6 +139,17 @@ def _segs(desc, xs, ys, base_x, base_y, isz_x, isz_y):
 # ----------------------------------------------------------------------------- batched parameter preparation
 PREP_PACK0, PREP_PACK1, PREP_BNFOLD, PREP_DWPACK = 0, 1, 2, 3
 
+# Writers that change parameters through RAW POINTERS (effdet_clip_adamw_step, every replay of a captured train step) never
+# move Tensor._version, which is what the inference-side "packed copies are still fresh" test looks at: they bump this
+# process-wide generation instead (ClipAdamW.step, graph.GraphedTrainStep.__call__), and the fingerprint includes it.
+_PARAM_GENERATION = 0
+
+
+def bump_param_generation():
+    global _PARAM_GENERATION
+    _PARAM_GENERATION += 1
+
+
 
 class ParamPrep:
     """Record / replay of the per-step parameter repacks (conv weight packs, frozen-BN folds, depthwise packs).
@@ -153,6 +164,7 @@ class ParamPrep:
         self.f32_arith = f32_arith          # arithmetic of the owner's MFMA launches on fp32 storage (see set_f32_arith)
         self.jobs, self.outs, self.bn_src = {}, {}, {}
         self.table, self.dirty, self.replay = None, False, False
+        self._n0 = 0                        # jobs of the first build since the last reset (bounds the table's growth)
         self._fresh = None                  # (source version sum, stream) the arena was last refreshed for -- inference only
         self.zbuf, self.zpos, self.zreq, self.zsize = None, 0, 0, 0
 
@@ -172,22 +184,43 @@ class ParamPrep:
             return v
         return torch.zeros(n, dtype=torch.float32, device=device)
 
+    def reset(self):
+        """Forget every recorded job (the next step records afresh)."""
+        self.jobs, self.outs, self.bn_src = {}, {}, {}
+        self.table, self.dirty, self.replay, self._fresh, self._n0 = None, False, False, None, 0
+
+    def _sources_moved(self):
+        """A recorded source tensor no longer lives where the job table says (p.data = ..., a parameter swapped for another
+        tensor, replicas of nn.DataParallel): the device-side table would read stale or foreign memory."""
+        for job in self.jobs.values():
+            for t, a in zip(job[1], job[7]):
+                if t is not None and t.data_ptr() != a:
+                    return True
+        return False
+
     def begin_step(self, device=None):
         if device is not None:
             self._begin_zeros(device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if self.jobs and not capturing:
+            # pointer validation (jobs are keyed on addresses): re-record from scratch when a source moved, and keep the table
+            # bounded -- lookups that miss every step (tensors re-created per forward) would otherwise grow it without limit
+            if self._sources_moved() or (self.table is not None and len(self.jobs) > 2 * max(self._n0, 64)):
+                self.reset()
         if self.dirty:
             self._build()
         self.replay = self.table is not None
         if self.replay:
-            # Inference: the packed copies in the arena stay valid while no source tensor was written (optimizer step,
-            # load_state_dict, .copy_ all bump Tensor._version): skip the launch (0.05 ms of a 5 ms D0 forward, 0.2 of 12 for D4).
+            # Inference: the packed copies in the arena stay valid while no source tensor was written (torch optimizers,
+            # load_state_dict, .copy_ all bump Tensor._version; the raw-pointer writers -- ClipAdamW, graph replays -- bump
+            # _PARAM_GENERATION): skip the launch (0.05 ms of a 5 ms D0 forward, 0.2 of 12 for D4).
             # Never under graph capture (a captured forward must refresh them on every replay) nor with autograd on.
             fp = None
-            if not torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
-                fp = (self._version_sum(), torch.cuda.current_stream().cuda_stream)
+            if not torch.is_grad_enabled() and not capturing:
+                fp = (self._version_sum(), _PARAM_GENERATION, torch.cuda.current_stream().cuda_stream)
                 if fp == self._fresh:
                     return
-            jobs, bj, bf, nblocks, _ = self.table
+            jobs, bj, bf, nblocks = self.table[:4]
             L.check(L.lib().effdet_prepare_params(L.ptr(jobs), L.ptr(bj), L.ptr(bf), nblocks, L.stream_ptr()), 'effdet_prepare_params')
             self._fresh = fp
 
@@ -199,7 +232,8 @@ class ParamPrep:
 
     def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0, code=None):
         if key not in self.jobs:
-            self.jobs[key] = (kind, srcs, dims, dtype, shape, eps, L.dtype_code(dtype) if code is None else code)
+            self.jobs[key] = (kind, srcs, dims, dtype, shape, eps, L.dtype_code(dtype) if code is None else code,
+                              tuple(t.data_ptr() if t is not None else 0 for t in srcs))
             self.dirty = True
 
     def _build(self):
@@ -208,7 +242,7 @@ class ParamPrep:
         dev = self.jobs[keys[0]][1][0].device
         offs, total = [], 0
         for k in keys:
-            kind, srcs, dims, dtype, shape, eps, _ = self.jobs[k]
+            kind, srcs, dims, dtype, shape, eps = self.jobs[k][:6]
             n = 1
             for d in shape:
                 n *= d
@@ -218,7 +252,7 @@ class ParamPrep:
         block_job, block_first, nb = [], [], 0
         self.outs, self.bn_src = {}, {}      # (drop the pointers of record-time temporaries)
         for i, k in enumerate(keys):
-            kind, srcs, dims, dtype, shape, eps, code = self.jobs[k]
+            kind, srcs, dims, dtype, shape, eps, code = self.jobs[k][:7]
             off, n = offs[i]
             out = arena[off:off + n * (2 if dtype == torch.bfloat16 else 4)].view(dtype).view(shape)
             j = arr[i]
@@ -235,6 +269,8 @@ class ParamPrep:
         bj = torch.from_numpy(np.asarray(block_job, dtype=np.int32)).to(dev)
         bf = torch.from_numpy(np.asarray(block_first, dtype=np.int32)).to(dev)
         self.table, self.dirty, self._fresh = (jobs_dev, bj, bf, nb, arena), False, None
+        if not self._n0:
+            self._n0 = len(keys)
 
 
 _tls = threading.local()     # .prep: the ParamPrep of the model whose forward / backward runs on this thread
@@ -279,7 +315,7 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
             hit = PREP.lookup(key)
             if hit is not None:
                 return hit
-            PREP.record(key, PREP_PACK1 if mode else PREP_PACK0, (w, bn[0] if bn else None, bn[1] if bn else None),
+            PREP.record(key, PREP_PACK1 if mode else PREP_PACK0, (w_oihw, bn[0] if bn else None, bn[1] if bn else None),
                         (Cout, Cin, KH, KW, cin_pad), dtype, shape, bn[2] if bn else 0.0, code)
     out = torch.empty(shape, dtype=dtype, device=w.device)
     L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), code, mode,
@@ -325,10 +361,10 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
 
-def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0):
-    """Weight gradient.  dw given: packed dw[Cout][taps][Cin] (fp32) += dz^T * im2col(x).  dw None: returns the
-    UNREDUCED split-K slabs (tensor [splits][Cout][taps][Cin] fp32) for unpack_wgrad to sum while unpacking.
-    dbias[Cout] += colsum(dz) either way."""
+def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True):
+    """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
+    split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
+    runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ..."""
     if isinstance(xs, Map):
         xs, dzs = [xs], [dzs]
     d = L.WgradDesc()
@@ -338,7 +374,7 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     base_z = min(z.addr() for z in dzs)
     d.x, d.dz = base_x, base_z
     d.dw = dw.data_ptr() if dw is not None else None
-    d.dbias = dbias.data_ptr() if dbias is not None else None
+    d.dbias = dbias.data_ptr() if dbias is not None else (1 if (want_bias and dw is None) else None)    # dw None: only a request flag
     d.dtype = _mma_dtype_code(x0.dtype)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
@@ -348,33 +384,43 @@ def conv2d_wgrad(xs, dzs, dw, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=
     splits = int(L.lib().effdet_conv2d_wgrad_splits(C.byref(d)))
     if splits < 1:
         raise RuntimeError('effdet_conv2d_wgrad: unsupported geometry')
-    slabs = torch.empty((splits, Cout, KH * KW, Cin), dtype=torch.float32, device=x0.t.device)
-    nbytes = slabs.numel() * 4
+    n = Cout * KH * KW * Cin
+    ws = torch.empty(splits * (n + Cout), dtype=torch.float32, device=x0.t.device)
+    nbytes = ws.numel() * 4
     # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
     _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else
            ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>'), flops,
-           lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(slabs), C.c_longlong(nbytes), L.stream_ptr()),
+           lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
-    return slabs
+    slabs = ws[:splits * n].view(splits, Cout, KH * KW, Cin)
+    parts = ws[splits * n:].view(splits, Cout) if d.dbias else None
+    return slabs, parts
 
 
-def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None):
-    """g: packed gradient [Cout][taps][Cin_pad] or unreduced slabs [splits][Cout][taps][Cin_pad] (summed here)."""
+def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None, dbias_part=None):
+    """g: packed gradient [Cout][taps][Cin_pad] or unreduced slabs [splits][Cout][taps][Cin_pad] (summed here).
+    dbias_part ([splits][Cout], from conv2d_wgrad): -> the bias gradient [Cout] (summed in slab order), else None."""
     Cout, Cin, KH, KW = dw_oihw.shape
     nslabs = g.shape[0] if g.dim() == 4 else 1
+    db = torch.empty(Cout, dtype=torch.float32, device=dw_oihw.device) if dbias_part is not None else None
+    assert dbias_part is None or dbias_part.shape == (nslabs, Cout)
     L.check(L.lib().effdet_unpack_conv_wgrad(L.ptr(g), L.ptr(scale), L.ptr(w_oihw), L.ptr(dw_oihw), L.ptr(wsum),
                                              int(accumulate), Cout, Cin, KH, KW, Cin if cin_pad is None else cin_pad,
-                                             nslabs, L.stream_ptr()), 'effdet_unpack_conv_wgrad')
+                                             nslabs, L.ptr(dbias_part), L.ptr(db), L.stream_ptr()), 'effdet_unpack_conv_wgrad')
+    return db
 
 
-def unpack_wgrad_bn(g, w_oihw, scale, dsum, mean, invstd, cin_pad=None):
-    """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta)."""
+def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None):
+    """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta); dsum_part: the [splits][Cout] rows of conv2d_wgrad."""
     Cout, Cin, KH, KW = w_oihw.shape
     nslabs = g.shape[0] if g.dim() == 4 else 1
+    if dsum_part.dim() == 1:
+        dsum_part = dsum_part.view(1, Cout)
+    assert dsum_part.shape == (nslabs, Cout) and dsum_part.is_contiguous()
     dw = torch.empty_like(w_oihw)
     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dw.device)
-    L.check(L.lib().effdet_unpack_conv_wgrad_bn(L.ptr(g), L.ptr(scale), L.ptr(w_oihw.detach()), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
+    L.check(L.lib().effdet_unpack_conv_wgrad_bn(L.ptr(g), L.ptr(scale), L.ptr(w_oihw.detach()), L.ptr(dw), L.ptr(dsum_part), L.ptr(mean),
                                                 L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cout, Cin, KH, KW,
                                                 Cin if cin_pad is None else cin_pad, nslabs, L.stream_ptr()),
             'effdet_unpack_conv_wgrad_bn')
@@ -407,12 +453,12 @@ def bn_fold(gamma, beta, mean, var, eps=1e-3):
         hit = PREP.lookup(key)
         if hit is not None:
             return hit[0], hit[1], hit[2]
-        PREP.record(key, PREP_BNFOLD, (gamma.detach(), beta.detach(), mean, var), (C_,), torch.float32, (3, C_), eps)
+        PREP.record(key, PREP_BNFOLD, (gamma, beta, mean, var), (C_,), torch.float32, (3, C_), eps)
     out = torch.empty((3, C_), dtype=torch.float32, device=gamma.device)     # scale | shift | invstd
     L.check(L.lib().effdet_bn_fold(L.ptr(gamma), L.ptr(beta), L.ptr(mean), L.ptr(var), C.c_float(eps),
                                    L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), C_, L.stream_ptr()), 'effdet_bn_fold')
     if PREP is not None:
-        PREP.bn_src[out[0].data_ptr()] = (gamma.detach(), var, eps)
+        PREP.bn_src[out[0].data_ptr()] = (gamma, var, eps)
     return out[0], out[1], out[2]
 
 
@@ -433,7 +479,7 @@ def dw_pack_weight(w_c1kk):
         hit = PREP.lookup(key)
         if hit is not None:
             return hit
-        PREP.record(key, PREP_DWPACK, (w_c1kk.detach(),), (Cc, 0, k * k), torch.float32, (k * k, Cc))
+        PREP.record(key, PREP_DWPACK, (w_c1kk,), (Cc, 0, k * k), torch.float32, (k * k, Cc))
     out = torch.empty((k * k, Cc), dtype=torch.float32, device=w_c1kk.device)
     L.check(L.lib().effdet_dw_pack_weight(L.ptr(w_c1kk.detach()), L.ptr(out), Cc, k, L.stream_ptr()), 'effdet_dw_pack_weight')
     return out
@@ -458,9 +504,17 @@ def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
     return dw, dgb[0], dgb[1]
 
 
-def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=None, save_y=True):
-    """-> (y, z); save_y=False (needs save_z) stores the pre-activation only: consumers recompute Swish (act=ACT_SWISH)."""
+def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=False, save_y=True):
+    """-> (y, z, pool_part); save_y=False (needs save_z) stores the pre-activation only: consumers recompute Swish (act=ACT_SWISH).
+    pool=True: pool_part [B][G][C] fp32 = per-(image, tile group) partial sums of the Swish output for se_gate_fwd."""
     assert save_y or save_z
+    if pool:
+        G = int(L.lib().effdet_dwconv_fwd_pool_groups(L.dtype_code(x.dtype), x.B, x.C, stride, Ho, Wo))
+        if G < 1:
+            raise RuntimeError('effdet_dwconv_fwd_pool_groups: unsupported geometry')
+        pool = torch.empty((x.B, G, x.C), dtype=torch.float32, device=x.t.device)
+    else:
+        pool = None
     y = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_y else None
     z = Map.new(x.B, Ho, Wo, x.C, x.dtype, x.t.device) if save_z else None
     nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (int(save_y) + int(save_z)))
@@ -468,7 +522,7 @@ def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=F
         L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t if y else None), L.ptr(z.t if z else None), L.ptr(pool),
         L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd'),
         'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
-    return y, z
+    return y, z, pool
 
 
 def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
@@ -482,7 +536,7 @@ def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
 
 
 def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
-    g = zeros((k * k + 1, x.C), x.t.device)       # taps | dsum (accumulated into by the kernel: must start at zero)
+    g = torch.empty((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum (overwritten by the slab reduction)
     geo = (L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W)
     nbytes = int(L.lib().effdet_dwconv_wgrad_workspace_bytes(*geo))
     if nbytes < 0:
@@ -496,16 +550,21 @@ def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
 
 
 # ----------------------------------------------------------------------------- squeeze-excite
-def se_gate_fwd(pool, w1, b1, w2, b2, inv_hw, save_mid=False):
-    B, Cc = pool.shape
+def se_gate_fwd(pool_part, w1, b1, w2, b2, inv_hw, save_mid=False):
+    """pool_part: [B][G][C] partial sums of dwconv_fwd (or a plain [B][C] pool) -> (gate, mid, pool [B][C] = the pooled SUM)."""
+    if pool_part.dim() == 2:
+        pool_part = pool_part.unsqueeze(1)
+    B, G, Cc = pool_part.shape
+    assert pool_part.is_contiguous()
     Cse = w1.shape[0]
-    gate = torch.empty((B, Cc), dtype=torch.float32, device=pool.device)
-    mid = torch.empty((B, Cse), dtype=torch.float32, device=pool.device) if save_mid else None
-    ws = torch.empty((B, Cse), dtype=torch.float32, device=pool.device)
-    L.check(L.lib().effdet_se_gate_fwd_split(L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()), L.ptr(w2.detach()), L.ptr(b2.detach()),
-                                             L.ptr(gate), L.ptr(mid), L.ptr(ws), B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()),
-            'effdet_se_gate_fwd_split')
-    return gate, mid
+    gate = torch.empty((B, Cc), dtype=torch.float32, device=pool_part.device)
+    pool = torch.empty((B, Cc), dtype=torch.float32, device=pool_part.device)
+    mid = torch.empty((B, Cse), dtype=torch.float32, device=pool_part.device) if save_mid else None
+    ws = torch.empty((B, Cse), dtype=torch.float32, device=pool_part.device)
+    L.check(L.lib().effdet_se_gate_fwd_split(L.ptr(pool_part), G, L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()), L.ptr(w2.detach()),
+                                             L.ptr(b2.detach()), L.ptr(gate), L.ptr(mid), L.ptr(ws), B, Cc, Cse, C.c_float(inv_hw),
+                                             L.stream_ptr()), 'effdet_se_gate_fwd_split')
+    return gate, mid, pool
 
 
 def channel_scale(x, gate, act=ACT_NONE):
@@ -517,14 +576,19 @@ def channel_scale(x, gate, act=ACT_NONE):
 
 
 def se_dgate(dy, x, act=ACT_NONE):
-    dg = zeros((x.B, x.C), x.t.device)
+    """-> dgate_part [B][slabs][C]: per-pixel-slab partial sums (added in slab order by se_gate_bwd)."""
+    dg = torch.empty((x.B, int(L.lib().effdet_se_dgate_slabs(C.c_longlong(x.H * x.W))), x.C), dtype=torch.float32, device=x.t.device)
     L.check(L.lib().effdet_se_dgate(L.ptr(dy.tensor()), L.ptr(x.tensor()), L.ptr(dg), act, L.dtype_code(x.dtype), x.B,
                                     C.c_longlong(x.H * x.W), x.C, L.stream_ptr()), 'effdet_se_dgate')
     return dg
 
 
 def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw):
-    """-> (dpool, dw1, db1, dw2, db2); the parameter grads are fresh tensors (overwritten, not accumulated)."""
+    """dgate: [B][slabs][C] partial rows of se_dgate (or a plain [B][C] gradient).
+    -> (dpool, dw1, db1, dw2, db2); the parameter grads are fresh tensors (overwritten, not accumulated)."""
+    if dgate.dim() == 2:
+        dgate = dgate.unsqueeze(1)
+    assert dgate.is_contiguous()
     B, Cc = pool.shape
     Cse = w1.shape[0]
     dev = pool.device
@@ -536,7 +600,7 @@ def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw):
     db2 = out[o:o + Cc]; o += Cc
     ws = out[o:]
     assert ws.numel() >= L.lib().effdet_se_gate_bwd_workspace_floats(B, Cc, Cse)
-    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
+    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
                                        L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(ws),
                                        B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
     return dpool, dw1, db1, dw2, db2
@@ -582,12 +646,16 @@ def bifpn_fuse_fwd(a, b, c, wraw, col, mode):
     return out
 
 
-FUSE_DN_FLOATS = 32 * 64          # EFFDET_FUSE_SLOTS x EFFDET_FUSE_SLOT_FLOATS (include/effdet_hip.h)
+FUSE_COL_FLOATS = 4 + 3 * 2048     # EFFDET_FUSE_COL_FLOATS (include/effdet_hip.h): per weight column, [count | per-workgroup partial triples]
+
+
+def fuse_dn_floats(wcols):
+    return wcols * FUSE_COL_FLOATS
 
 
 def bifpn_fuse_bwd(dout, a, b, c, da, db, dc, da_acc, db_acc, dc_acc, wraw, dn, col, mode):
-    assert dn.numel() == FUSE_DN_FLOATS
     wr, wc = wraw.shape
+    assert dn.numel() == fuse_dn_floats(wc)
     L.check(L.lib().effdet_bifpn_fuse_bwd(L.ptr(dout.tensor()), L.ptr(a.tensor()), L.ptr(b.tensor()),
                                           L.ptr(c.tensor() if c is not None else None), L.ptr(da.tensor()), L.ptr(db.tensor()),
                                           L.ptr(dc.tensor() if dc is not None else None), int(da_acc), int(db_acc), int(dc_acc),
@@ -649,7 +717,7 @@ def gather_dets(boxes, score, label, idx, count):
 def focal_loss_fwd(cls, reg, anc, annots):
     B, A, nc = cls.shape
     N = annots.shape[1]
-    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A)))
+    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A), nc))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=cls.device)
     losses = torch.empty(2, dtype=torch.float32, device=cls.device)
     L.check(L.lib().effdet_focal_loss_fwd(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(losses), L.ptr(ws),
@@ -682,7 +750,7 @@ def focal_loss_fwd_grad(cls, reg, anc, annots, dtype, dld):
     """Training fast path: -> (losses [2], ws, dcls_pix [B, A/9, dld]) in one pass over cls; dcls_pix is the gradient wrt the
     logits for an upstream gradient of ONE (the caller scales downstream, see effdet_hip.h)."""
     B, A, nc = cls.shape
-    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A)))
+    nbytes = int(L.lib().effdet_loss_workspace_bytes(B, C.c_longlong(A), nc))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=cls.device)
     losses = torch.empty(2, dtype=torch.float32, device=cls.device)
     dcls = torch.empty((B, A // 9, dld), dtype=dtype, device=cls.device)

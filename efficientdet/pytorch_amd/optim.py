@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import ops as ops_mod
 
 
 class ClipAdamW(torch.optim.Optimizer):
@@ -27,6 +28,7 @@ class ClipAdamW(torch.optim.Optimizer):
         self.write_clipped_grads = bool(write_clipped_grads)
         self._table = None
         self._step = 0
+        self._captured = False               # a step() ran under stream capture (its launch sequence is frozen in a hipGraph)
 
     # ---- the device tables (built once; parameter and moment storage is stable) ----
     def _build(self):
@@ -64,6 +66,10 @@ class ClipAdamW(torch.optim.Optimizer):
             'g_last': None,
             'scratch': torch.zeros(64 + nb, dtype=torch.float32, device=dev), 'offs': offs,
             'steps': torch.zeros(n, dtype=torch.int32, device=dev), 'p_sig': [p.data_ptr() for p in ps],
+            # hyper-parameters live on the device (read by the update kernel at run time): a captured step follows the
+            # schedule of param_groups[0] -- sync_hyper() refreshes them ahead of a graph replay
+            'hyper': torch.zeros(6, dtype=torch.float32, device=dev), 'hyper_host': torch.zeros(6, dtype=torch.float32).pin_memory(),
+            'hyper_last': None, 'hyper_evt': None,
         }
         for i, p in enumerate(ps):                                     # per-parameter views for state_dict()
             self.state[p] = {'step': torch.tensor(0.0),                # refreshed from the device counters in state_dict()
@@ -101,6 +107,32 @@ class ClipAdamW(torch.optim.Optimizer):
         t['steps'].copy_(steps)
         self._step = int(steps.max()) if t['n'] else 0
 
+    def _hyper_values(self):
+        g = self.param_groups[0]
+        b1, b2 = g['betas']
+        return (float(g['max_norm'] or 0.0), float(g['lr']), float(b1), float(b2), float(g['eps']), float(g['weight_decay']))
+
+    def sync_hyper(self):
+        """Upload param_groups[0]'s {max_norm, lr, betas, eps, weight_decay} to the device buffer the update kernel reads, if
+        they changed since the last upload.  step() calls it; graph.GraphedTrainStep calls it before every replay, so an lr
+        scheduler (train.py:133,269: ReduceLROnPlateau) drives captured steps exactly like eager ones."""
+        if self._table is None:
+            return
+        t, hv = self._table, self._hyper_values()
+        if hv == t['hyper_last']:
+            return
+        if t['hyper_last'] is not None and (hv[0] > 0.0) != (t['hyper_last'][0] > 0.0) and self._captured:
+            raise RuntimeError('ClipAdamW: max_norm switched between 0 and > 0 after the step was captured as a hipGraph '
+                               '(the norm pass is part of the captured launch sequence); re-capture the step')
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError('ClipAdamW: hyper-parameters changed under stream capture; call sync_hyper() before capturing')
+        if t['hyper_evt'] is not None:
+            t['hyper_evt'].synchronize()                               # the copy that last read the pinned buffer has finished
+        t['hyper_host'].copy_(torch.tensor(hv, dtype=torch.float32))
+        t['hyper'].copy_(t['hyper_host'], non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+        t['hyper_evt'], t['hyper_last'] = ev, hv
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -137,11 +169,18 @@ class ClipAdamW(torch.optim.Optimizer):
                 t['g_last'] = ptrs
         self._step += 1
         b1, b2 = g['betas']
+        if torch.cuda.is_current_stream_capturing():
+            self._captured = True
+            if t['hyper_last'] is None:
+                raise RuntimeError('ClipAdamW: run one eager step (or sync_hyper()) before capturing the step as a hipGraph')
+        else:
+            self.sync_hyper()
+        ops_mod.bump_param_generation()      # parameters are rewritten through raw pointers: Tensor._version does not move
         L.check(L.lib().effdet_clip_adamw_step(L.ptr(t['p_ptr']), L.ptr(t['g_ptr']), L.ptr(t['m_ptr']), L.ptr(t['v_ptr']), L.ptr(t['numel']),
                                                L.ptr(t['block_tensor']), L.ptr(t['block_first']), t['n'], t['nblocks'],
                                                L.ptr(t['scratch']), L.ptr(t['steps']), C.c_float(g['max_norm'] or 0.0),
                                                C.c_float(g['lr']), C.c_float(b1), C.c_float(b2), C.c_float(g['eps']),
-                                               C.c_float(g['weight_decay']), int(self.write_clipped_grads), L.stream_ptr()),
+                                               C.c_float(g['weight_decay']), int(self.write_clipped_grads), L.ptr(t['hyper']), L.stream_ptr()),
                 'effdet_clip_adamw_step')
         return loss
 

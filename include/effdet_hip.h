@@ -89,6 +89,11 @@ int effdet_tuning_set(int key, int value);
 /* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]
  * (fp32, packed [Cout][KH*KW][Cin]; split-K partial slabs + a reduce pass, so levels / K-splits add up),
  * and optionally dbias[n] += sum_m dz[m][n].  Replaces autograd of F.conv2d w.r.t. weight/bias.
+ * No float atomics: every split-K block stores its partial tile (and its partial bias row) with plain stores and the
+ * partials are added in slab order, so two runs on the same inputs are BITWISE equal.
+ * dbias: with dw != NULL, dbias[n] += the sum.  With dw == NULL (slabs left unreduced) any non-NULL dbias only REQUESTS the
+ * per-split partial rows [splits][Cout], stored in `workspace` right behind the slabs (at float offset
+ * splits*Cout*KH*KW*Cin) for effdet_unpack_conv_wgrad / _bn to sum; the dbias pointer itself is not written.
  * Segment geometry: in_* addresses x, out_* addresses dz (Ho,Wo rows).
  * dtype EFFDET_F32_BF16X3: fp32 x / dz; the pyramid levels the DMA-staged kernel can take (stride 1, 'same' taps, even
  * row pairs) form their products as bf16x3 (both operands split in registers), the others use the exact fp32 kernel. */
@@ -100,7 +105,7 @@ typedef struct {
   int nseg;
   effdet_seg_t seg[EFFDET_MAX_SEG];
 } effdet_wgrad_t;
-/* workspace: effdet_conv2d_wgrad_workspace_bytes(p) bytes of scratch for the split-K partial slabs. */
+/* workspace: effdet_conv2d_wgrad_workspace_bytes(p) bytes of scratch for the split-K partial slabs + bias partial rows. */
 long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p);
 /* number of split-K slabs the launch writes; with p->dw == NULL the slabs are left unreduced in `workspace`
  * ([splits][Cout][KH*KW][Cin] fp32) for effdet_unpack_conv_wgrad(..., nslabs = splits) to sum while unpacking. */
@@ -115,13 +120,16 @@ int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long work
 int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, int dtype, int mode,
                             int Cout, int Cin, int KH, int KW, int Cin_pad, effdet_stream_t stream);
 /* packed fp32 gradient [nslabs][Cout][KH*KW][Cin_pad] (slabs summed) -> OIHW fp32:  dw_oihw (+)= scale[cout] * g.
- * If wsum != NULL also wsum[cout] = sum_{tap,c} w_oihw * g  (needed for the frozen-BN gamma grad). */
+ * If wsum != NULL also wsum[cout] = sum_{tap,c} w_oihw * g  (needed for the frozen-BN gamma grad).
+ * dbias_part / dbias_out (both or neither): the [nslabs][Cout] bias partial rows of effdet_conv2d_wgrad -> dbias_out[cout] =
+ * their sum in slab order (overwritten, not accumulated). */
 int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
                              float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
-                             effdet_stream_t stream);
+                             const float* dbias_part, float* dbias_out, effdet_stream_t stream);
 /* The same unpack for a conv followed by a frozen BatchNorm, with effdet_bn_param_grad fused in (one launch instead
- * of two per BN conv): dw = scale*g, dgamma = invstd*(sum_k w*g - mean*dsum), dbeta = dsum. */
-int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w_oihw, float* dw_oihw, const float* dsum,
+ * of two per BN conv): dw = scale*g, dgamma = invstd*(sum_k w*g - mean*dsum), dbeta = dsum, where dsum[cout] is the sum of
+ * the [nslabs][Cout] partial rows dsum_part (see effdet_conv2d_wgrad). */
+int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w_oihw, float* dw_oihw, const float* dsum_part,
                                 const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout, int Cin,
                                 int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream);
 
@@ -162,10 +170,14 @@ int effdet_bn_param_grad(const float* wsum, const float* dsum, const float* mean
  * Depthwise kxk conv (k = 3 or 5, stride 1 or 2, asymmetric zero pad) + frozen BN + Swish, with
  * the per-(image, channel) sum of the output (the squeeze of squeeze-excite) as a side output.
  * Replaces models/efficientnet.py:91 (_depthwise_conv/_bn1/_swish) and the adaptive_avg_pool2d
- * of :95.  w: [k*k][C] fp32.  pool: [B][C] fp32, must be zeroed by the caller (+= atomics).
+ * of :95.  w: [k*k][C] fp32.
+ * pool (optional): PARTIAL sums [B][G][C] fp32, G = effdet_dwconv_fwd_pool_groups(...) -- one row per (image, group of
+ * output tiles), every entry overwritten with a plain store (no zeroing, no float atomics); effdet_se_gate_fwd adds the G
+ * rows of an image in a fixed order, so the pooled sum -- and everything downstream -- is bitwise reproducible.
  * y (Swish output) and z (pre-activation, for backward) are each optional but not both NULL; with
  * y == NULL the pooled sum is that of Swish(stored z), i.e. exactly what the consumers recompute.
  * ------------------------------------------------------------------------------------------- */
+int effdet_dwconv_fwd_pool_groups(int dtype, int B, int C, int stride, int Ho, int Wo);
 int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, const float* shift,
                       void* y, void* z, float* pool, int dtype, int B, int H, int W, int C, int k,
                       int stride, int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
@@ -174,9 +186,9 @@ int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, con
 int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,
                         void* dx, int dtype, int B, int H, int W, int C, int k, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
-/* weight gradient g[tap][c] = sum dz*x (unscaled), dsum[c] = sum dz.  g and dsum MUST BE ZERO on entry: maps larger
- * than 8x8 accumulate into them with one wave-wide fp32 atomic per (workgroup, tap, 64 channels); tiny maps go through
- * per-workgroup slabs in `workspace` (effdet_dwconv_wgrad_workspace_bytes) + a reduce pass. */
+/* weight gradient g[tap][c] = sum dz*x (unscaled), dsum[c] = sum dz (both OVERWRITTEN).  Every workgroup stores its partial
+ * rows into its own slab in `workspace` (effdet_dwconv_wgrad_workspace_bytes) and a reduce pass adds the slabs in a fixed
+ * order: no float atomics, two runs are bitwise equal. */
 long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t,
                                               int pad_l, int Ho, int Wo);
 int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, void* workspace,
@@ -196,30 +208,35 @@ int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale, const floa
  * Replaces models/efficientnet.py:95-97.  w1: [Cse][C], w2: [C][Cse] (the 1x1 conv weights as
  * stored), fp32.  One workgroup per image, wave-level reductions.  mid (optional) saves the
  * pre-swish squeeze activations [B][Cse] for backward.
+ * pool_part: [B][G][C] partial sums as left by effdet_dwconv_fwd (G = 1: a plain [B][C] pool); they are added in a fixed
+ * order and the pooled SUM is published in pool_out [B][C] (optional; the gate backward needs it).
  * ------------------------------------------------------------------------------------------- */
-int effdet_se_gate_fwd(const float* pool, const float* w1, const float* b1, const float* w2,
+int effdet_se_gate_fwd(const float* pool_part, int G, float* pool_out, const float* w1, const float* b1, const float* w2,
                        const float* b2, float* gate, float* mid, int B, int C, int Cse, float inv_hw,
                        effdet_stream_t stream);
 /* The same gate for small batches (B <= 16): 8 workgroups per image, one launch per layer (a single workgroup per image is
  * bound by what one CU can pull: 34 us per block for D4 at B = 8).  ws_sw: [B][Cse] floats of scratch.  B > 16 forwards to
  * effdet_se_gate_fwd. */
-int effdet_se_gate_fwd_split(const float* pool, const float* w1, const float* b1, const float* w2, const float* b2,
-                             float* gate, float* mid, float* ws_sw, int B, int C, int Cse, float inv_hw,
-                             effdet_stream_t stream);
+int effdet_se_gate_fwd_split(const float* pool_part, int G, float* pool_out, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* gate, float* mid, float* ws_sw, int B, int C, int Cse,
+                             float inv_hw, effdet_stream_t stream);
 /* y = act(x) * gate[b][c]  (models/efficientnet.py:98).  act = EFFDET_ACT_NONE: x is the depthwise OUTPUT;
  * act = EFFDET_ACT_SWISH: x is the depthwise PRE-activation z (training stores z only -- the step is bound by HBM
  * write bandwidth -- and every consumer recomputes Swish from the stored value). */
 int effdet_channel_scale(const void* x, const float* gate, void* y, int act, int dtype, int B, long long HW,
                          int C, effdet_stream_t stream);
 /* backward of (gate, scale):  given dy (grad of act(x)*gate) and x (act as above):
- *   dgate_raw[b][c] = sum_hw dy*act(x)   (fp32 atomics into dgate, caller zeroes)   */
-int effdet_se_dgate(const void* dy, const void* x, float* dgate, int act, int dtype, int B, long long HW, int C,
+ *   dgate_part[b][slab][c] = sum over the pixel slab of dy*act(x), slab < effdet_se_dgate_slabs(HW)
+ * (every entry overwritten with a plain store; effdet_se_gate_bwd adds the slabs in order: no float atomics)   */
+int effdet_se_dgate_slabs(long long HW);
+int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, int dtype, int B, long long HW, int C,
                     effdet_stream_t stream);
-/* tiny FC backward: from dgate[b][c] (grad wrt gate), gate, mid, pool -> dpool[b][c] (grad wrt the
+/* tiny FC backward: from dgate_part[b][slab][c] (partial grads wrt gate, dgate_slabs rows per image; 1 = a plain
+ * [B][C] gradient), gate, mid, pool -> dpool[b][c] (grad wrt the
  * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (OVERWRITTEN, fp32; batch reductions with one
  * thread per parameter: no atomics, deterministic).  workspace: effdet_se_gate_bwd_workspace_floats() fp32. */
 long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse);
-int effdet_se_gate_bwd(const float* dgate, const float* gate, const float* mid, const float* pool,
+int effdet_se_gate_bwd(const float* dgate_part, int dgate_slabs, const float* gate, const float* mid, const float* pool,
                        const float* w1, const float* b1, const float* w2, float* dpool, float* dw1, float* db1,
                        float* dw2, float* db2, float* workspace, int B, int C, int Cse, float inv_hw,
                        effdet_stream_t stream);
@@ -232,7 +249,7 @@ int effdet_act_bwd(const void* dy, const void* aux, const float* rowscale, void*
                    int B, long long HWC, effdet_stream_t stream);
 /* y (+)= x   (gradient accumulation across branches) */
 int effdet_add_inplace(void* y, const void* x, int dtype, long long n, effdet_stream_t stream);
-/* per-channel column sum: out[c] += sum_rows x[row][c] */
+/* per-channel column sum: out[c] += sum_rows x[row][c]  (one workgroup per 64 columns, fixed order) */
 int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, int ldx,
                   effdet_stream_t stream);
 
@@ -247,13 +264,15 @@ int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, i
 int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out, const float* wraw,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                           effdet_stream_t stream);
-/* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and
- * dn[slot][r*wcols + col] += d loss / d n_r  (grad wrt the ONCE-normalised weights).  dn is an fp32 scratch of
- * EFFDET_FUSE_SLOTS x EFFDET_FUSE_SLOT_FLOATS, zeroed by the caller: workgroups scatter their partial sums over
- * the 256-byte slots (same-cache-line atomics serialise on gfx950); wrows*wcols <= EFFDET_FUSE_SLOT_FLOATS.
- * effdet_bifpn_weight_bwd then sums the slots and maps dn -> dwraw (+=) through the first normalisation. */
-#define EFFDET_FUSE_SLOTS 32
-#define EFFDET_FUSE_SLOT_FLOATS 64
+/* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and the partial sums of
+ * d loss / d n_r (grad wrt the ONCE-normalised weights), one row per workgroup and NO float atomics:
+ *   dn[col * EFFDET_FUSE_COL_FLOATS]                    = number of workgroups of this node's launch
+ *   dn[col * EFFDET_FUSE_COL_FLOATS + 4 + 3*wg + r]     = workgroup wg's partial of d loss / d n_r
+ * dn is an fp32 scratch of wcols * EFFDET_FUSE_COL_FLOATS floats, zeroed by the caller (a column whose node is never
+ * launched then contributes nothing).  effdet_bifpn_weight_bwd adds each column's rows in a fixed order and maps
+ * dn -> dwraw (+=) through the first normalisation: two runs are bitwise equal. */
+#define EFFDET_FUSE_MAX_WG 2048
+#define EFFDET_FUSE_COL_FLOATS (4 + 3 * EFFDET_FUSE_MAX_WG)
 int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, void* da, void* db,
                           void* dc, int da_accum, int db_accum, int dc_accum, const float* wraw, float* dn,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
@@ -295,9 +314,10 @@ int effdet_gather_dets(const float* boxes, const float* score, const int* label,
  * annots [B][N][5] (pad rows label = -1).  Outputs: losses[2] (batch-mean cls, reg), and the
  * gradients wrt the LOGITS of cls (dcls_logit, written in `dtype`) and wrt reg (dreg, `dtype`),
  * already scaled by gscale[0] (cls) / gscale[1] (reg) = the upstream grads of the two losses.
- * workspace: effdet_loss_workspace_bytes(B, A).
+ * workspace: effdet_loss_workspace_bytes(B, A, num_classes) (anchor assignment, per-image statistics and the per-workgroup
+ * partial sums of both loss terms: they are added in a fixed order, so the losses are bitwise reproducible).
  * ------------------------------------------------------------------------------------------- */
-long long effdet_loss_workspace_bytes(int B, long long A);
+long long effdet_loss_workspace_bytes(int B, long long A, int num_classes);
 int effdet_focal_loss_fwd(const float* cls, const float* reg, const float* anchors, const float* annots,
                           float* losses, void* workspace, long long workspace_bytes, int B, long long A,
                           int num_classes, int N, effdet_stream_t stream);
@@ -334,13 +354,17 @@ int effdet_focal_loss_bwd_reg(const float* reg, const float* anchors, const floa
  *                                           (advanced on device for every tensor that has a gradient, as torch does)
  * max_norm <= 0 disables clipping.  write_grad != 0 writes the clipped gradients back like clip_grad_norm_ does (costs
  * one more store per element).
+ * hyper_dev (optional, DEVICE, 6 floats {max_norm, lr, beta1, beta2, eps, weight_decay}): when given, the update kernel
+ * reads the hyper-parameters from it at RUN time instead of the by-value arguments, so that a captured step (hipGraph
+ * replay) follows a learning-rate schedule (train.py:133,269 drives ReduceLROnPlateau every epoch).  Whether the norm pass
+ * runs at all is still decided by the by-value max_norm (> 0) at launch / capture time.
  * ------------------------------------------------------------------------------------------- */
 int effdet_opt_chunk(void);
 int effdet_clip_adamw_step(const unsigned long long* params, const unsigned long long* grads,
                            const unsigned long long* exp_avg, const unsigned long long* exp_avg_sq, const long long* numel,
                            const int* block_tensor, const int* block_first, int ntensors, int nblocks, float* scratch,
                            int* steps, float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                           int write_grad, effdet_stream_t stream);
+                           int write_grad, const float* hyper_dev, effdet_stream_t stream);
 
 /* Row repack with zero channel padding: dst[b][pix][0..Cpad) = src[src_off + b*src_bstride + pix*src_ld + c]
  * for c < C, 0 beyond (makes an unaligned-channel gradient map consumable by effdet_conv2d). */

@@ -252,6 +252,8 @@ CASES = {
     'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),
     'd4_1024_eval': lambda E: case_eval(E, 'd4_1024_eval', 'efficientdet-d4', 80, 1, 1024, threshold=0.6, full=False, dets=False),
     'd0_128_dets_separated': lambda E: case_dets_separated(E, 'd0_128_dets_separated', 'efficientdet-d0', 20, 2, 128),
+    # the same at a BASELINE geometry (configs[1]: D0 @512, 80 classes): complete detection lists, not 'count within 1 %'
+    'd0_512_dets_separated': lambda E: case_dets_separated(E, 'd0_512_dets_separated', 'efficientdet-d0', 80, 2, 512, gain=0.5, seed=2),
     'd0_128_dropconnect': lambda E: case_train_dropconnect(E, 'd0_128_dropconnect', 'efficientdet-d0', 20, 4, 128),
 }
 

@@ -15,6 +15,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     out_path, dtype_name = sys.argv[1], sys.argv[2]
+    wrap = sys.argv[3] if len(sys.argv) > 3 else 'ddp.wrap'
     from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, ddp, synthetic_batch
     from efficientdet.pytorch_amd.optim import ClipAdamW
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
@@ -31,13 +32,16 @@ def main():
         m.train(); m.is_training = True; m.freeze_bn()
         return m
     model = build()
-    net_ddp = ddp.wrap(model, device_ids=[0])
+    if wrap == 'reference':        # train.py:250-251 as written: every parameter trainable, unused-parameter search on
+        net_ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], find_unused_parameters=True)
+    else:
+        net_ddp = ddp.wrap(model, device_ids=[0])
     params = [p for p in model.parameters() if p.requires_grad]
     opt = ClipAdamW(params, lr=1e-4, max_norm=0.1)
     img, ann = synthetic_batch(2 * world, 128, seed=3, num_classes=nc)
     simg, sann = ddp.shard_batch(img, ann, rank, world)
     simg, sann = simg.cuda(), sann.cuda()
-    res = {'rank': rank, 'world': world, 'dtype': dtype_name}
+    res = {'rank': rank, 'world': world, 'dtype': dtype_name, 'wrap': wrap}
     # ---- step 1: DDP-averaged shard gradients == single-process full-batch gradients
     opt.zero_grad(set_to_none=True)
     cl, rl = net_ddp([simg, sann])
@@ -50,7 +54,7 @@ def main():
     worst, worst_l2, nchk = 0.0, 0.0, 0
     for (k, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
         if q.grad is None:
-            assert p.grad is None or not p.requires_grad, k
+            assert p.grad is None or not p.requires_grad or not bool(p.grad.any()), k
             continue
         scale = float(q.grad.abs().max()) + 1e-12
         worst = max(worst, float((p.grad - q.grad).abs().max()) / scale); nchk += 1
@@ -59,7 +63,7 @@ def main():
     # ---- 3 optimizer steps over bucket views, never synchronising in between; replicas must stay bit-identical
     opt.step()
     for it in range(2):
-        opt.zero_grad(set_to_none=False)          # bucket views stay in place (DDP's gradient_as_bucket_view)
+        opt.zero_grad(set_to_none=(wrap == 'reference'))          # ddp.wrap: bucket views stay in place (gradient_as_bucket_view)
         cl, rl = net_ddp([simg, sann])
         (cl.mean() + rl.mean()).backward()
         opt.step()

@@ -42,3 +42,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     import pytest
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _lib.lib()
+
+
+def test_no_float_atomics_in_the_kernels():
+    """Every reduction of the path is a fixed-order sum of per-workgroup partials (bitwise-reproducible runs,
+    tests/test_gpu_determinism.py): the only atomics left in csrc/ act on integers (counters, bit masks, hash slots) or on an
+    integer count (loss.hip: num_pos), and the build does not ask for unsafe fp atomics."""
+    import glob
+    src = os.path.join(ROOT, 'efficientdet', 'pytorch_amd', 'csrc')
+    for f in sorted(glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.h'))):
+        code = re.sub(r'//.*', '', open(f).read())
+        hits = [m.group(0) for m in re.finditer(r'atomicAdd\s*\([^;]*;', code)]
+        floaty = [h for h in hits if not re.search(r'kcount|kover_n|nvalid|&cnt|\(int|counter', h)]
+        assert not floaty, (os.path.basename(f), floaty)
+    assert 'unsafe-fp-atomics' not in open(os.path.join(ROOT, 'efficientdet', 'pytorch_amd', 'build.py')).read()

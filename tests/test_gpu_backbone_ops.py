@@ -43,24 +43,27 @@ def test_dwconv_fwd_bwd(dtype, cfg):
     dev = 'cuda'
     wk = ops.dw_pack_weight(w.detach().to(dev))
     assert_close(wk.cpu(), w.detach().reshape(C, k * k).t(), 1e-7, 'dw pack')
-    pool = torch.zeros(B, C, device=dev)
     xm = nhwc(x.detach(), dtype)
-    ym, zm = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=pool)
+    ym, zm, pp = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=True)
     torch.cuda.synchronize()
     assert_close(nchw(zm), z, TOL[dtype], 'dw z'); assert_close(nchw(ym), y, TOL[dtype], 'dw y')
-    assert_close(pool.cpu(), q(y.detach()).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool')
+    # the squeeze-excite pool arrives as per-(image, tile group) partial rows [B][G][C]: no atomics, two launches bitwise equal
+    assert pp.dim() == 3 and pp.shape[0] == B and pp.shape[2] == C
+    assert_close(pp.sum(dim=1).cpu(), q(y.detach()).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool')
+    assert torch.equal(ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=True)[2], pp)
     # z-only storage (training): same stored z, no y, and the pooled sum is that of Swish(stored z)
-    pool2 = torch.zeros(B, C, device=dev)
-    y2, z2 = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=pool2, save_y=False)
+    y2, z2, pp2 = ops.dwconv_fwd(xm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=True, save_y=False)
     assert y2 is None and torch.equal(z2.tensor(), zm.tensor())
     zs = nchw(z2)
-    assert_close(pool2.cpu(), (zs * torch.sigmoid(zs)).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool (z-only)')
+    assert_close(pp2.sum(dim=1).cpu(), (zs * torch.sigmoid(zs)).sum(dim=(2, 3)), 5 * TOL[dtype], 'se pool (z-only)')
     # backward wrt the pre-activation z: dz given
     dz = q(torch.randn(z.shape, generator=g))
     z.backward(dz)
     dzm = nhwc(dz, dtype)
     dxm = ops.dwconv_dgrad(dzm, wk, scale.to(dev), None, H, W, k, s, plo, plo)
     gk, dsum = ops.dwconv_wgrad(xm, dzm, k, s, plo, plo)
+    gk2, dsum2 = ops.dwconv_wgrad(xm, dzm, k, s, plo, plo)
+    assert torch.equal(gk, gk2) and torch.equal(dsum, dsum2)              # slab reduction in a fixed order: bitwise reproducible
     wsum = torch.empty(C, device=dev)
     dw = ops.dw_unpack_wgrad(gk, scale.to(dev), w.detach().to(dev), wsum)
     torch.cuda.synchronize()
@@ -103,7 +106,12 @@ def test_squeeze_excite_fwd_bwd(dtype, cfg):
     pool = x.detach().sum(dim=(2, 3)).to(dev)
     inv = 1.0 / (H * W)
     w1d, b1d, w2d, b2d = (t.detach().to(dev) for t in (w1, b1, w2, b2))
-    gd, midd = ops.se_gate_fwd(pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), b2d, inv, save_mid=True)
+    gd, midd, pool_out = ops.se_gate_fwd(pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), b2d, inv, save_mid=True)
+    assert torch.equal(pool_out, pool)                                   # G = 1: the pooled sum is passed through
+    # the same pool handed over as 3 partial rows per image: summed in order inside the gate kernel
+    parts = torch.stack([0.25 * pool, 0.5 * pool, 0.25 * pool], dim=1).contiguous()
+    gd3, _, pool3 = ops.se_gate_fwd(parts, w1d.view(Cse, C), b1d, w2d.view(C, Cse), b2d, inv, save_mid=True)
+    assert_close(pool3.cpu(), pool.cpu(), 1e-6, 'se pool from partial rows'); assert_close(gd3.cpu(), gd.cpu(), 1e-5, 'se gate from partial rows')
     ymm = ops.channel_scale(xm, gd)
     torch.cuda.synchronize()
     assert_close(gd.cpu(), gate.detach().view(B, C), 1e-4, 'se gate')
@@ -111,12 +119,15 @@ def test_squeeze_excite_fwd_bwd(dtype, cfg):
     # the same two ops fed with the pre-activation (z-only storage): Swish is recomputed inside
     assert_close(nchw(ops.channel_scale(zm, gd, ops.ACT_SWISH)), y.detach(), TOL[dtype], 'se scale (from z)')
     dym = nhwc(dy, dtype)
-    dg = ops.se_dgate(dym, xm)
-    dg_z = ops.se_dgate(dym, zm, ops.ACT_SWISH)
+    dgp = ops.se_dgate(dym, xm)                                          # [B][slabs][C] partial rows, no atomics
+    assert torch.equal(dgp, ops.se_dgate(dym, xm))
+    dg = dgp.sum(dim=1)
+    assert_close(dg.cpu(), (dy * x.detach()).sum(dim=(2, 3)), 5 * TOL[dtype], 'se dgate')
+    dg_z = ops.se_dgate(dym, zm, ops.ACT_SWISH).sum(dim=1)
     # bf16: Swish(z) here is unrounded while xm holds its bf16 rounding -> a 2^-9 perturbation of every term of a sum with
     # cancellation: compare at tensor scale
     assert_close_scale(dg_z.cpu(), dg.cpu(), 1e-4 if dtype == torch.float32 else 1e-2, 'se dgate (from z)')
-    dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dg, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
+    dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgp, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
     dzm = ops.se_bwd_apply(dym, gd, dpool, zm)
     torch.cuda.synchronize()
     t = 5 * TOL[dtype]
@@ -181,6 +192,6 @@ def test_se_gate_both_forms(B, C, Cse):
     inv = 1.0 / 49.0
     mid = (pool * inv) @ w1.t() + b1
     gate = torch.sigmoid((mid * torch.sigmoid(mid)) @ w2.t() + b2)
-    gd, midd = ops.se_gate_fwd(pool.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), inv, save_mid=True)
+    gd, midd, _ = ops.se_gate_fwd(pool.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), inv, save_mid=True)
     torch.cuda.synchronize()
     assert_close(midd.cpu(), mid, 1e-4, 'se mid'); assert_close(gd.cpu(), gate, 1e-4, 'se gate')

@@ -45,7 +45,7 @@ def test_fuse_node(dtype, mode):
     assert_close(nchw(om), out.detach(), TOL[dtype], 'fuse fwd')
     da = Map.new(am.B, am.H, am.W, C, dtype, dev); db = Map.new(bm.B, bm.H, bm.W, C, dtype, dev)
     dc = Map.new(am.B, am.H, am.W, C, dtype, dev) if mode == 1 else None
-    dn = torch.zeros(ops.FUSE_DN_FLOATS, device=dev)
+    dn = torch.zeros(ops.fuse_dn_floats(cols), device=dev)
     ops.bifpn_fuse_bwd(nhwc(dout, dtype), am, bm, cm, da, db, dc, False, False, False, wd, dn, col, mode)
     dw = torch.zeros(rows, cols, device=dev)
     ops.bifpn_weight_bwd(wd, dn, dw)

@@ -17,25 +17,25 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
-def test_two_rank_ddp_hip_model(tmp_path, dtype):
+@pytest.mark.parametrize('dtype,wrap', [('f32', 'ddp.wrap'), ('bf16', 'ddp.wrap'), ('f32', 'reference')])
+def test_two_rank_ddp_hip_model(tmp_path, dtype, wrap):
+    """wrap = 'reference': the reference's own DistributedDataParallel(model, device_ids=[gpu], find_unused_parameters=True)
+    (train.py:250-251) with the five never-executed tensors left trainable, instead of ddp.wrap."""
     out = str(tmp_path / 'ddp.json')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'ddp_product_worker.py'), out, dtype]
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'ddp_product_worker.py'), out, dtype, wrap]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     log_dir = os.path.join(ROOT, 'gpurun_out')
     if os.path.isdir(log_dir):                                      # keep the log (scratch on the GPU box, merged back)
-        open(os.path.join(log_dir, 'ddp_product_%s.log' % dtype), 'w').write(r.stdout[-4000:] + '\n--- stderr ---\n' + r.stderr[-4000:])
+        open(os.path.join(log_dir, 'ddp_product_%s_%s.log' % (dtype, wrap)), 'w').write(r.stdout[-4000:] + '\n--- stderr ---\n' + r.stderr[-4000:])
     assert r.returncode == 0, r.stderr[-3000:]
     res = json.load(open(out))
     if os.path.isdir(log_dir):
-        json.dump(res, open(os.path.join(log_dir, 'ddp_product_%s.json' % dtype), 'w'))
+        json.dump(res, open(os.path.join(log_dir, 'ddp_product_%s_%s.json' % (dtype, wrap)), 'w'))
     assert res['world'] == 2 and res['grad_tensors'] > 250
-    # DDP average of the two shard gradients == full-batch gradient (fp32: summation-order noise only)
-    # fp32 measured 1.2e-6; the gates leave room for one ReLU / smooth-L1 tie falling the other way between the two runs (seen in
-    # single-process twin comparisons: single entries up to 7e-3 of a head tensor's scale, whole tensors < 5e-3)
-    assert res['grad_worst_rel'] <= (2e-2 if dtype == 'f32' else 0.1), res
+    # DDP average of the two shard gradients == full-batch gradient (fp32: the batch is summed in another order, measured 1.2e-6)
+    assert res['grad_worst_rel'] <= (5e-3 if dtype == 'f32' else 0.1), res
     assert res['grad_worst_l2'] <= (5e-3 if dtype == 'f32' else 0.1), res
     assert res['finite'] and res['prep_replay']
     assert res['param_checksums'][0] == res['param_checksums'][1], res       # replicas bit-identical after 3 ClipAdamW steps

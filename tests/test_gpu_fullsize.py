@@ -51,10 +51,13 @@ def _restore_arith():
     ('efficientdet-d4', 8, 1024, torch.bfloat16, 0.10),       # configs[4] geometry (the D4 bf16 gate of the golden tests:
                                                               #  B = 1 takes the 16x16x32 head kernel, B = 8 the persistent 32x32x16
                                                               #  one -- another summation order, amplified like storage rounding)
+    ('efficientdet-d4', 8, 1024, torch.float32, 1e-4),        # configs[4] in the parity modes: exact fp32 ...
+    ('efficientdet-d4', 8, 1024, 'f32_bf16x3', 3e-4),         # ... and fp32 storage + bf16x3 products (the headline mode)
 ])
 def test_batch_independence_at_benchmark_size(net, B, S, dtype, tol):
-    """fp32: identical K-reduction order per output element, so only the SE-pool atomics' order differs (1e-6); bf16: that
-    noise flips bf16 roundings which the network amplifies like any storage rounding (gate: the golden tests' tolerance)."""
+    """fp32: identical K-reduction order per output element; what differs between B = 1 and B = 32 is the number of tile groups
+    the squeeze-excite pool is summed over (1e-6); bf16: that flips bf16 roundings which the network amplifies like any storage
+    rounding (gate: the golden tests' tolerance)."""
     m = _model(net, 80, torch.float32, False, f32_arith='bf16x3') if dtype == 'f32_bf16x3' else _model(net, 80, dtype, False)
     img = O.synthetic_batch(B, S, seed=5, num_classes=80)[0].cuda()
     with torch.no_grad():
@@ -143,11 +146,12 @@ def _check_greedy_definition(boxes, score, keep, thr, score_thr, chunk=4096):
     return order.numel(), nk
 
 
-@pytest.mark.parametrize('net,B,S', [('efficientdet-d0', 32, 512), ('efficientdet-d4', 8, 1024)])
-def test_nms_satisfies_the_greedy_definition_at_benchmark_size(net, B, S):
+@pytest.mark.parametrize('net,B,S,dtype', [('efficientdet-d0', 32, 512, torch.float32), ('efficientdet-d4', 8, 1024, torch.bfloat16),
+                                           ('efficientdet-d4', 8, 1024, torch.float32)])
+def test_nms_satisfies_the_greedy_definition_at_benchmark_size(net, B, S, dtype):
     """configs[1] / configs[4] on random-init weights: every anchor is a candidate (49 104 / 196 416 per image)."""
     from efficientdet.pytorch_amd import ops
-    m = _model(net, 80, torch.float32 if net.endswith('d0') else torch.bfloat16, False)
+    m = _model(net, 80, dtype, False)
     img = O.synthetic_batch(B, S, seed=2, num_classes=80)[0].cuda()
     with torch.no_grad():
         cls, reg, anc = m.forward_raw(img)
@@ -194,8 +198,9 @@ def test_graph_replayed_step_tracks_eager_at_benchmark_size():
     outs = step()
     torch.cuda.synchronize()
     lg = float((outs[0].mean() + outs[1].mean()).detach())
-    # the first replay is the 3rd optimizer step of the twin: compare like with like
-    assert abs(lg - eager[2]) <= 2e-2 * abs(eager[2]), (lg, eager)
+    # the first replay is the 3rd optimizer step of the twin: compare like with like (no float atomics: the same kernels in the
+    # same order give the same bits, so the loss is EQUAL up to the float() conversions)
+    assert abs(lg - eager[2]) <= 1e-5 * abs(eager[2]), (lg, eager)
     worst, worst_abs = 0.0, 0.0
     for a, b in zip(pe, pg):
         d = float((a.detach() - b.detach()).abs().max())

@@ -181,11 +181,8 @@ def test_forward_raw_is_differentiable(dtype):
     rc, rr, _ = O.forward_raw(live, net, nc, img)
     ((rc * wc).sum() + (rr * wr).sum()).backward()
     # fp32: 5e-3 of the tensor's scale -- the BiFPN max-pool routing and the ReLU masks are discontinuous in the forward values,
-    # so a 1e-7 summation-order difference occasionally moves one gradient entry by a fixed amount (seen: 3.6e-3 on one neck
-    # conv weight in some runs, with bitwise-stable kernels: tools/wgrad_stress.py); bf16: see below
-    # (... and once in ~6 full-suite runs a single entry beyond 5e-3: hence entries at 2e-2 of scale and the tensor as a whole at
-    #  5e-3 in L2, with the absolute floor of the other gradient tests)
-    tol = 2e-2 if dtype == torch.float32 else 0.35
+    # so the 1e-7 summation-order difference to the CPU oracle can move one gradient entry by a fixed amount; bf16: see below
+    tol = 5e-3 if dtype == torch.float32 else 0.35
     assert_close_scale(cls.detach().cpu(), rc.detach(), 1e-3 if dtype == torch.float32 else 4e-2, 'cls')
     gmax = max(float(v.grad.norm()) for v in params.values() if v.grad is not None)
     for k, p in m.named_parameters():
@@ -323,7 +320,7 @@ def test_graphed_train_step_tracks_eager():
     assert all(np.isfinite(le)) and all(np.isfinite(lg))
     for i, (a, b) in enumerate(zip(le, lg)):
         if i != 2:                                                  # (index 2 = the warm-up step inside the constructor)
-            assert abs(a - b) <= 2e-2 * abs(a), (le, lg)
+            assert abs(a - b) <= 1e-5 * abs(a), (le, lg)           # same kernels, same masks, same order: equal up to float() printing
     assert len(set(lg[3:])) == 3                                    # replays do real, different steps
     d = (runs['eager'][1] - runs['graph'][1]).abs()
     assert float(d.mean()) < 0.5 * lr and float(d.max()) <= 6 * 2 * lr + 1e-6, (float(d.mean()), float(d.max()))
@@ -341,14 +338,13 @@ def test_graphed_detect_matches_eager():
         got = gd()
         assert len(got) == 3
         for (s, l, b), (es, el, eb) in zip(got, eager):
-            assert abs(len(s) - len(es)) <= max(2, len(es) // 100)          # (two passes: atomics-order noise can flip a near-tie)
-            k = min(20, len(es), len(s))
-            assert_close(s[:k].cpu(), es[:k].cpu(), 1e-4, 'scores'); assert l.dtype == torch.int64 and b.shape[1] == 4
+            assert torch.equal(s, es) and torch.equal(l, el) and torch.equal(b, eb)      # a replay runs the same kernels: bitwise equal
+            assert l.dtype == torch.int64 and b.shape[1] == 4
     img2, _ = O.synthetic_batch(3, 128, seed=9, num_classes=8)
     gd.images.copy_(img2.cuda())
     got2 = gd()
     e2 = m.detect(img2.cuda())
-    assert abs(len(got2[0][0]) - len(e2[0][0])) <= max(2, len(e2[0][0]) // 100) and not torch.equal(got2[0][0][:5], eager[0][0][:5])
+    assert torch.equal(got2[0][0], e2[0][0]) and not torch.equal(got2[0][0][:5], eager[0][0][:5])
 
 
 def test_inference_skips_param_prep_only_while_weights_are_unchanged():
@@ -365,8 +361,8 @@ def test_inference_skips_param_prep_only_while_weights_are_unchanged():
         fresh = prep._fresh
         c2, r2, _ = m.forward_raw(img)             # skipped launch
         assert prep._fresh == fresh
-        assert_close(c2.cpu(), c1.cpu(), 1e-3, 'skip == replay (cls)'); assert_close(r2.cpu(), r1.cpu(), 1e-3, 'skip == replay (reg)')   # (SE pool atomics: not bitwise)
-        assert_close(c1.cpu(), c0.cpu(), 1e-3, 'replay == record')
+        assert torch.equal(c2, c1) and torch.equal(r2, r1)          # skip == replay, bit for bit (no float atomics anywhere)
+        assert torch.equal(c1, c0) and torch.equal(r1, r0)          # replay == record
         m.bbox_head.retina_reg.weight.mul_(2.0); m.bbox_head.retina_reg.bias.mul_(2.0)
         c3, r3, _ = m.forward_raw(img)
         assert prep._fresh != fresh
@@ -421,3 +417,181 @@ def test_interleaved_models_keep_their_own_f32_arithmetic():
                 assert p.grad is None or bool(torch.isfinite(p.grad).all())
     finally:
         ops.set_f32_arith('f32')
+
+
+# ------------------------------------------------------------------------------------------------ boundary claims as tests
+def _train_model(nc=8, dtype=torch.float32, seed=0, **kw):
+    m = _model('efficientdet-d0', nc, dtype, **kw)
+    m.backbone.drop_connect_rate = 0.0
+    m.train(); m.is_training = True; m.freeze_bn()
+    return m
+
+
+def test_eval_after_raw_pointer_updates_sees_the_new_weights():
+    """The inference-side 'packed copies are still fresh' shortcut looks at Tensor._version, which raw-pointer writers never
+    move: an eager ClipAdamW.step() and a hipGraph replay of the whole train step both have to invalidate it."""
+    from efficientdet.pytorch_amd import ddp
+    from efficientdet.pytorch_amd.graph import GraphedTrainStep
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    nc = 8
+    m = _train_model(nc)
+    ddp.freeze_dead_parameters(m)
+    opt = ClipAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-2, max_norm=0.0)
+    img, ann = O.synthetic_batch(2, 128, seed=3, num_classes=nc)
+    img, ann = img.cuda(), ann.cuda()
+
+    def eval_out():
+        m.eval(); m.is_training = False
+        with torch.no_grad():
+            c, r, _ = m.forward_raw(img)
+        m.train(); m.is_training = True; m.freeze_bn()
+        return c.clone(), r.clone()
+
+    def fresh_twin_out():              # a second model loaded from the CURRENT state_dict: packs everything anew
+        t = _model('efficientdet-d0', nc, torch.float32, is_training=False)
+        t.load_state_dict(m.state_dict()); t = t.cuda().eval()
+        with torch.no_grad():
+            c, r, _ = t.forward_raw(img)
+        return c, r
+    e0 = eval_out(); e0b = eval_out()
+    assert torch.equal(e0[1], e0b[1])
+    # (1) eager ClipAdamW step between two eval forwards
+    opt.zero_grad(set_to_none=True)
+    cl, rl = m([img, ann]); (cl.mean() + rl.mean()).backward(); opt.step()
+    del cl, rl
+    e1 = eval_out(); e1b = eval_out()          # the second one takes the 'still fresh' shortcut
+    assert not torch.equal(e1[1], e0[1]) and torch.equal(e1[1], e1b[1])
+    t1 = fresh_twin_out()
+    assert torch.equal(e1[0], t1[0]) and torch.equal(e1[1], t1[1])
+    # (2) eval, graph replays, eval: the arena was last packed BEFORE the final replay's optimizer update
+    g = GraphedTrainStep(m, opt, img, ann, warmup=1)
+    e2 = eval_out()
+    g(); g()
+    e3 = eval_out()
+    assert not torch.equal(e3[1], e2[1])
+    t3 = fresh_twin_out()
+    assert torch.equal(e3[0], t3[0]) and torch.equal(e3[1], t3[1])
+
+
+def test_graphed_step_follows_the_lr_schedule():
+    """ClipAdamW's hyper-parameters live in a device buffer that GraphedTrainStep refreshes before each replay: lr = 0 freezes
+    the weights, restoring it moves them again (train.py:133,269 drives ReduceLROnPlateau).  A stock optimizer, whose
+    kernels bake the values in at capture, must fail loudly instead of silently ignoring the change."""
+    from efficientdet.pytorch_amd import ddp
+    from efficientdet.pytorch_amd.graph import GraphedTrainStep
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    nc = 8
+    m = _train_model(nc)
+    ddp.freeze_dead_parameters(m)
+    params = [p for p in m.parameters() if p.requires_grad]
+    opt = ClipAdamW(params, lr=1e-3, max_norm=0.1, weight_decay=0.0)
+    img, ann = O.synthetic_batch(2, 128, seed=3, num_classes=nc)
+    img, ann = img.cuda(), ann.cuda()
+    g = GraphedTrainStep(m, opt, img, ann, warmup=1)
+    snap = lambda: torch.cat([p.detach().reshape(-1) for p in params]).clone()
+    p0 = snap(); g(); p1 = snap()
+    assert float((p1 - p0).abs().max()) > 1e-4
+    opt.param_groups[0]['lr'] = 0.0
+    g(); p2 = snap()
+    assert torch.equal(p2, p1)                                   # lr = 0 (and no weight decay): nothing moves
+    opt.param_groups[0]['lr'] = 1e-3
+    g(); p3 = snap()
+    assert float((p3 - p2).abs().max()) > 1e-4
+    # eager steps after the capture use the same device buffer
+    opt.param_groups[0]['lr'] = 0.0
+    opt.zero_grad(set_to_none=True)
+    cl, rl = m([img, ann]); (cl.mean() + rl.mean()).backward(); opt.step()
+    assert torch.equal(snap(), p3)
+    # an optimizer without a device-side hyper-parameter buffer (stock torch optimizers bake lr into the captured kernels):
+    # a change after capture must raise, not be silently ignored
+    class Stock:
+        param_groups = [{'params': [], 'lr': 1e-3, 'betas': (0.9, 0.999)}]
+    g.optimizer = Stock(); g._hyper0 = g._hyper_sig()
+    g()
+    Stock.param_groups[0]['lr'] = 5e-4
+    with pytest.raises(RuntimeError, match='hyper-parameters changed'):
+        g()
+
+
+def test_param_prep_re_records_when_a_parameter_moves():
+    """The recorded job table holds device addresses: p.data = <new tensor> (or any other move of a source) must be noticed
+    (pointer validation on every eager step) and the table re-recorded -- never a replay against stale memory."""
+    nc = 8
+    m = _model('efficientdet-d0', nc, torch.float32, is_training=False); m.eval()
+    img = O.synthetic_batch(2, 128, seed=3, num_classes=nc)[0].cuda()
+    with torch.no_grad():
+        m.forward_raw(img); c1, r1, _ = m.forward_raw(img)
+        prep = next(iter(m._prep.values()))
+        assert prep.replay
+        w = m.bbox_head.retina_reg.weight
+        old = w.data
+        w.data = (2.0 * old).clone()                          # new storage; the old tensor stays alive (and unchanged)
+        m.bbox_head.retina_reg.bias.data = (2.0 * m.bbox_head.retina_reg.bias.data).clone()
+        c2, r2, _ = m.forward_raw(img)                        # detects the move, records again
+        c3, r3, _ = m.forward_raw(img)                        # replays the new table
+    assert torch.equal(c2, c1) and torch.equal(c3, c1)
+    assert_close(r2.cpu(), (2.0 * r1).cpu(), 1e-5, 'reg doubled after the move'); assert torch.equal(r3, r2)
+    n1 = len(prep.jobs)
+    for _ in range(3):
+        with torch.no_grad():
+            m.forward_raw(img)
+    assert len(prep.jobs) == n1                               # bounded: no growth from step to step
+
+
+def test_data_parallel_single_device_train_step_equals_plain():
+    """train.py:262-265 (the reference's default wrap): nn.DataParallel(model) on the one visible GPU.  Same losses and gradients
+    as the bare module, bit for bit, step after step, with the parameter-preparation table bounded."""
+    nc = 8
+    img, ann = O.synthetic_batch(4, 128, seed=6, num_classes=nc)
+    img, ann = img.cuda(), ann.cuda()
+    res = {}
+    for wrapped in (False, True):
+        m = _train_model(nc)
+        net = torch.nn.DataParallel(m, device_ids=[0]) if wrapped else m
+        opt = torch.optim.AdamW(m.parameters(), lr=1e-4)
+        out = []
+        for it in range(3):
+            opt.zero_grad()
+            cl, rl = net([img, ann])
+            (cl.mean() + rl.mean()).backward()
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.1)
+            opt.step()
+            out.append((float(cl), float(rl)))
+        res[wrapped] = (out, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(), len(next(iter(m._prep.values())).jobs))
+    assert res[True][0] == res[False][0], (res[True][0], res[False][0])
+    assert torch.equal(res[True][1], res[False][1])
+    assert res[True][2] == res[False][2]
+
+
+def test_gradient_accumulation_over_two_backward_passes():
+    """train.py:114-118 with grad_accumulation_steps = 2: two backward passes into the same .grad == the sum of the two
+    single-pass gradients (through the custom autograd nodes), and ClipAdamW.step() on the accumulated gradients == on their sum."""
+    from efficientdet.pytorch_amd import ddp
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    nc = 8
+    m = _train_model(nc)
+    ddp.freeze_dead_parameters(m)
+    params = [p for p in m.parameters() if p.requires_grad]
+    ia, aa = O.synthetic_batch(2, 128, seed=6, num_classes=nc)
+    ib, ab = O.synthetic_batch(2, 128, seed=7, num_classes=nc)
+    batches = [(ia.cuda(), aa.cuda()), (ib.cuda(), ab.cuda())]
+    single = []
+    for img, ann in batches:
+        for p in params:
+            p.grad = None
+        cl, rl = m([img, ann]); ((cl.mean() + rl.mean()) / 2).backward()
+        single.append([p.grad.clone() for p in params])
+    for p in params:
+        p.grad = None
+    for img, ann in batches:                                   # accumulate: no zero_grad in between
+        cl, rl = m([img, ann]); ((cl.mean() + rl.mean()) / 2).backward()
+    for p, g0, g1 in zip(params, single[0], single[1]):
+        assert torch.equal(p.grad, g0 + g1)
+    twin = copy.deepcopy(m)
+    tparams = [p for p in twin.parameters() if p.requires_grad]
+    for q, g0, g1 in zip(tparams, single[0], single[1]):
+        q.grad = g0 + g1
+    o1 = ClipAdamW(params, lr=1e-3, max_norm=0.1); o2 = ClipAdamW(tparams, lr=1e-3, max_norm=0.1)
+    o1.step(); o2.step()
+    for p, q in zip(params, tparams):
+        assert torch.equal(p.detach(), q.detach())

@@ -73,9 +73,10 @@ def test_nms_and_detections(golden_dir, case):
         np.testing.assert_allclose(s.numpy()[:16], g[f'det{b}_scores'][:16], rtol=1e-4)
 
 
-def test_complete_detection_lists_when_scores_are_separated(golden_dir):
+@pytest.mark.parametrize('case', ['d0_128_dets_separated', 'd0_512_dets_separated'])       # last: BASELINE configs[1] geometry
+def test_complete_detection_lists_when_scores_are_separated(golden_dir, case):
     """Oracle == the real reference on every score / label / box of a case with well-separated candidate scores."""
-    g = _load(golden_dir, 'd0_128_dets_separated')
+    g = _load(golden_dir, case)
     net, nc = str(g['network']), int(g['num_classes'])
     sd = O.make_state_dict(net, nc, seed=int(g['seed']))
     sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
@@ -83,7 +84,7 @@ def test_complete_detection_lists_when_scores_are_separated(golden_dir):
     with torch.no_grad():
         dets = O.detect(sd, net, nc, img, threshold=float(g['threshold']))
     for b, (s, c, bx) in enumerate(dets):
-        assert len(s) == len(g[f'det{b}_scores']) >= 10
+        assert len(s) == len(g[f'det{b}_scores']) >= 5
         np.testing.assert_array_equal(c.numpy(), g[f'det{b}_labels'])
         np.testing.assert_allclose(s.numpy(), g[f'det{b}_scores'], rtol=1e-5)
         np.testing.assert_allclose(bx.numpy(), g[f'det{b}_boxes'], rtol=1e-4, atol=1e-3)

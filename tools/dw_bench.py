@@ -32,7 +32,7 @@ for (C, H, k, s) in [(32, 256, 3, 1), (96, 256, 3, 2), (144, 128, 3, 1), (144, 1
     plo = (k - 1) // 2 if s == 1 else (k - 2) // 2
     pool = torch.zeros(B, C, device=dev)
     for save_z in (True, False):
-        us = timeit(lambda: ops.dwconv_fwd(x, w, sc, sh, k, s, plo, plo, Ho, Ho, save_z=save_z, pool=pool))
+        us = timeit(lambda: ops.dwconv_fwd(x, w, sc, sh, k, s, plo, plo, Ho, Ho, save_z=save_z, pool=True))
         by = 2 * B * C * (H * H + Ho * Ho * (2 if save_z else 1))
         print('dw fwd C%-4d %3d^2 k%d s%d z=%d  %7.1f us  %5.2f TB/s' % (C, H, k, s, save_z, us, by / us / 1e6))
     dz = Map.of(torch.randn(B, Ho, Ho, C, device=dev).to(dt))

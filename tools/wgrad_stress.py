@@ -15,7 +15,7 @@ for (B, H, W, Cin, Cout) in [(2, 4, 4, 64, 64), (2, 2, 2, 64, 64), (2, 8, 8, 64,
     for rep in range(40):
         junk = torch.randn(1 << 20, device='cuda')          # perturb allocator / cache state between runs
         db = torch.zeros(Cout, device='cuda')
-        G = ops.conv2d_wgrad(xm, zm, None, db, Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1)
+        G, _dbp = ops.conv2d_wgrad(xm, zm, None, db, Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1)
         dw = torch.empty(Cout, Cin, 3, 3, device='cuda'); ops.unpack_wgrad(G, dw)
         torch.cuda.synchronize()
         outs.append(dw.cpu())
