@@ -21,6 +21,16 @@ import torch
 from . import ops
 
 
+def _build_pending_tables(model):
+    """The first step of a model RECORDS its parameter-preparation jobs; the device-side job table is built at the start of the
+    next step -- which must not be the captured one (building allocates and uploads).  Build it now."""
+    while isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        model = model.module
+    for prep in getattr(model, '_prep', {}).values():
+        if prep.dirty:
+            prep._build()
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, images, annotations, warmup=2, clip_fn=None):
         if not images.is_cuda:
@@ -35,6 +45,7 @@ class GraphedTrainStep:
                 self._step()                    # capture must not touch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _build_pending_tables(model)            # (a table recorded by the warm-up is built here: no allocation / H2D copy under capture)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.losses = self._step()
@@ -97,6 +108,7 @@ class GraphedDetect:
                 run()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _build_pending_tables(model)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.boxes, self.score, self.label = run()
