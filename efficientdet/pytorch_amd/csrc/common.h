@@ -68,6 +68,27 @@ __device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
   *(uint2*)p = u;
 }
 
+// EFFDET_F32_SPLIT element: 4 bytes like fp32 (so pointer arithmetic in ELEMENTS is that of the fp32 tensor), but every 128-byte
+// group of a row -- 32 channels -- holds [32 x bf16 hi | 32 x bf16 lo], value = hi + lo.  With 128-byte aligned rows the position
+// inside the group follows from the address itself, so a split store of 4 consecutive channels is a drop-in for store4(float*).
+struct split_t { uint32_t bits; };
+__device__ __forceinline__ void store4(split_t* p, f32x4 v) {
+  const unsigned long long a = (unsigned long long)p;
+  char* grp = (char*)(a & ~127ull) + ((a & 127ull) >> 1);          // channel c (0..28, % 4 == 0) of the group -> hi at byte 2c
+  uint2 hi, lo;
+  hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+  lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+  lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+  *(uint2*)grp = hi; *(uint2*)(grp + 64) = lo;
+}
+__device__ __forceinline__ f32x4 load4(const split_t* p) {
+  const unsigned long long a = (unsigned long long)p;
+  const char* grp = (const char*)(a & ~127ull) + ((a & 127ull) >> 1);
+  const uint2 hi = *(const uint2*)grp, lo = *(const uint2*)(grp + 64);
+  return f32x4{__uint_as_float(hi.x << 16) + __uint_as_float(lo.x << 16), __uint_as_float(hi.x & 0xffff0000u) + __uint_as_float(lo.x & 0xffff0000u),
+               __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16), __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u)};
+}
+
 // 16-byte chunk <-> CE floats (CE = 4 or 8)
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {

@@ -46,6 +46,7 @@ struct ConvK {
   int Kc;    // K in 16-byte chunks (= KH*KW*Cin/CE)
   int cpt;   // chunks per tap (= Cin/CE)
   int act, res_mode, out_f32, vec_ok;
+  int out_split;               // y (and a ReLU-mask res) are in the split layout: 32-channel groups of [32 x bf16 hi | 32 x bf16 lo]
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   int kord;                    // K walk of the persistent kernel: 0 tap-major, 1 channel-group-major
@@ -76,6 +77,10 @@ template <> struct Mma<float> {
 // SPLIT (fp32 storage only): "bf16x3" arithmetic -- each fp32 operand value is split in registers into bf16 hi + bf16 lo
 // (x = hi + lo + O(2^-17 |x|)) and a K-step costs 3 v_mfma_f32_16x16x32_bf16 (hi*hi + hi*lo + lo*hi, fp32 accumulate)
 // per tile instead of 8 v_mfma_f32_16x16x4_f32: products carry ~16 mantissa bits, the matrix pipe does 3/8 of the passes.
+// SPLIT = 2 (EFFDET_F32_SPLIT): the ACTIVATIONS arrive pre-split too -- 4 bytes per element like fp32, but every 128-byte group
+// of a pixel row holds [32 x bf16 hi | 32 x bf16 lo] of 32 channels (written that way by the producing epilogue / the loss kernel)
+// -- so both fragments of a K-step are plain ds_read_b128 (chunk lq = hi, chunk 4 + lq = lo of k = 8*lq .. 8*lq+7) and the
+// loop has no splitting VALU at all; the byte geometry of the DMA staging is unchanged.
 // NS: LDS stages of the K loop.  2 is right when two workgroups share a CU (the other one's MFMAs cover this one's DMA latency);
 // launches too small for that (<= 1 tile per CU: BiFPN convs on the coarse levels, the late backbone 1x1 convs) run ONE
 // workgroup per CU and were bound by the DMA round trip (1.27 us per K-step for 0.35 us of MFMA work): NS = 4 keeps three
@@ -237,7 +242,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
       for (int b = 0; b < MT; ++b) {
         const int r = buf * XLD + (wm0 + b * 16 + l15) * 8;
-        split8(xs[r + ((2 * lq) ^ lsw)], xs[r + ((2 * lq + 1) ^ lsw)], f.xh[b], f.xl[b]);
+        if constexpr (SPLIT == 2) { f.xh[b] = xs[r + (lq ^ lsw)]; f.xl[b] = xs[r + ((4 + lq) ^ lsw)]; }
+        else split8(xs[r + ((2 * lq) ^ lsw)], xs[r + ((2 * lq + 1) ^ lsw)], f.xh[b], f.xl[b]);
       }
     };
     auto mmasp = [&](const Frags& f) {
@@ -341,6 +347,26 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
       else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
       else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
       if (p.rowscale) v *= rs;
+      if constexpr (SPLIT == 2) {
+        if (p.out_split) {
+          // split layout: channel n of a pixel row sits at byte (n >> 5) * 128 + (n & 31) * 2 (hi) and + 64 (lo); the lane's 4
+          // consecutive channels (n0 % 4 == 0) are two 8-byte stores.  Host guarantees Cout % 32 == 0 and 128-byte aligned rows.
+          const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
+          if (p.res_mode == EFFDET_RES_RELU_MASK) {         // res = the forward activation in the same layout: sign of hi decides
+            const uint2 rh = *(const uint2*)((const char*)p.res + orow * 4 + goff);
+            const unsigned rv[4] = {rh.x & 0xffffu, rh.x >> 16, rh.y & 0xffffu, rh.y >> 16};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = ((rv[r] & 0x7fffu) != 0u && !(rv[r] & 0x8000u)) ? v[r] : 0.f;
+          }
+          uint2 hi, lo;
+          hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+          lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+          lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+          char* dst = (char*)p.y + orow * 4 + goff;
+          *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
+          continue;
+        }
+      }
       if (p.res_mode != EFFDET_RES_NONE) {
         f32x4 q;
         if (full) q = load4((const T*)p.res + o);
@@ -800,17 +826,29 @@ extern "C" int effdet_tuning_set(int key, int value) {
 static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   if (!p || !p->x || !p->w || !p->y) return EFFDET_EINVAL;
   if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
-  if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16 && p->dtype != EFFDET_F32_BF16X3) return EFFDET_EINVAL;
+  if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16 && p->dtype != EFFDET_F32_BF16X3 && p->dtype != EFFDET_F32_SPLIT) return EFFDET_EINVAL;
   const int ce = p->dtype == EFFDET_BF16 ? 8 : 4;
   if (p->Cin % ce || p->ldx % ce || p->KH < 1 || p->KW < 1 || p->stride < 1) return EFFDET_EUNSUPPORTED;
   if (p->res_mode != EFFDET_RES_NONE && !p->res) return EFFDET_EINVAL;
-  if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
+  const bool splitfmt = p->dtype == EFFDET_F32_SPLIT;
+  if (splitfmt) {
+    // x in the split layout (whole 32-channel groups, 128-byte aligned rows); y either plain fp32 (out_f32; res may be ADDed)
+    // or split as well (res, if any, is the ReLU-mask activation in the same layout); no pre-activation copy
+    if (p->Cin % 32 || p->ldx % 32 || p->z) return EFFDET_EUNSUPPORTED;
+    if (p->out_f32 ? (p->res_mode != EFFDET_RES_NONE && p->res_mode != EFFDET_RES_ADD)
+                   : (p->Cout % 32 || p->ldy % 32 || (p->res_mode != EFFDET_RES_NONE && p->res_mode != EFFDET_RES_RELU_MASK))) return EFFDET_EUNSUPPORTED;
+    for (int s = 0; s < p->nseg; ++s) {
+      if (p->seg[s].in_off % 32 || p->seg[s].in_bstride % 32) return EFFDET_EUNSUPPORTED;
+      if (!p->out_f32 && (p->seg[s].out_off % 32 || p->seg[s].out_bstride % 32)) return EFFDET_EUNSUPPORTED;
+    }
+  } else if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
   k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res;
   k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
   k.ldx = p->ldx; k.ldy = p->ldy;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt;
   k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32; k.kord = g_tuning[EFFDET_TUNE_IGEMM_KORD];
+  k.out_split = (splitfmt && !p->out_f32) ? 1 : 0;
   k.nseg = p->nseg;
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
@@ -862,6 +900,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   }
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
+  if (p->dtype == EFFDET_F32_SPLIT) return 8 + (bt > 1 ? 1 : bt);                        // (block tiles of 128 / 64 output channels)
   return bt;
 }
 
@@ -885,5 +924,9 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     default: break;
   }
   if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
+  if (id == 8 || id == 9) {
+    k.ntiles = (k.Cout + (id == 8 ? 127 : 63)) / (id == 8 ? 128 : 64);
+    return id == 8 ? launch<float, 128, 2, 8, 2>(k, st) : launch<float, 64, 1, 4, 2>(k, st);
+  }
   return p->dtype == EFFDET_BF16 ? dispatch<bf16_t>(k, st) : dispatch<float>(k, st);
 }

@@ -318,8 +318,16 @@ __device__ __forceinline__ unsigned oob_if(unsigned long long mask, unsigned val
   return __builtin_amdgcn_inverse_ballot_w64(mask) ? EFFDET_OOB : val;                 // one v_cndmask on an SGPR-pair mask
 }
 
-template <int NW>
+// X3S = 1 (EFFDET_F32_SPLIT): both operands are fp32-precision activations stored in the SPLIT layout -- every 128-byte group of a
+// pixel row = 32 channels as [32 x bf16 hi | 32 x bf16 lo] -- which this kernel stages and transposes exactly like a bf16 tensor
+// of twice the channel count (all staging fields of WgradK are in that bf16 VIEW: Cin, lddz, ldx, Kc, cpt, offsets).  A 64-wide
+// block of the view is one 32-channel group, its 16-channel MFMA blocks 0,1 = hi and 2,3 = lo, so a wave tile of 64 x 64 (NW = 4)
+// holds everything the bf16x3 product of a 32 x 32 block of G needs: acc[a][b] += hi_a*hi_b + hi_a*lo_b + lo_a*hi_b -- 12 MFMAs on
+// 8 transposed fragment reads per 32 pixels and NO splitting VALU (conv_wgrad_f32dma_kernel<4, 1> splits both operands in
+// registers: 5 VALU per value pair).  p.Cout / p.K stay ALGORITHMIC (the slab is [Cout][K] fp32 as for every other kernel).
+template <int NW, int X3S = 0>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) {
+  static_assert(!X3S || NW == 4, "the split-operand form is built for 4 waves of 64 x 64");
   constexpr int WJ = NW / 2;                    // waves along j (2 along n): 4 waves = 2x2 of 64x64, 8 waves = 2x4 of 64x32
   constexpr int WTJ = 128 / WJ, JT = WTJ / 16;
   constexpr int BKM = 64;                       // pixels per stage (two 32-pixel MFMA k-steps)
@@ -426,6 +434,66 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
   const int l15 = lane & 15, lq = lane >> 4;
   float* slab = p.slab + (long long)split * p.Cout * p.K;
 
+  if constexpr (X3S) {
+    // ---- split operands: 32 x 32 algorithmic outputs per wave, three MFMAs per accumulator tile and 32-pixel k-step ----
+    f32x4 acc3[2][2], bs3[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      bs3[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int n_alg0 = nt * 64 + (wn0 >> 6) * 32, j_alg0 = jt * 64 + (wj0 >> 6) * 32;
+    if (nsteps > 0) {
+      stage(0);
+      for (int kt = 0; kt < nsteps; ++kt) {
+        const unsigned cur = (unsigned)(kt & 1) * BUFB;
+        dma_wait_all();
+        __syncthreads();
+        if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          uint4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+          for (int a = 0; a < 2; ++a) { ah[a] = frag(a_addr[a] + cur + (unsigned)ks * 8192u); al[a] = frag(a_addr[2 + a] + cur + (unsigned)ks * 8192u); }
+#pragma unroll
+          for (int b = 0; b < 2; ++b) { bh[b] = frag(b_addr[b] + cur + (unsigned)ks * 8192u); bl[b] = frag(b_addr[2 + b] + cur + (unsigned)ks * 8192u); }
+          // term-major: consecutive MFMAs go to different accumulators (the small cross terms first, the main term last)
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) WMma<bf16_t>::run(t == 0 ? al[a] : ah[a], t == 1 ? bl[b] : bh[b], acc3[a][b]);
+          if (want_bias) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { WMma<bf16_t>::run(al[a], ones, bs3[a]); WMma<bf16_t>::run(ah[a], ones, bs3[a]); }
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int n = n_alg0 + a * 16 + lq * 4 + rr;
+          if (n >= p.Cout) continue;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int j = j_alg0 + b * 16 + l15;
+            if (j < p.K) slab[(long long)n * p.K + j] = acc3[a][b][rr];
+          }
+          if (want_bias && l15 == 0) p.dbp[(long long)split * p.Cout + n] = bs3[a][rr];
+        }
+      }
+    } else {
+      for (int i = tid; i < 64 * 64; i += NW * 64) {
+        const int n = nt * 64 + i / 64, j = jt * 64 + (i & 63);
+        if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
+      }
+      if (p.dbp && jt == 0 && tid < 64 && nt * 64 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 64 + tid] = 0.f;
+    }
+    return;
+  }
   if (nsteps > 0) {
     stage(0);
     for (int kt = 0; kt < nsteps; ++kt) {
@@ -813,14 +881,36 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
 }
 }  // namespace
 
-// EFFDET_F32_BF16X3 (fp32 storage, split-bf16 products): same storage geometry as EFFDET_F32
-#define WGRAD_NORMALISE_DTYPE(p, q) effdet_wgrad_t q; bool q##_x3 = false; \
-  if (p) { q = *p; if (q.dtype == EFFDET_F32_BF16X3) { q.dtype = EFFDET_F32; q##_x3 = true; } p = &q; } (void)q##_x3
+// EFFDET_F32_BF16X3 (fp32 storage, split-bf16 products): same storage geometry as EFFDET_F32.
+// EFFDET_F32_SPLIT (both operands in the split layout): planned and staged as the bf16 tensor of twice the channel count it is
+// byte for byte (the VIEW: channel counts, pitches, offsets x 2; the dz width is its whole padded pitch); q##_alg keeps the
+// algorithmic Cout / Cin for the slab layout and the epilogue.
+#define WGRAD_NORMALISE_DTYPE(p, q) effdet_wgrad_t q; bool q##_x3 = false, q##_split = false; int q##_cout = 0, q##_cin = 0; \
+  if (p) { q = *p; q##_cout = q.Cout; q##_cin = q.Cin; \
+    if (q.dtype == EFFDET_F32_BF16X3) { q.dtype = EFFDET_F32; q##_x3 = true; } \
+    else if (q.dtype == EFFDET_F32_SPLIT) { \
+      q##_split = true; q.dtype = EFFDET_BF16; \
+      if (q.Cin % 32 || q.ldx % 32 || q.lddz % 32 || q.Cout > q.lddz || q.nseg < 1 || q.nseg > EFFDET_MAX_SEG) q.nseg = 0;   /* -> EFFDET_EINVAL in plan() */ \
+      q.Cin *= 2; q.ldx *= 2; q.Cout = 2 * q.lddz; q.lddz *= 2; \
+      for (int s_ = 0; s_ < q.nseg; ++s_) { q.seg[s_].in_off *= 2; q.seg[s_].in_bstride *= 2; q.seg[s_].out_off *= 2; q.seg[s_].out_bstride *= 2; } \
+    } \
+    p = &q; } (void)q##_x3; (void)q##_split; (void)q##_cout; (void)q##_cin
+
+namespace { bool tr_eligible(const effdet_wgrad_t* p, const WgradK& k, int s); }
+// every pyramid level of a split-layout launch must qualify for the DMA + transpose-read kernel (there is no other split kernel)
+static bool split_all_eligible(const effdet_wgrad_t* pv, const WgradK& k) {
+  for (int s = 0; s < pv->nseg; ++s) if (!tr_eligible(pv, k, s)) return false;
+  return true;
+}
 
 extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   if (plan(p, k, splits) != EFFDET_OK) return -1;
+  if (pn_split) {
+    if (!split_all_eligible(p, k)) return -1;
+    return (long long)splits * pn_cout * ((long long)(k.K / 2) + 1) * (long long)sizeof(float);
+  }
   return (long long)splits * p->Cout * (k.K + 1) * (long long)sizeof(float);      // slabs + the [splits][Cout] bias partials
 }
 
@@ -828,6 +918,7 @@ extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
   if (plan(p, k, splits) != EFFDET_OK) return -1;
+  if (pn_split && !split_all_eligible(p, k)) return -1;
   return splits;
 }
 
@@ -878,6 +969,38 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   WgradK k; int splits = 0;
   const int rc = plan(p, k, splits);
   if (rc != EFFDET_OK) return rc;
+  if (pn_split) {
+    // split-layout operands: one launch of the transpose-read kernel in its three-product form (k = the bf16 VIEW for staging;
+    // Cout / K back to algorithmic for the [Cout][K] fp32 slabs, the bias partial rows and the epilogue)
+    if (!split_all_eligible(p, k)) return EFFDET_EUNSUPPORTED;
+    const long long Kalg = k.K / 2, nalg = (long long)pn_cout * Kalg;
+    if (workspace_bytes < (long long)splits * (nalg + pn_cout) * (long long)sizeof(float)) return EFFDET_EINVAL;
+    k.slab = (float*)workspace;
+    k.dbp = p->dbias ? (float*)workspace + (long long)splits * nalg : nullptr;
+    k.Cout = pn_cout; k.K = (int)Kalg;
+    for (int s = 0; s < p->nseg; ++s) {
+      WSeg& d = k.seg[s];
+      if (p->KH == 1 && p->KW == 1 && d.in_bs == (long long)d.H * d.W * p->ldx && d.out_bs == (long long)d.Ho * d.Wo * p->lddz) {
+        d.H = d.Ho = 1; d.W = d.Wo = d.M;
+      }
+    }
+    const size_t lds4 = (size_t)4 * 128 * 8 * sizeof(uint4);
+    hipStream_t st4 = (hipStream_t)stream;
+    EFFDET_SET_MAX_LDS((conv_wgrad_tr_kernel<4, 1>), lds4);
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 1>), dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(4 * 64), lds4, st4, k);
+    EFFDET_CHECK_LAUNCH();
+    if (p->dw) {
+      long long g = (nalg / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st4, (const float*)workspace, p->dw, nalg, splits);
+      EFFDET_CHECK_LAUNCH();
+      if (p->dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((pn_cout + 255) / 256)), dim3(256), 0, st4, (const float*)k.dbp, p->dbias,
+                           pn_cout, splits);
+        EFFDET_CHECK_LAUNCH();
+      }
+    }
+    return EFFDET_OK;
+  }
   const long long n = (long long)p->Cout * k.K;
   if (workspace_bytes < (long long)splits * (n + p->Cout) * (long long)sizeof(float)) return EFFDET_EINVAL;
   k.slab = (float*)workspace;

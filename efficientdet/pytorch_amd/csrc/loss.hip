@@ -30,6 +30,7 @@ struct LossK {
   void* dcls; void* dreg;
   int B, nc, N; long long A;
   int dld;           // channel pitch of the pixel-major dcls layout (0 = [B][A][nc])
+  int reg_ld;        // channel pitch of a pixel-major dreg layout [B][A/9][reg_ld] (channel = anchor*4 + k, zeros beyond 36); 0 = [B][A][4]
 };
 
 // stat[b][2] holds the number of positive anchors as an int32 bit pattern (integer atomics: exact, order-independent)
@@ -307,7 +308,14 @@ __global__ void loss_bwd_reg_kernel(const LossK p) {
         g[q] = gs * ((d <= 1.0f / 9.0f) ? 9.0f * d * sgn : sgn);
       }
     }
-    store4((T*)p.dreg + i * 4, g);
+    if (p.reg_ld) {       // pixel-major rows with a padded pitch (the layout the head's data-gradient conv reads; pad channels zeroed here)
+      const long long pix = a / 9; const int an = (int)(a - pix * 9);
+      T* row = (T*)p.dreg + (b * (p.A / 9) + pix) * p.reg_ld;
+      store4(row + an * 4, g);
+      if (an == 8) for (int c = 36; c < p.reg_ld; c += 4) store4(row + c, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
+      store4((T*)p.dreg + i * 4, g);
+    }
   }
 }
 
@@ -400,8 +408,9 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
                                           int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream) {
   if (!cls || !reg || !anchors || !annots || !losses || !workspace || !dcls_pix) return EFFDET_EINVAL;
   if (workspace_bytes < effdet_loss_workspace_bytes(B, A, num_classes) || B > 65535 || N < 1) return EFFDET_EINVAL;
-  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16 && dtype != EFFDET_F32_SPLIT) return EFFDET_EINVAL;
   if (dld <= 0 || A % 9 || num_classes % 4 || dld % 4 || dld < 9 * num_classes) return EFFDET_EINVAL;
+  if (dtype == EFFDET_F32_SPLIT && (dld % 32 || ((unsigned long long)dcls_pix & 127ull))) return EFFDET_EINVAL;     // whole [hi|lo] groups, aligned rows
   if (A * num_classes >= 0x7fffffffLL || (A / 9) * dld >= 0x7fffffffLL) return EFFDET_EUNSUPPORTED;
   LossK k{}; k.cls = cls; k.reg = reg; k.anchors = anchors; k.annots = annots; k.losses = losses;
   k.dcls = dcls_pix; k.dld = dld; k.B = B; k.nc = num_classes; k.N = N; k.A = A;
@@ -415,6 +424,7 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
   if (k.ncb > cls_blocks_max(A, num_classes)) return EFFDET_EINVAL;
   dim3 g1((unsigned)k.ncb, B);
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(loss_cls_grad_pix_kernel<float>, g1, dim3(256), 0, st, k);
+  else if (dtype == EFFDET_F32_SPLIT) hipLaunchKernelGGL(loss_cls_grad_pix_kernel<split_t>, g1, dim3(256), 0, st, k);
   else hipLaunchKernelGGL(loss_cls_grad_pix_kernel<bf16_t>, g1, dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, st, k);
@@ -423,15 +433,18 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
 }
 
 extern "C" int effdet_focal_loss_bwd_reg(const float* reg, const float* anchors, const float* annots, const float* gscale,
-                                         const void* workspace, void* dreg, int dtype, int B, long long A, int N,
+                                         const void* workspace, void* dreg, int reg_ld, int dtype, int B, long long A, int N,
                                          effdet_stream_t stream) {
   if (!reg || !anchors || !annots || !gscale || !workspace || !dreg) return EFFDET_EINVAL;
-  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16) return EFFDET_EINVAL;
+  if (dtype != EFFDET_F32 && dtype != EFFDET_BF16 && dtype != EFFDET_F32_SPLIT) return EFFDET_EINVAL;
+  if (reg_ld && (reg_ld < 36 || reg_ld % 4 || A % 9)) return EFFDET_EINVAL;
+  if (dtype == EFFDET_F32_SPLIT && (!reg_ld || reg_ld % 32 || ((unsigned long long)dreg & 127ull))) return EFFDET_EINVAL;
   LossK k{}; k.reg = reg; k.anchors = anchors; k.annots = annots; k.gscale = gscale; k.dreg = dreg;
-  k.B = B; k.N = N; k.A = A;
+  k.B = B; k.N = N; k.A = A; k.reg_ld = reg_ld;
   carve_loss(k, const_cast<void*>(workspace), B, A);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(loss_bwd_reg_kernel<float>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
+  else if (dtype == EFFDET_F32_SPLIT) hipLaunchKernelGGL(loss_bwd_reg_kernel<split_t>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
   else hipLaunchKernelGGL(loss_bwd_reg_kernel<bf16_t>, dim3(grid_for((long long)B * A)), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;

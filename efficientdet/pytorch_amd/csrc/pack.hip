@@ -209,6 +209,12 @@ __global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, 
   }
 }
 
+// plain fp32 -> split layout, 4 elements per thread (same element index on both sides; the group position follows from the address)
+__global__ void to_split_kernel(const float* __restrict__ src, split_t* __restrict__ dst, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    store4(dst + i * 4, *(const f32x4*)(src + i * 4));
+}
+
 inline int grid_for(long long n, int block = 256) {
   long long g = (n + block - 1) / block;
   return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -300,6 +306,14 @@ extern "C" int effdet_pad_rows(const void* src, void* dst, int dtype, long long 
   if (dtype == EFFDET_F32) hipLaunchKernelGGL(pad_rows_kernel<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)src, (float*)dst, src_off, src_bstride, src_ld, HW, C, Cpad, n);
   else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(pad_rows_kernel<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, src_off, src_bstride, src_ld, HW, C, Cpad, n);
   else return EFFDET_EINVAL;
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_to_split(const float* src, void* dst, long long n, effdet_stream_t stream) {
+  if (!src || !dst || n < 4 || (n & 3) || ((unsigned long long)src & 15ull) || ((unsigned long long)dst & 127ull) || (const void*)src == dst) return EFFDET_EINVAL;
+  long long g = (n / 4 + 255) / 256; if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst, n / 4);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

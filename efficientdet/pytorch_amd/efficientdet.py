@@ -277,7 +277,7 @@ class _HeadLossFn(torch.autograd.Function):
             # ONE pass over the 15.7 MB/image of probabilities: losses + d(logits) for an upstream gradient of one, already in
             # the pixel-major, 64-channel-padded rows the head's gradient convs read; cls itself is not kept for backward
             dld = (9 * nc + 63) // 64 * 64
-            losses, ws, dpix = ops.focal_loss_fwd_grad(cls, reg, anchors, annots, dtype, dld)
+            losses, ws, dpix = ops.focal_loss_fwd_grad(cls, reg, anchors, annots, dtype, dld, split=saved[5])    # (split-layout head: see functional.head_uses_split)
             ctx.saved = (saved, None, reg, anchors, annots, ws, dtype, dpix, dld)
         else:
             losses, ws = ops.focal_loss_fwd(cls, reg, anchors, annots)
@@ -290,8 +290,10 @@ class _HeadLossFn(torch.autograd.Function):
         saved, cls, reg, anchors, annots, ws, dtype, dpix, dld = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
         if dpix is not None:
-            dreg = ops.focal_loss_bwd_reg(reg, anchors, annots, gscale, ws, dtype)
-            dp, g = Fn.head_bwd(saved, dpix, dreg, dtype, dcls_ld=dld, cls_gscale=gscale[0:1])
+            split = saved[5]
+            rld = 64 if split else 0                # split layout: d(reg) pixel-major, 36 -> 64 channels (two [hi|lo] groups)
+            dreg = ops.focal_loss_bwd_reg(reg, anchors, annots, gscale, ws, dtype, reg_ld=rld, split=split)
+            dp, g = Fn.head_bwd(saved, dpix, dreg, dtype, dcls_ld=dld, cls_gscale=gscale[0:1], dreg_ld=rld, in_split=split)
         else:
             nc = cls.shape[2]
             if nc % 4 == 0:      # d(logits) straight into the pixel-major, 64-channel-padded rows the head's gradient convs read

@@ -284,6 +284,23 @@ def head_out_maps(buf, B, sizes, per_anchor):
     return maps
 
 
+HEAD_SPLIT = os.environ.get('EFFDET_HEAD_SPLIT', '1') == '1'     # A/B switch: split-layout head activations in the bf16x3 arithmetic
+_split_ok = {}
+
+
+def head_uses_split(B, sizes, Wc, dtype):
+    """bf16x3 arithmetic on fp32 storage: the RetinaHead's activations and gradients live in the SPLIT layout (every 32 channels
+    as [32 x bf16 hi | 32 x bf16 lo], same 4 bytes per element) so that the head's convs and weight gradients -- 95 % of the
+    step's FLOPs -- read ready-made MFMA operands instead of splitting fp32 values in registers in every K-step.  Needs pyramid
+    levels the split weight-gradient kernel can take (whole 8-pixel runs per row); otherwise the plain-fp32 path stays."""
+    if not (HEAD_SPLIT and dtype == torch.float32 and ops.F32_ARITH == 'bf16x3' and Wc % 32 == 0):
+        return False
+    key = (B, tuple(sizes), Wc)
+    if key not in _split_ok:
+        _split_ok[key] = ops.wgrad_split_supported(B, sizes, 256, 256, 256) and ops.wgrad_split_supported(B, sizes, Wc, 256, 256)
+    return _split_ok[key]
+
+
 def head_fwd(p, HP, num_classes, dtype, train):
     """models/retinahead.py:109-132 for all 5 levels per launch (weights are shared across levels).
     p: 5 Maps; HP: dict of head parameter tensors.  -> classification [B,A,nc] fp32 (probabilities),
@@ -292,53 +309,79 @@ def head_fwd(p, HP, num_classes, dtype, train):
     B, Wc = p[0].B, p[0].C
     sizes = [(m.H, m.W) for m in p]
     A = sum(h * w for (h, w) in sizes) * 9
+    split = head_uses_split(B, sizes, Wc, dtype)
+    pin = p
+    if split:                 # the pyramid once in the split layout: operand of both towers' first conv and of their weight gradients
+        _, pin = pyramid_alloc(B, sizes, Wc, dtype, dev)
+        for src, dst in zip(p, pin):
+            L_ = src.B * src.H * src.W * src.C
+            ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(src.tensor()), ops.C.c_void_p(dst.addr()), ops.C.c_longlong(L_), ops.L.stream_ptr()),
+                        'effdet_to_split')
     acts = {'cls': [], 'reg': []}
     for tower in ('cls', 'reg'):
-        cur = p
+        cur = pin
         for t in range(4):
             w, b = HP[f'{tower}_convs.{t}.weight'], HP[f'{tower}_convs.{t}.bias']
             _, nxt = pyramid_alloc(B, sizes, 256, dtype, dev)
-            ops.conv2d(cur, ops.pack_weight(w, dtype), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
-                       shift=b, act=ACT_RELU)
+            ops.conv2d(cur, ops.pack_weight(w, dtype, x3=split), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
+                       shift=b, act=ACT_RELU, split=split)
             acts[tower].append(nxt); cur = nxt
     cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
     reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
-    ops.conv2d(acts['cls'][3], ops.pack_weight(HP['retina_cls.weight'], dtype), head_out_maps(cls, B, sizes, num_classes),
+    ops.conv2d(acts['cls'][3], ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
                Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
-               act=ACT_SIGMOID, out_f32=True)
-    ops.conv2d(acts['reg'][3], ops.pack_weight(HP['retina_reg.weight'], dtype), head_out_maps(reg, B, sizes, 4),
-               Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True)
-    saved = (p, acts, sizes, HP, num_classes) if train else None
+               act=ACT_SIGMOID, out_f32=True, split=split)
+    ops.conv2d(acts['reg'][3], ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
+               Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split)
+    saved = (pin, acts, sizes, HP, num_classes, split) if train else None
     return cls, reg, saved
 
 
-def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
+def _split_rows(maps, Cfp, dtype):
+    """plain fp32 gradient maps (possibly strided views of a [B, A, per] buffer) -> fresh contiguous maps of Cfp (% 32 == 0)
+    channels per pixel in the split layout."""
+    out = []
+    for m in maps:
+        padded = ops.pad_rows(m, Cfp) if (m.C != Cfp or m.ld != Cfp or m.bstride != m.H * m.W * Cfp or m.off) else m
+        out.append(Map.of(ops.to_split(padded.tensor())))
+    return out
+
+
+def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld=0, in_split=False):
     """dcls_logit [B,A,nc] (or, with dcls_ld, pixel-major and channel-padded [B,A/9,dcls_ld]: ops.focal_loss_bwd_pix),
-    dreg [B,A,4]: gradients wrt the cls LOGITS and box deltas, in `dtype`.  -> (dp: 5 Maps, grads dict keyed like HP).
+    dreg [B,A,4] (or, with dreg_ld, pixel-major [B,A/9,dreg_ld]): gradients wrt the cls LOGITS and box deltas, in `dtype` -- when
+    the head was run in the split layout (saved[5]) they are needed in the split layout too: in_split says the pixel-major forms
+    already are (the loss kernels write it directly), anything else is converted here.  -> (dp: 5 Maps, grads dict keyed like HP).
     cls_gscale (fp32 tensor [1]): dcls_logit was computed for an upstream gradient of one (ops.focal_loss_fwd_grad); the
     real scalar enters here where the chain is linear: as the per-image output scale of retina_cls's data-gradient conv
     and as a factor on retina_cls's own parameter gradients."""
-    p, acts, sizes, HP, nc = saved
+    p, acts, sizes, HP, nc, split = saved
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     g = {}
     dp_maps = None
-    for tower, dout, per in (('cls', dcls_logit, nc), ('reg', dreg, 4)):
+    apix = sum(h * w for (h, w) in sizes)
+    for tower, dout, per, pix_ld in (('cls', dcls_logit, nc, dcls_ld), ('reg', dreg, 4, dreg_ld)):
         fin = f'retina_{tower}'
         wf = HP[fin + '.weight']
         Cf = wf.shape[0]
-        ce = chunk_elems(dtype)
-        if tower == 'cls' and dcls_ld:
-            # the loss kernel already wrote rows of dcls_ld channels per pixel (zeros past 9*nc): aligned 128-B K-slices
-            Cfp, apix, poff, dzmaps = dcls_ld, sum(h * w for (h, w) in sizes), 0, []
+        ce = 32 if split else chunk_elems(dtype)
+        if pix_ld:
+            # the loss kernel already wrote rows of pix_ld channels per pixel (zeros past 9*per): aligned 128-B K-slices
+            Cfp, poff, dzmaps = pix_ld, 0, []
             for (h, w) in sizes:
                 dzmaps.append(Map(dout, B, h, w, Cfp, ld=Cfp, bstride=apix * Cfp, off=poff * Cfp)); poff += h * w
+            if split and not in_split:
+                assert Cfp % 32 == 0
+                dzmaps = _split_rows(dzmaps, Cfp, dtype)
         else:
             dzmaps = head_out_maps(dout, B, sizes, per)
             Cfp = (Cf + ce - 1) // ce * ce
-            if Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
+            if split:
+                dzmaps = _split_rows(dzmaps, Cfp, dtype)
+            elif Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
                 dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
-        G, dbp = ops.conv2d_wgrad(acts[tower][3], dzmaps, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1)
+        G, dbp = ops.conv2d_wgrad(acts[tower][3], dzmaps, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1, split=split)
         dw = torch.empty_like(wf); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
         rows = None
         if tower == 'cls' and cls_gscale is not None:
@@ -347,26 +390,26 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None):
         g[fin + '.weight'], g[fin + '.bias'] = dw, db
         # data gradient with the ReLU mask of the producing tower layer fused into the epilogue
         _, dz = pyramid_alloc(B, sizes, 256, dtype, dev)
-        ops.conv2d(dzmaps, ops.pack_weight(wf, dtype, mode=1, cin_pad=Cfp), dz, Cin=Cfp, Cout=256, KH=3, KW=3, pad_t=1,
-                   pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK, rowscale=rows)
+        ops.conv2d(dzmaps, ops.pack_weight(wf, dtype, mode=1, cin_pad=Cfp, x3=split), dz, Cin=Cfp, Cout=256, KH=3, KW=3, pad_t=1,
+                   pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK, rowscale=rows, split=split)
         for t in range(3, -1, -1):
             w = HP[f'{tower}_convs.{t}.weight']
             xin = acts[tower][t - 1] if t > 0 else p
             Cin = w.shape[1]
-            G, dbp = ops.conv2d_wgrad(xin, dz, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1)
+            G, dbp = ops.conv2d_wgrad(xin, dz, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, split=split)
             dw = torch.empty_like(w); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
             g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
-            wd = ops.pack_weight(w, dtype, mode=1)
+            wd = ops.pack_weight(w, dtype, mode=1, x3=split)
             if t > 0:
                 _, nz = pyramid_alloc(B, sizes, 256, dtype, dev)
                 ops.conv2d(dz, wd, nz, Cin=256, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, res=acts[tower][t - 1],
-                           res_mode=RES_RELU_MASK)
+                           res_mode=RES_RELU_MASK, split=split)
                 dz = nz
-            else:
+            else:                                       # back to plain fp32 for the neck (out_f32 in the split form)
                 if dp_maps is None:
                     _, dp_maps = pyramid_alloc(B, sizes, Wc, dtype, dev)
-                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, split=split, out_f32=split)
                 else:                                   # second tower: accumulate onto the first one's gradient
                     ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, res=dp_maps,
-                               res_mode=RES_ADD)
+                               res_mode=RES_ADD, split=split, out_f32=split)
     return dp_maps, g

@@ -88,6 +88,10 @@ def _igemm_symbol(dtype, desc):
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % (v[0], v[1], v[2])
     if 4 <= kid < 8:
         return 'conv_igemm_kernel<f32,%d,bf16x3>' % (128, 64, 32, 16)[kid - 4]
+    if kid in (8, 9):
+        return 'conv_igemm_kernel<split,%d,bf16x3>' % (128, 64)[kid - 8]
+    if kid >= 10000:
+        return 'conv_igemm_pers_kernel<split,bf16x3>'
     return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', (128, 64, 32, 16)[max(kid, 0)])
 
 
@@ -298,15 +302,16 @@ def zeros(shape, device):
     return t.view(shape)
 
 
-def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
-    """OIHW fp32 -> packed [Cout][taps][Cin_pad] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1)."""
+def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
+    """OIHW fp32 -> packed [Cout][taps][Cin_pad] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1).
+    x3=True: always the pre-split bf16x3 operand layout (the convs on split-layout activations need it whatever the size)."""
     Cout, Cin, KH, KW = w_oihw.shape
     w = w_oihw.detach()
     assert w.dtype == torch.float32 and w.is_contiguous()
     if cin_pad is None:
         cin_pad = Cin if mode == 0 else Cout
     shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, cin_pad)
-    code = _mma_dtype_code(dtype, KH * KW * cin_pad, shape[0])
+    code = L.F32_BF16X3 if x3 else _mma_dtype_code(dtype, KH * KW * cin_pad, shape[0])
     PREP = get_prep()
     if PREP is not None:
         bn = PREP.bn_src.get(scale.data_ptr()) if scale is not None else None
@@ -324,8 +329,10 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None):
 
 
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
-           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False):
-    """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level."""
+           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False):
+    """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
+    split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
+    is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed)."""
     if isinstance(xs, Map):
         xs, ys = [xs], [ys]
         zs = [zs] if zs is not None else None
@@ -349,7 +356,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
             assert (r.addr() - br) * isy == (y.addr() - base_y) * r.t.element_size() and r.ld == y.ld and r.bstride == y.bstride
         d.res = br
     d.scale, d.shift, d.rowscale = (t.data_ptr() if t is not None else None for t in (scale, shift, rowscale))
-    d.dtype, d.out_f32 = _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout), int(out_f32)
+    d.dtype, d.out_f32 = (L.F32_SPLIT if split else _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout)), int(out_f32)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.ldy = x0.ld, y0.ld
@@ -361,7 +368,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
 
-def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True):
+def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False):
     """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
     split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
     runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ..."""
@@ -375,7 +382,7 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     d.x, d.dz = base_x, base_z
     d.dw = dw.data_ptr() if dw is not None else None
     d.dbias = dbias.data_ptr() if dbias is not None else (1 if (want_bias and dw is None) else None)    # dw None: only a request flag
-    d.dtype = _mma_dtype_code(x0.dtype)
+    d.dtype = L.F32_SPLIT if split else _mma_dtype_code(x0.dtype)     # split: both operands in the split layout (see conv2d)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.lddz = x0.ld, z0.ld
@@ -389,7 +396,8 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     nbytes = ws.numel() * 4
     # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
     _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else
-           ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>'), flops,
+           ('conv_wgrad_tr_kernel<4,split,bf16x3>' if split else
+            ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>')), flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
@@ -425,6 +433,31 @@ def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None):
                                                 Cin if cin_pad is None else cin_pad, nslabs, L.stream_ptr()),
             'effdet_unpack_conv_wgrad_bn')
     return dw, dgb[0], dgb[1]
+
+
+def wgrad_split_supported(B, sizes, Cin, Cout, lddz, KH=3, KW=3, pad=1):
+    """Can the split-operand weight-gradient kernel take these pyramid levels (same-padded stride-1 conv, flat level-major
+    buffers)?  Host-side query only (no device work)."""
+    d = L.WgradDesc()
+    d.x, d.dz, d.dw, d.dbias = 128, 128, None, None
+    d.dtype, d.B, d.Cin, d.Cout, d.KH, d.KW = L.F32_SPLIT, B, Cin, Cout, KH, KW
+    d.stride, d.pad_t, d.pad_l, d.ldx, d.lddz = 1, pad, pad, Cin, lddz
+    d.nseg = len(sizes)
+    ox = oz = 0
+    for i, (h, w) in enumerate(sizes):
+        s = d.seg[i]
+        s.H, s.W, s.Ho, s.Wo = h, w, h, w
+        s.in_off, s.in_bstride, s.out_off, s.out_bstride = ox, h * w * Cin, oz, h * w * lddz
+        ox += B * h * w * Cin; oz += B * h * w * lddz
+    return int(L.lib().effdet_conv2d_wgrad_splits(C.byref(d))) >= 1
+
+
+def to_split(t):
+    """plain fp32 tensor (rows of whole 32-channel groups) -> the same shape in the split layout (out of place)."""
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() % 32 == 0
+    out = torch.empty_like(t)
+    L.check(L.lib().effdet_to_split(L.ptr(t), L.ptr(out), C.c_longlong(t.numel()), L.stream_ptr()), 'effdet_to_split')
+    return out
 
 
 def nhwc_to_nchw(m):
@@ -746,7 +779,7 @@ def focal_loss_bwd_pix(cls, reg, anc, annots, gscale, ws, dtype, dld):
     return dcls, dreg
 
 
-def focal_loss_fwd_grad(cls, reg, anc, annots, dtype, dld):
+def focal_loss_fwd_grad(cls, reg, anc, annots, dtype, dld, split=False):
     """Training fast path: -> (losses [2], ws, dcls_pix [B, A/9, dld]) in one pass over cls; dcls_pix is the gradient wrt the
     logits for an upstream gradient of ONE (the caller scales downstream, see effdet_hip.h)."""
     B, A, nc = cls.shape
@@ -755,17 +788,18 @@ def focal_loss_fwd_grad(cls, reg, anc, annots, dtype, dld):
     losses = torch.empty(2, dtype=torch.float32, device=cls.device)
     dcls = torch.empty((B, A // 9, dld), dtype=dtype, device=cls.device)
     L.check(L.lib().effdet_focal_loss_fwd_grad(L.ptr(cls), L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(losses), L.ptr(ws),
-                                               C.c_longlong(nbytes), L.ptr(dcls), dld, L.dtype_code(dtype), B, C.c_longlong(A), nc,
+                                               C.c_longlong(nbytes), L.ptr(dcls), dld, L.F32_SPLIT if split else L.dtype_code(dtype), B, C.c_longlong(A), nc,
                                                annots.shape[1], L.stream_ptr()), 'effdet_focal_loss_fwd_grad')
     return losses, ws, dcls
 
 
-def focal_loss_bwd_reg(reg, anc, annots, gscale, ws, dtype):
+def focal_loss_bwd_reg(reg, anc, annots, gscale, ws, dtype, reg_ld=0, split=False):
+    """-> dreg [B, A, 4], or with reg_ld pixel-major and channel-padded [B, A/9, reg_ld] (split=True: in the split layout)."""
     B, A, _ = reg.shape
-    dreg = torch.empty((B, A, 4), dtype=dtype, device=reg.device)
-    L.check(L.lib().effdet_focal_loss_bwd_reg(L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(gscale), L.ptr(ws), L.ptr(dreg),
-                                              L.dtype_code(dtype), B, C.c_longlong(A), annots.shape[1], L.stream_ptr()),
-            'effdet_focal_loss_bwd_reg')
+    dreg = torch.empty((B, A // 9, reg_ld) if reg_ld else (B, A, 4), dtype=dtype, device=reg.device)
+    L.check(L.lib().effdet_focal_loss_bwd_reg(L.ptr(reg), L.ptr(anc), L.ptr(annots), L.ptr(gscale), L.ptr(ws), L.ptr(dreg), reg_ld,
+                                              L.F32_SPLIT if split else L.dtype_code(dtype), B, C.c_longlong(A), annots.shape[1],
+                                              L.stream_ptr()), 'effdet_focal_loss_bwd_reg')
     return dreg
 
 

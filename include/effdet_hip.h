@@ -30,7 +30,16 @@ enum { EFFDET_F32 = 0, EFFDET_BF16 = 1,
         * v_mfma_f32_16x16x32_bf16 with fp32 accumulation (~16 mantissa bits per product; 3/8 of the matrix-pipe passes
         * of v_mfma_f32_16x16x4_f32).  effdet_conv2d: KH*KW*Cin % 32 == 0 and w packed by effdet_pack_conv_weight /
         * EFFDET_PREP_PACK* with this same dtype (pre-split [32 x hi | 32 x lo] groups, same byte size as fp32). */
-       EFFDET_F32_BF16X3 = 2 };
+       EFFDET_F32_BF16X3 = 2,
+       /* effdet_conv2d / effdet_conv2d_wgrad / effdet_to_split only: the SPLIT activation layout of the bf16x3 arithmetic.  4
+        * bytes per element like fp32 (same offsets / strides, in elements), but every 128-byte group of a pixel row -- 32
+        * channels -- holds [32 x bf16 hi | 32 x bf16 lo] with value = hi + lo (+ O(2^-17 |value|)): channel n at byte
+        * (n / 32) * 128 + (n % 32) * 2 (hi) and + 64 (lo).  Written by the epilogue of effdet_conv2d (y of an EFFDET_F32_SPLIT conv
+        * unless out_f32), the loss kernels and effdet_to_split; read by effdet_conv2d / effdet_conv2d_wgrad as MFMA operands with
+        * no splitting work in the loop.  Channel counts and row pitches are multiples of 32, rows 128-byte aligned.
+        * effdet_conv2d: x split; w packed with EFFDET_F32_BF16X3; y split (Cout % 32 == 0; res, if any, is the EFFDET_RES_RELU_MASK
+        * activation in the same layout) or, with out_f32, plain fp32 (res, if any, EFFDET_RES_ADD in plain fp32); no z. */
+       EFFDET_F32_SPLIT = 3 };
 enum { EFFDET_ACT_NONE = 0, EFFDET_ACT_RELU = 1, EFFDET_ACT_SWISH = 2, EFFDET_ACT_SIGMOID = 3 };
 /* what the `res` tensor of a conv does in the epilogue */
 enum { EFFDET_RES_NONE = 0, EFFDET_RES_ADD = 1, EFFDET_RES_RELU_MASK = 2, EFFDET_RES_SWISH_GRAD = 3 };
@@ -337,8 +346,12 @@ int effdet_focal_loss_bwd_pix(const float* cls, const float* reg, const float* a
 int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, const float* anchors, const float* annots,
                                float* losses, void* workspace, long long workspace_bytes, void* dcls_pix, int dld,
                                int dtype, int B, long long A, int num_classes, int N, effdet_stream_t stream);
+/* dtype EFFDET_F32_SPLIT (fwd_grad / bwd_reg): the gradient rows are written in the split layout (dld / reg_ld % 32 == 0, 128-byte
+ * aligned buffers) -- ready-made MFMA operands of the head's gradient convs in the bf16x3 arithmetic.
+ * reg_ld != 0: d(reg) is written PIXEL-major like dcls_pix -- dreg[b][pixel][reg_ld], channel = anchor*4 + k, zeros in [36, reg_ld);
+ * reg_ld == 0: [B][A][4]. */
 int effdet_focal_loss_bwd_reg(const float* reg, const float* anchors, const float* annots, const float* gscale,
-                              const void* workspace, void* dreg, int dtype, int B, long long A, int N,
+                              const void* workspace, void* dreg, int reg_ld, int dtype, int B, long long A, int N,
                               effdet_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -370,6 +383,10 @@ int effdet_clip_adamw_step(const unsigned long long* params, const unsigned long
  * for c < C, 0 beyond (makes an unaligned-channel gradient map consumable by effdet_conv2d). */
 int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, long long src_bstride, int src_ld,
                     int B, int HW, int C, int Cpad, effdet_stream_t stream);
+
+/* plain fp32 -> split layout (EFFDET_F32_SPLIT), elementwise over n elements (n % 4 == 0; rows are whole 32-channel groups and
+ * both buffers 128-byte aligned, so element i of src lands in the group of element i of dst).  Out of place. */
+int effdet_to_split(const float* src, void* dst, long long n, effdet_stream_t stream);
 
 /* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
 int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
