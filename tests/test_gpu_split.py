@@ -182,7 +182,7 @@ def test_loss_kernels_write_the_split_layout():
     assert not bool(back[..., 36:].any())
 
 
-@pytest.mark.parametrize('S', [512, 640])       # (pyramids whose coarsest level still has whole 8-pixel runs: >= 4 x 4, i.e. inputs >= 512)
+@pytest.mark.parametrize('S', [512, 1024])       # (pyramids whose coarsest level still has whole 8-pixel runs: >= 4 x 4, i.e. inputs >= 512)
 def test_model_with_split_head_matches_plain_head(S):
     """Whole model, bf16x3 arithmetic: the split-layout head == the plain-fp32-storage head (register splits) on losses and all
     274 gradients -- the two differ only in WHEN the same hi / lo values are formed."""
