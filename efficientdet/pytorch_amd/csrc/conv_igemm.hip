@@ -234,26 +234,41 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     auto loadsp = [&](int buf, Frags& f) {
       // weights arrive pre-split (pack.hip, store_x3): chunk lq = hi, chunk 4 + lq = lo of k = 8*lq .. 8*lq+7 -- so the
       // activation side takes the same k: chunks 2*lq, 2*lq + 1 (both conflict-free under the (row>>1)&7 swizzle)
+      if constexpr (SPLIT == 2) {
+        // both operands pre-split: the hi fragments first, so that the hi*hi MFMAs can start while the lo fragments are in flight
 #pragma unroll
-      for (int a = 0; a < NT; ++a) {
-        const int r = buf * WLD + (wn0 + a * 16 + l15) * 8;
-        f.wh[a] = ws[r + (lq ^ lsw)]; f.wl[a] = ws[r + ((4 + lq) ^ lsw)];
-      }
+        for (int a = 0; a < NT; ++a) f.wh[a] = ws[buf * WLD + (wn0 + a * 16 + l15) * 8 + (lq ^ lsw)];
 #pragma unroll
-      for (int b = 0; b < MT; ++b) {
-        const int r = buf * XLD + (wm0 + b * 16 + l15) * 8;
-        if constexpr (SPLIT == 2) { f.xh[b] = xs[r + (lq ^ lsw)]; f.xl[b] = xs[r + ((4 + lq) ^ lsw)]; }
-        else split8(xs[r + ((2 * lq) ^ lsw)], xs[r + ((2 * lq + 1) ^ lsw)], f.xh[b], f.xl[b]);
+        for (int b = 0; b < MT; ++b) f.xh[b] = xs[buf * XLD + (wm0 + b * 16 + l15) * 8 + (lq ^ lsw)];
+#pragma unroll
+        for (int b = 0; b < MT; ++b) f.xl[b] = xs[buf * XLD + (wm0 + b * 16 + l15) * 8 + ((4 + lq) ^ lsw)];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) f.wl[a] = ws[buf * WLD + (wn0 + a * 16 + l15) * 8 + ((4 + lq) ^ lsw)];
+      } else {
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+          const int r = buf * WLD + (wn0 + a * 16 + l15) * 8;
+          f.wh[a] = ws[r + (lq ^ lsw)]; f.wl[a] = ws[r + ((4 + lq) ^ lsw)];
+        }
+#pragma unroll
+        for (int b = 0; b < MT; ++b) {
+          const int r = buf * XLD + (wm0 + b * 16 + l15) * 8;
+          split8(xs[r + ((2 * lq) ^ lsw)], xs[r + ((2 * lq + 1) ^ lsw)], f.xh[b], f.xl[b]);
+        }
       }
     };
     auto mmasp = [&](const Frags& f) {
-      // term-major: consecutive MFMAs go to different accumulators (the small cross terms first, the main term last)
+      // term-major: consecutive MFMAs go to different accumulators.  SPLIT == 1: the small cross terms first, the main term last;
+      // SPLIT == 2: in the order the fragments arrive (hi*hi, hi*lo, lo*hi)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int a = 0; a < NT; ++a)
 #pragma unroll
-          for (int b = 0; b < MT; ++b) Mma<bf16_t>::run(t == 0 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
+          for (int b = 0; b < MT; ++b) {
+            if constexpr (SPLIT == 2) Mma<bf16_t>::run(t == 2 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
+            else Mma<bf16_t>::run(t == 0 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
+          }
     };
     // ONE register set: 110 VGPRs = 4 waves / SIMD (two workgroups per CU).  An A/B register double buffer across K-steps
     // (184 VGPRs, 2 waves / SIMD) measured 232-286 TFLOP/s on the head shapes against 278-348 for this form -- the other

@@ -318,16 +318,8 @@ __device__ __forceinline__ unsigned oob_if(unsigned long long mask, unsigned val
   return __builtin_amdgcn_inverse_ballot_w64(mask) ? EFFDET_OOB : val;                 // one v_cndmask on an SGPR-pair mask
 }
 
-// X3S = 1 (EFFDET_F32_SPLIT): both operands are fp32-precision activations stored in the SPLIT layout -- every 128-byte group of a
-// pixel row = 32 channels as [32 x bf16 hi | 32 x bf16 lo] -- which this kernel stages and transposes exactly like a bf16 tensor
-// of twice the channel count (all staging fields of WgradK are in that bf16 VIEW: Cin, lddz, ldx, Kc, cpt, offsets).  A 64-wide
-// block of the view is one 32-channel group, its 16-channel MFMA blocks 0,1 = hi and 2,3 = lo, so a wave tile of 64 x 64 (NW = 4)
-// holds everything the bf16x3 product of a 32 x 32 block of G needs: acc[a][b] += hi_a*hi_b + hi_a*lo_b + lo_a*hi_b -- 12 MFMAs on
-// 8 transposed fragment reads per 32 pixels and NO splitting VALU (conv_wgrad_f32dma_kernel<4, 1> splits both operands in
-// registers: 5 VALU per value pair).  p.Cout / p.K stay ALGORITHMIC (the slab is [Cout][K] fp32 as for every other kernel).
-template <int NW, int X3S = 0>
+template <int NW>
 __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) {
-  static_assert(!X3S || NW == 4, "the split-operand form is built for 4 waves of 64 x 64");
   constexpr int WJ = NW / 2;                    // waves along j (2 along n): 4 waves = 2x2 of 64x64, 8 waves = 2x4 of 64x32
   constexpr int WTJ = 128 / WJ, JT = WTJ / 16;
   constexpr int BKM = 64;                       // pixels per stage (two 32-pixel MFMA k-steps)
@@ -434,66 +426,6 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
   const int l15 = lane & 15, lq = lane >> 4;
   float* slab = p.slab + (long long)split * p.Cout * p.K;
 
-  if constexpr (X3S) {
-    // ---- split operands: 32 x 32 algorithmic outputs per wave, three MFMAs per accumulator tile and 32-pixel k-step ----
-    f32x4 acc3[2][2], bs3[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      bs3[a] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int b = 0; b < 2; ++b) acc3[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    const int n_alg0 = nt * 64 + (wn0 >> 6) * 32, j_alg0 = jt * 64 + (wj0 >> 6) * 32;
-    if (nsteps > 0) {
-      stage(0);
-      for (int kt = 0; kt < nsteps; ++kt) {
-        const unsigned cur = (unsigned)(kt & 1) * BUFB;
-        dma_wait_all();
-        __syncthreads();
-        if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          uint4 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-          for (int a = 0; a < 2; ++a) { ah[a] = frag(a_addr[a] + cur + (unsigned)ks * 8192u); al[a] = frag(a_addr[2 + a] + cur + (unsigned)ks * 8192u); }
-#pragma unroll
-          for (int b = 0; b < 2; ++b) { bh[b] = frag(b_addr[b] + cur + (unsigned)ks * 8192u); bl[b] = frag(b_addr[2 + b] + cur + (unsigned)ks * 8192u); }
-          // term-major: consecutive MFMAs go to different accumulators (the small cross terms first, the main term last)
-#pragma unroll
-          for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-              for (int b = 0; b < 2; ++b) WMma<bf16_t>::run(t == 0 ? al[a] : ah[a], t == 1 ? bl[b] : bh[b], acc3[a][b]);
-          if (want_bias) {
-#pragma unroll
-            for (int a = 0; a < 2; ++a) { WMma<bf16_t>::run(al[a], ones, bs3[a]); WMma<bf16_t>::run(ah[a], ones, bs3[a]); }
-          }
-        }
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const int n = n_alg0 + a * 16 + lq * 4 + rr;
-          if (n >= p.Cout) continue;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            const int j = j_alg0 + b * 16 + l15;
-            if (j < p.K) slab[(long long)n * p.K + j] = acc3[a][b][rr];
-          }
-          if (want_bias && l15 == 0) p.dbp[(long long)split * p.Cout + n] = bs3[a][rr];
-        }
-      }
-    } else {
-      for (int i = tid; i < 64 * 64; i += NW * 64) {
-        const int n = nt * 64 + i / 64, j = jt * 64 + (i & 63);
-        if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
-      }
-      if (p.dbp && jt == 0 && tid < 64 && nt * 64 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 64 + tid] = 0.f;
-    }
-    return;
-  }
   if (nsteps > 0) {
     stage(0);
     for (int kt = 0; kt < nsteps; ++kt) {
@@ -534,6 +466,174 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
     }
   } else {
     for (int i = tid; i < 128 * 128; i += NW * 64) {
+      const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
+      if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
+    }
+    if (p.dbp && jt == 0 && tid < 128 && nt * 128 + tid < p.Cout) p.dbp[(long long)split * p.Cout + nt * 128 + tid] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// EFFDET_F32_SPLIT weight gradient: both operands are fp32-precision activations stored in the SPLIT layout -- every 128-byte
+// group of a pixel row = 32 channels as [32 x bf16 hi | 32 x bf16 lo] -- i.e. byte for byte a bf16 tensor of twice the channel count
+// (the VIEW: all staging fields of WgradK -- lddz, ldx, Kc, cpt, offsets -- are in view units; p.Cout / p.K stay ALGORITHMIC, the
+// slab is [Cout][K] fp32 as for every other kernel).  A 64-wide block of the view is one 32-channel group whose 16-channel MFMA
+// blocks 0,1 are hi and 2,3 lo, so the bf16x3 product of a 32 x 32 block of G is acc += hi_a*hi_b + hi_a*lo_b + lo_a*hi_b on
+// fragments read straight out of LDS with ds_read_b64_tr_b16: NO splitting VALU (conv_wgrad_f32dma_kernel<4, 1> splits both
+// operands in registers, 5 VALU per value pair, and tops out at 230 TFLOP/s on the head shapes).
+//   Workgroup tile 128 n x 128 j algorithmic (256 x 256 of the view), 8 waves as 2 (n) x 4 (j); a wave owns 64 n x 32 j = two
+//   n-groups x one j-group: 12 fragments (24 transposed reads) feed 24 MFMAs per 32-pixel k-step -- 1.0 LDS read per MFMA (the bf16
+//   kernel above: 1.5) and 170 staged bytes per MFMA (256), which is what the three-products-per-value arithmetic needs to pay off.
+//   Stage = 32 pixels: dz [4 row groups][4 pieces] + x [4][4] pieces of 8 pixels x 128 B = 32 KiB, two stages, two workgroups per
+//   CU (4 waves / SIMD).  Waves 0-3 stage dz (row group w, its four 64-wide pieces), waves 4-7 stage x: one scalar pixel cursor per
+//   wave, four DMA instructions per stage.  LDS image of a piece and the fragment addressing are those of conv_wgrad_tr_kernel.
+__global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradK p) {
+  constexpr unsigned OPB = 16384, BUFB = 2 * OPB, RG = 4096;     // operand / stage / row-group (8 pixels x 4 pieces) bytes
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 2, wj = wave & 3;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = logical % p.ntiles, jt = (logical / p.ntiles) % p.jtiles, split = logical / (p.ntiles * p.jtiles);
+  int si = 0;
+#pragma unroll
+  for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+    if (s < p.nseg && split >= p.seg[s].split_start) si = s;
+  const WSeg sg = p.seg[si];
+  const int m_begin = (split - sg.split_start) * p.mchunk;
+  const int m_end = min(sg.M, m_begin + p.mchunk);
+  const int nsteps = (m_end - m_begin + 31) / 32;
+
+  // ---- staging role of this wave: operand (dz | x) and row group; per 64-wide piece hf the lane's source offset and masks ----
+  const bool stage_x = wave >= 4;                                 // wave-uniform
+  const int rgi = wave & 3;
+  const int Wr = sg.Wo < 8 ? sg.Wo : 8, RP = 8 / Wr;               // pixels per image row / image rows per piece
+  const int r = lane >> 3, g = (lane & 7) ^ (((r >> 1) & 3) << 1);  // pixel in the piece, SOURCE 16-byte chunk (32-byte blocks swizzled)
+  const int dho = r / Wr, dwo = r - dho * Wr;
+  // per-lane validity flags of each piece (bit 0: never valid, 1..4: invalid when the piece touches the top / bottom / left / right
+  // border of the image): one VGPR per piece and 3 VALU per DMA -- the 64-bit lane-mask form of the bf16 kernel would need 40
+  // SGPRs here (4 pieces x 5 masks) and spilled
+  int off_s[4]; unsigned flg[4];
+#pragma unroll
+  for (int hf = 0; hf < 4; ++hf) {
+    if (!stage_x) {
+      const int n = nt * 256 + hf * 64 + g * 8;                    // view channel of the chunk
+      off_s[hf] = (r * p.lddz + n) * 2;
+      flg[hf] = (n + 8 > p.lddz) ? 1u : 0u;
+    } else {
+      const int jq = jt * 32 + hf * 8 + g;                         // 16-byte chunk of the view's (tap, channel) axis
+      const bool jok = jq < p.Kc;
+      const int tap = jok ? jq / p.cpt : 0, cc = jok ? jq - tap * p.cpt : 0;
+      const int kh = tap / p.KW, kw = tap - kh * p.KW;
+      const int dkh = kh - p.pad_t, dkw = kw - p.pad_l;
+      off_s[hf] = ((dkh * sg.W + dkw + r) * p.ldx + cc * 8) * 2;
+      flg[hf] = (jok ? 0u : 1u) | ((dkh < 0 && dho == 0) ? 2u : 0u) | ((dkh > 0 && dho == RP - 1) ? 4u : 0u) |
+                ((dkw < 0 && dwo == 0) ? 8u : 0u) | ((dkw > 0 && dwo == Wr - 1) ? 16u : 0u);
+    }
+  }
+  const u32x4_t srd = stage_x ? make_srd_raw((const bf16_t*)p.x + sg.in_off, sg.x_bytes)
+                              : make_srd_raw((const bf16_t*)p.dz + sg.out_off, sg.dz_bytes);
+  const u32x4_t srd_u = u32x4_t{(unsigned)__builtin_amdgcn_readfirstlane((int)srd[0]), (unsigned)__builtin_amdgcn_readfirstlane((int)srd[1]),
+                                (unsigned)__builtin_amdgcn_readfirstlane((int)srd[2]), (unsigned)__builtin_amdgcn_readfirstlane((int)srd[3])};
+  const unsigned s_bs = (unsigned)((stage_x ? sg.in_bs : sg.out_bs) * 2), s_ld = (unsigned)((stage_x ? p.ldx : p.lddz) * 2);
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned dst0 = lds0 + (stage_x ? OPB : 0u) + (unsigned)rgi * RG;
+
+  const int HoWo = sg.Ho * sg.Wo;
+  int cm = m_begin + 8 * rgi;                                      // scalar pixel cursor of this wave's row group
+  int cb = cm / HoWo, crem = cm - cb * HoWo;
+  int cho = crem / sg.Wo, cwo = crem - cho * sg.Wo;
+  auto stage = [&](int buf) {
+    // scalar: which flag bits invalidate a lane for THIS row group (bit 0 always; past the split's end: every lane)
+    const bool all_out = cm >= m_end;
+    const unsigned cmask = 1u | (cho == 0 ? 2u : 0u) | (cho == sg.Ho - RP ? 4u : 0u) | (cwo == 0 ? 8u : 0u) | (cwo == sg.Wo - Wr ? 16u : 0u);
+    const unsigned base = (unsigned)cb * s_bs + (unsigned)(cho * sg.Wo + cwo) * s_ld;
+    const unsigned dst = dst0 + (unsigned)buf * BUFB;
+#pragma unroll
+    for (int hf = 0; hf < 4; ++hf)
+      dma16_async(srd_u, dst + (unsigned)hf * 1024u, (all_out || (flg[hf] & cmask)) ? EFFDET_OOB : base + (unsigned)off_s[hf]);
+    cm += 32; cwo += 32;
+    while (cwo >= sg.Wo) { cwo -= sg.Wo; if (++cho == sg.Ho) { cho = 0; ++cb; } }
+  };
+
+  // ---- fragment read addresses (bytes, stage-relative): 16-lane group q takes pixel rows {4q'..} of row groups (q >> 1) and + 2 ----
+  const int s16 = lane & 15, q = lane >> 4, jrow = s16 >> 2;
+  const unsigned lane_base = (unsigned)(q >> 1) * RG + (unsigned)((q & 1) * 4 + jrow) * 128u + (unsigned)(s16 & 3) * 8u;
+  const int xr = (q & 1) * 2 + (jrow >> 1);
+  unsigned a_addr[2][4], b_addr[4];                                  // [n-group][16-channel block: 0,1 hi | 2,3 lo]
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a_addr[gi][k] = lds0 + lane_base + (unsigned)(2 * wn + gi) * 1024u + (unsigned)((k ^ xr) * 32);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) b_addr[k] = lds0 + OPB + lane_base + (unsigned)wj * 1024u + (unsigned)((k ^ xr) * 32);
+  auto frag = [&](unsigned addr) -> uint4 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)addr);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(size_t)(addr + 2u * RG));
+    const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+    return make_uint4(l2.x, l2.y, h2.x, h2.y);
+  };
+
+  f32x4 acc[2][2][2], bsum[2][2];
+#pragma unroll
+  for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      bsum[gi][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b = 0; b < 2; ++b) acc[gi][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  const bool want_bias = (p.dbp != nullptr) && (jt == 0) && (wj == 0);
+  const uint4 ones = WMma<bf16_t>::ones();
+  const int l15 = lane & 15, lq = lane >> 4;
+  float* slab = p.slab + (long long)split * p.Cout * p.K;
+  const int n_alg0 = nt * 128 + wn * 64, j_alg0 = jt * 128 + wj * 32;
+
+  if (nsteps > 0) {
+    stage(0);
+    for (int kt = 0; kt < nsteps; ++kt) {
+      const unsigned cur = (unsigned)(kt & 1) * BUFB;
+      dma_wait_all();
+      __syncthreads();
+      if (kt + 1 < nsteps) stage((kt & 1) ^ 1);
+      uint4 bh[2], bl[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) { bh[b] = frag(b_addr[b] + cur); bl[b] = frag(b_addr[2 + b] + cur); }
+#pragma unroll
+      for (int gi = 0; gi < 2; ++gi) {
+        uint4 ah[2], al[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { ah[a] = frag(a_addr[gi][a] + cur); al[a] = frag(a_addr[gi][2 + a] + cur); }
+        // term-major: consecutive MFMAs go to different accumulators (the small cross terms first, the main term last)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) WMma<bf16_t>::run(t == 0 ? al[a] : ah[a], t == 1 ? bl[b] : bh[b], acc[gi][a][b]);
+        if (want_bias) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) { WMma<bf16_t>::run(al[a], ones, bsum[gi][a]); WMma<bf16_t>::run(ah[a], ones, bsum[gi][a]); }
+        }
+      }
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const int n = n_alg0 + gi * 32 + a * 16 + lq * 4 + rr;
+          if (n >= p.Cout) continue;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int j = j_alg0 + b * 16 + l15;
+            if (j < p.K) slab[(long long)n * p.K + j] = acc[gi][a][b][rr];
+          }
+          if (want_bias && l15 == 0) p.dbp[(long long)split * p.Cout + n] = bsum[gi][a][rr];
+        }
+  } else {
+    for (int i = tid; i < 128 * 128; i += 512) {
       const int n = nt * 128 + i / 128, j = jt * 128 + (i & 127);
       if (n < p.Cout && j < p.K) slab[(long long)n * p.K + j] = 0.f;
     }
@@ -809,7 +909,7 @@ __global__ void wgrad_bias_reduce_kernel(const float* __restrict__ part, float* 
 }  // namespace
 
 namespace {
-int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
+int plan(const effdet_wgrad_t* p, WgradK& k, int& splits, int tile = 128) {
   if (!p || p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
   if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16) return EFFDET_EINVAL;
   const int ce = p->dtype == EFFDET_F32 ? 4 : 8;
@@ -819,7 +919,7 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits) {
   k.ldx = p->ldx; k.lddz = p->lddz; k.B = p->B;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt; k.K = p->KH * p->KW * p->Cin;
   k.nseg = p->nseg;
-  k.ntiles = (p->Cout + 127) / 128; k.jtiles = (k.K + 127) / 128;
+  k.ntiles = (p->Cout + tile - 1) / tile; k.jtiles = (k.K + tile - 1) / tile;      // (tile = 256 of the bf16 VIEW for the split-layout kernel)
   k.vec_a = (p->lddz % ce == 0) && (((p->Cout + ce - 1) / ce * ce) <= p->lddz) ? 1 : 0;
   const int bkm = 8 * ce;
   long long Mtot = 0;
@@ -906,7 +1006,7 @@ static bool split_all_eligible(const effdet_wgrad_t* pv, const WgradK& k) {
 extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  if (plan(p, k, splits) != EFFDET_OK) return -1;
+  if (plan(p, k, splits, pn_split ? 256 : 128) != EFFDET_OK) return -1;
   if (pn_split) {
     if (!split_all_eligible(p, k)) return -1;
     return (long long)splits * pn_cout * ((long long)(k.K / 2) + 1) * (long long)sizeof(float);
@@ -917,7 +1017,7 @@ extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p
 extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  if (plan(p, k, splits) != EFFDET_OK) return -1;
+  if (plan(p, k, splits, pn_split ? 256 : 128) != EFFDET_OK) return -1;
   if (pn_split && !split_all_eligible(p, k)) return -1;
   return splits;
 }
@@ -967,7 +1067,7 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  const int rc = plan(p, k, splits);
+  const int rc = plan(p, k, splits, pn_split ? 256 : 128);
   if (rc != EFFDET_OK) return rc;
   if (pn_split) {
     // split-layout operands: one launch of the transpose-read kernel in its three-product form (k = the bf16 VIEW for staging;
@@ -984,10 +1084,10 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
         d.H = d.Ho = 1; d.W = d.Wo = d.M;
       }
     }
-    const size_t lds4 = (size_t)4 * 128 * 8 * sizeof(uint4);
+    const size_t lds4 = (size_t)4 * 128 * 8 * sizeof(uint4);      // 2 stages x (dz 16 KiB + x 16 KiB)
     hipStream_t st4 = (hipStream_t)stream;
-    EFFDET_SET_MAX_LDS((conv_wgrad_tr_kernel<4, 1>), lds4);
-    hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 1>), dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(4 * 64), lds4, st4, k);
+    EFFDET_SET_MAX_LDS(conv_wgrad_split_kernel, lds4);
+    hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(512), lds4, st4, k);
     EFFDET_CHECK_LAUNCH();
     if (p->dw) {
       long long g = (nalg / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
