@@ -54,6 +54,7 @@ struct ConvK {
 };
 
 constexpr int BM = 128;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -85,9 +86,15 @@ template <> struct Mma<float> {
 // launches too small for that (<= 1 tile per CU: BiFPN convs on the coarse levels, the late backbone 1x1 convs) run ONE
 // workgroup per CU and were bound by the DMA round trip (1.27 us per K-step for 0.35 us of MFMA work): NS = 4 keeps three
 // tiles in flight (s_waitcnt vmcnt = pieces of the tiles issued after the one needed).
-template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2>
+// M32 (SPLIT == 2 only; A/B knob EFFDET_SPLIT_M32, off): the same loop on v_mfma_f32_32x32x16_bf16 tiles (wave tile 32 pixels x 64
+// channels = 1 x 2 MFMA tiles).  With no splitting VALU left, the 16x16x32 form reaches 1200 TFLOP/s of MFMA rate (3 x 400
+// algorithmic) -- the ceiling a bare loop of that instruction showed (1195-1335, tools/probe/mfma_peak.hip) -- so the faster-issuing
+// shape was the obvious try: it measured 342-360 against 370-390 (same LDS fragment bytes per MAC, longer dependent chains per
+// accumulator): the loop is bound by LDS port + latency hiding at this tile size, not by MFMA issue.
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2, int M32 = 0>
 __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
   static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
+  static_assert(!M32 || SPLIT == 2, "the 32x32x16 form is built for the split layout");
   static_assert(NS == 2 || !SPLIT, "deep staging is implemented for the plain loop");
   constexpr int CE = Elem<T>::CE;
   constexpr int NTHREADS = NWAVES * 64;
@@ -216,7 +223,59 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
       for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
   };
-  if constexpr (SPLIT) {
+  constexpr int NT32 = M32 ? WTN / 32 : 1, MT32 = M32 ? WTM / 32 : 1;
+  f32x16 acc32[NT32][MT32];
+  const int l31 = lane & 31, lh = lane >> 5;
+  if constexpr (M32) {
+    static_assert(WTN % 32 == 0 && WTM % 32 == 0, "32x32 MFMA tiles");
+#pragma unroll
+    for (int a = 0; a < NT32; ++a)
+#pragma unroll
+      for (int b = 0; b < MT32; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc32[a][b][e] = 0.f;
+    // a K-step (one 128-byte [32 hi | 32 lo] group per row) = two K16 slices kk: lane (row l & 31, half l >> 5) takes chunk 2*kk + half
+    // of the hi part and chunk 4 + 2*kk + half of the lo part; (row >> 1) & 7 swizzle as everywhere (conflict-free for 32-row
+    // fragments too: the persistent bf16 kernel reads the same image)
+    const int sw32 = (l31 >> 1) & 7;
+    auto mm32 = [](const uint4& a, const uint4& b, f32x16& c) {
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    };
+    auto kstep = [&](int buf) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        uint4 wh[NT32], wl[NT32], xh[MT32], xl[MT32];
+        const int ch = ((2 * kk + lh) ^ sw32), cl = ((4 + 2 * kk + lh) ^ sw32);
+#pragma unroll
+        for (int a = 0; a < NT32; ++a) wh[a] = ws[buf * WLD + (wn0 + a * 32 + l31) * 8 + ch];
+#pragma unroll
+        for (int b = 0; b < MT32; ++b) xh[b] = xs[buf * XLD + (wm0 + b * 32 + l31) * 8 + ch];
+#pragma unroll
+        for (int b = 0; b < MT32; ++b) xl[b] = xs[buf * XLD + (wm0 + b * 32 + l31) * 8 + cl];
+#pragma unroll
+        for (int a = 0; a < NT32; ++a) wl[a] = ws[buf * WLD + (wn0 + a * 32 + l31) * 8 + cl];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int a = 0; a < NT32; ++a)
+#pragma unroll
+            for (int b = 0; b < MT32; ++b) mm32(t == 2 ? wl[a] : wh[a], t == 1 ? xl[b] : xh[b], acc32[a][b]);
+      }
+    };
+    stage(0);
+    if (nk > 1) stage(1);
+    dma_wait_all();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int c = kt & 1;
+      kstep(c);
+      if (kt + 1 < nk) {
+        dma_wait_all();                    // tile kt+1 has landed (issued one whole K-step ago) ...
+        __syncthreads();                   // ... for everyone, and every wave has read tile kt out of buffer c
+        if (kt + 2 < nk) stage(c);
+      }
+    }
+  } else if constexpr (SPLIT) {
     // one slice per K-step: lane (row, lq) takes chunks lq and 4 + lq = 8 floats -> one 16x16x32 operand (any k <-> lane
     // assignment works as long as both operands share it); one barrier per K-step as below.
     struct Frags { uint4 wh[NT], wl[NT], xh[MT], xl[MT]; };
@@ -326,19 +385,94 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   // (An LDS-transposed variant with full-row 16-byte stores was measured: no gain -- PMC showed the epilogue of the
   //  HBM-bound pointwise convs VALU-bound (~1100 VALU per wave for 16 MFMAs), not store-bound; hence the hoisted
   //  16-byte scale/shift loads here and the v_rcp_f32 / v_cvt_pk_bf16_f32 helpers in common.h.)
-  f32x4 scv[NT], shv[NT];
+  // emit(n0, accumulators of channels n0..n0+3, scale, shift, output row, row scale): the fused epilogue of one lane's 4-channel group
+  auto emit = [&](int n0, f32x4 v, const f32x4& sc, const f32x4& sh, long long orow, float rs) {
+    v = v * sc + sh;
+    const bool full = p.vec_ok && (n0 + 3 < p.Cout);
+    const long long o = orow + n0;
+    if (p.z) {
+      if (full) store4((T*)p.z + o, v);
+      else
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.z + o + r, v[r]);
+    }
+    if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+    else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+    else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+    if (p.rowscale) v *= rs;
+    if constexpr (SPLIT == 2) {
+      if (p.out_split) {
+        // split layout: channel n of a pixel row sits at byte (n >> 5) * 128 + (n & 31) * 2 (hi) and + 64 (lo); the lane's 4
+        // consecutive channels (n0 % 4 == 0) are two 8-byte stores.  Host guarantees Cout % 32 == 0 and 128-byte aligned rows.
+        const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
+        if (p.res_mode == EFFDET_RES_RELU_MASK) {         // res = the forward activation in the same layout: sign of hi decides
+          const uint2 rh = *(const uint2*)((const char*)p.res + orow * 4 + goff);
+          const unsigned rv[4] = {rh.x & 0xffffu, rh.x >> 16, rh.y & 0xffffu, rh.y >> 16};
 #pragma unroll
-  for (int a = 0; a < NT; ++a) {
-    const int n0 = n_base + wn0 + a * 16 + lq * 4;
-    scv[a] = f32x4{1.f, 1.f, 1.f, 1.f}; shv[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int r = 0; r < 4; ++r) v[r] = ((rv[r] & 0x7fffu) != 0u && !(rv[r] & 0x8000u)) ? v[r] : 0.f;
+        }
+        uint2 hi, lo;
+        hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+        lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+        char* dst = (char*)p.y + orow * 4 + goff;
+        *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
+        return;
+      }
+    }
+    if (p.res_mode != EFFDET_RES_NONE) {
+      f32x4 q;
+      if (full) q = load4((const T*)p.res + o);
+      else
+        for (int r = 0; r < 4; ++r) q[r] = (n0 + r < p.Cout) ? Elem<T>::ld((const T*)p.res + o + r) : 0.f;
+      if (p.res_mode == EFFDET_RES_ADD) { v += q; }
+      else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
+      else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
+    }
+    if (p.out_f32) {
+      if (full) store4((float*)p.y + o, v);
+      else
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) ((float*)p.y)[o + r] = v[r];
+    } else {
+      if (full) store4((T*)p.y + o, v);
+      else
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.y + o + r, v[r]);
+    }
+  };
+  auto scale_shift = [&](int n0, f32x4& sc, f32x4& sh) {
+    sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (n0 + 3 < p.Cout) {
-      if (p.scale) scv[a] = *(const f32x4*)(p.scale + n0);
-      if (p.shift) shv[a] = *(const f32x4*)(p.shift + n0);
+      if (p.scale) sc = *(const f32x4*)(p.scale + n0);
+      if (p.shift) sh = *(const f32x4*)(p.shift + n0);
     } else {
       for (int r = 0; r < 4; ++r)
-        if (n0 + r < p.Cout) { if (p.scale) scv[a][r] = p.scale[n0 + r]; if (p.shift) shv[a][r] = p.shift[n0 + r]; }
+        if (n0 + r < p.Cout) { if (p.scale) sc[r] = p.scale[n0 + r]; if (p.shift) sh[r] = p.shift[n0 + r]; }
     }
+  };
+  if constexpr (M32) {
+    // 32x32 accumulator: lane (pixel column l & 31, half l >> 5) holds channels 8*g + 4*half + 0..3 of MFMA tile row-block a, g = 0..3
+#pragma unroll
+    for (int b = 0; b < MT32; ++b) {
+      const int m = m_base + wm0 + b * 32 + l31;
+      if (m >= sg.M) continue;
+      const int bi = m / HoWo, pix = m - bi * HoWo;
+      const long long orow = sg.out_off + (long long)bi * sg.out_bs + (long long)pix * p.ldy;
+      const float rs = p.rowscale ? p.rowscale[bi] : 1.0f;
+#pragma unroll
+      for (int a = 0; a < NT32; ++a)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int n0 = n_base + wn0 + a * 32 + gq * 8 + lh * 4;
+          if (n0 >= p.Cout) continue;
+          f32x4 sc, sh;
+          scale_shift(n0, sc, sh);
+          emit(n0, f32x4{acc32[a][b][4 * gq], acc32[a][b][4 * gq + 1], acc32[a][b][4 * gq + 2], acc32[a][b][4 * gq + 3]}, sc, sh, orow, rs);
+        }
+    }
+    return;
   }
+  f32x4 scv[NT], shv[NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a) scale_shift(n_base + wn0 + a * 16 + lq * 4, scv[a], shv[a]);
 #pragma unroll
   for (int b = 0; b < MT; ++b) {
     const int m = m_base + wm0 + b * 16 + l15;
@@ -350,56 +484,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     for (int a = 0; a < NT; ++a) {
       const int n0 = n_base + wn0 + a * 16 + lq * 4;
       if (n0 >= p.Cout) continue;
-      f32x4 v = acc[a][b] * scv[a] + shv[a];
-      const bool full = p.vec_ok && (n0 + 3 < p.Cout);
-      const long long o = orow + n0;
-      if (p.z) {
-        if (full) store4((T*)p.z + o, v);
-        else
-          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.z + o + r, v[r]);
-      }
-      if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
-      else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
-      else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
-      if (p.rowscale) v *= rs;
-      if constexpr (SPLIT == 2) {
-        if (p.out_split) {
-          // split layout: channel n of a pixel row sits at byte (n >> 5) * 128 + (n & 31) * 2 (hi) and + 64 (lo); the lane's 4
-          // consecutive channels (n0 % 4 == 0) are two 8-byte stores.  Host guarantees Cout % 32 == 0 and 128-byte aligned rows.
-          const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
-          if (p.res_mode == EFFDET_RES_RELU_MASK) {         // res = the forward activation in the same layout: sign of hi decides
-            const uint2 rh = *(const uint2*)((const char*)p.res + orow * 4 + goff);
-            const unsigned rv[4] = {rh.x & 0xffffu, rh.x >> 16, rh.y & 0xffffu, rh.y >> 16};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = ((rv[r] & 0x7fffu) != 0u && !(rv[r] & 0x8000u)) ? v[r] : 0.f;
-          }
-          uint2 hi, lo;
-          hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
-          lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
-          lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
-          char* dst = (char*)p.y + orow * 4 + goff;
-          *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
-          continue;
-        }
-      }
-      if (p.res_mode != EFFDET_RES_NONE) {
-        f32x4 q;
-        if (full) q = load4((const T*)p.res + o);
-        else
-          for (int r = 0; r < 4; ++r) q[r] = (n0 + r < p.Cout) ? Elem<T>::ld((const T*)p.res + o + r) : 0.f;
-        if (p.res_mode == EFFDET_RES_ADD) { v += q; }
-        else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
-        else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
-      }
-      if (p.out_f32) {
-        if (full) store4((float*)p.y + o, v);
-        else
-          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) ((float*)p.y)[o + r] = v[r];
-      } else {
-        if (full) store4((T*)p.y + o, v);
-        else
-          for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.y + o + r, v[r]);
-      }
+      emit(n0, acc[a][b], scv[a], shv[a], orow, rs);
     }
   }
 }
@@ -423,7 +508,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 //     moved back by the pad margin so that SGPR offset is never negative.  ~0 address VALU per K-step.
 // Same LDS image (128-byte rows, chunk ^ ((row>>1)&7) applied at the DMA source), same two-level software pipeline
 // (DMA two tiles ahead, fragments one K16-slice ahead, one barrier per K-step) and the same fused epilogue.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 // Out-of-range sentinel of this kernel's VGPR offsets.  The SGPR offset takes part in the hardware range check (measured:
 // a valid lane whose voffset + soffset passes num_records reads zeros), so (a) num_records covers the whole extent
 // relative to the shifted base and (b) the sentinel leaves headroom for the largest soffset without wrapping 32 bits.
@@ -445,7 +529,14 @@ __device__ __forceinline__ void dma16_async_s(u32x4_t rsrc, unsigned lds_byte_ad
 // NS = LDS stages (DMA runs NS-1 K-steps ahead).  With two stages a tile's DMA has exactly one K-step to land and the
 // barrier waits for the slowest of ~500 cache lines per CU (PMC: 22 % of them L2 misses): the K-step time tracked the miss tail,
 // not the MFMA time -- whatever the tile shape.
-template <int WM, int WN, int NS>
+// X3 = 1 (EFFDET_F32_SPLIT): activations in the split layout, weights packed for bf16x3.  Byte for byte the operands are bf16 tensors of
+// twice the channel count, so setup / tap walk / DMA run unchanged on a ConvK whose INPUT-side fields (ldx, in_off, in_bs, cpt, Kc) are
+// given in that bf16 view by the host; a K-step (128 bytes per row = one [32 hi | 32 lo] group) is two K16 phases kk, each 8 fragment
+// reads (w hi / lo, x hi / lo of k = 16*kk .. 16*kk+15) feeding 12 MFMAs (hi*hi, hi*lo, lo*hi on the 2 x 2 tiles): 0.33 LDS reads per
+// 16x16x32-equivalent MFMA against 0.5 in the 128 x 128 kernel, half its DMA bytes per MFMA.  One fragment set (32 VGPRs, as the
+// two slice sets of the bf16 form): the kernel lives in 128 VGPRs.  Output side (out_off, out_bs, ldy) in real 4-byte elements:
+// split or plain fp32 rows, ReLU-mask residual read from the split activation.
+template <int WM, int WN, int NS, int X3 = 0>
 __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const ConvK p) {
   constexpr int NW = WM * WN, TM = 64 * WM, TN = 64 * WN;
   constexpr int XP = TM / (8 * NW), WP = TN / (8 * NW);
@@ -583,6 +674,46 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    if constexpr (X3) {
+      dma_wait_all();
+      __syncthreads();
+      int cur = 0;
+      auto phase = [&](int stage, int kk) {
+        uint4 wh[2], wl[2], xh[2], xl[2];
+        const int ch = (2 * kk + lh) ^ lsw, cl = (4 + 2 * kk + lh) ^ lsw;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) wh[a] = smem[stage * STG + ai[a] + ch];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) xh[b] = smem[stage * STG + bi[b] + ch];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) xl[b] = smem[stage * STG + bi[b] + cl];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) wl[a] = smem[stage * STG + ai[a] + cl];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t == 2 ? wl[a] : wh[a]),
+                                                                  __builtin_bit_cast(bf16x8, t == 1 ? xl[b] : xh[b]), acc[a][b], 0, 0, 0);
+      };
+      for (int kt = 0; kt < nk; ++kt) {
+        const int nxt = (cur + 1 == NS) ? 0 : cur + 1;
+        phase(cur, 0);
+        phase(cur, 1);
+        if (kt + 1 < nk) {
+          wait_tiles(kt + NS - 1 < nk);        // tile kt+1 has landed (this wave's pieces) ...
+          __syncthreads();                     // ... and everyone's; all fragment reads of tile kt are complete (in registers)
+          if (kt + NS < nk) {                  // refill the stage just drained with tile kt+NS
+#pragma unroll
+            for (int q = 0; q < NP; ++q) piece(cur, q, c_rx, c_xv, c_vm, c_wv);
+            advance(c_W);
+          }
+        }
+        cur = nxt;
+      }
+    } else {
     uint4 wA[2], xA[2], wB[2], xB[2];
     dma_wait_all();        // (the previous tile's epilogue stores share the counter and retire out of order with loads: wait for all)
     __syncthreads();
@@ -623,6 +754,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
       mma(wA, xA);
       mma(wB, xB);
     }
+    }
     // ---- hand-over: every wave has its last fragments in registers -> both LDS stages are free for the next tile ----
     const int e_si = c_si, e_mbase = c_mbase, e_nbase = c_nbase;
     const int next = tile + (int)gridDim.x;
@@ -641,7 +773,66 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
       }
     }
     // ---- epilogue of the finished tile (its stores overlap the fetch just issued) ----
-    {
+    if constexpr (X3) {
+      // 4-byte output elements: split rows (two 8-byte stores per 4-channel group, ReLU-mask residual = sign of the split
+      // activation's hi half) or plain fp32 rows (optionally + plain fp32 residual)
+      const SegD sg = p.seg[e_si];
+      const int HoWo = sg.Ho * sg.Wo;
+      const int nw0 = e_nbase + wn * 64;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int m = e_mbase + wm * 64 + b * 32 + l31;
+        if (m >= sg.M) continue;
+        const int bimg = m / HoWo, pix = m - bimg * HoWo;
+        const long long orow = sg.out_off + (long long)bimg * sg.out_bs + (long long)pix * p.ldy;
+        const float rs = p.rowscale ? p.rowscale[bimg] : 1.0f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int n0 = nw0 + a * 32 + gq * 8 + lh * 4;
+            if (n0 >= p.Cout) continue;
+            f32x4 v = f32x4{acc[a][b][4 * gq], acc[a][b][4 * gq + 1], acc[a][b][4 * gq + 2], acc[a][b][4 * gq + 3]};
+            const bool full = p.vec_ok && (n0 + 3 < p.Cout);
+            if (full) {
+              if (p.scale) v = v * *(const f32x4*)(p.scale + n0);
+              if (p.shift) v = v + *(const f32x4*)(p.shift + n0);
+            } else {
+              for (int r = 0; r < 4; ++r)
+                if (n0 + r < p.Cout) { if (p.scale) v[r] *= p.scale[n0 + r]; if (p.shift) v[r] += p.shift[n0 + r]; }
+            }
+            if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+            else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+            else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+            if (p.rowscale) v *= rs;
+            if (p.out_split) {
+              const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
+              if (p.res_mode == EFFDET_RES_RELU_MASK) {
+                const uint2 rh = *(const uint2*)((const char*)p.res + orow * 4 + goff);
+                const unsigned rv[4] = {rh.x & 0xffffu, rh.x >> 16, rh.y & 0xffffu, rh.y >> 16};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = ((rv[r] & 0x7fffu) != 0u && !(rv[r] & 0x8000u)) ? v[r] : 0.f;
+              }
+              uint2 hi, lo;
+              hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+              lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+              lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+              char* dst = (char*)p.y + orow * 4 + goff;
+              *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
+            } else {
+              const long long o = orow + n0;
+              if (p.res_mode == EFFDET_RES_ADD) {
+                if (full) v += *(const f32x4*)((const float*)p.res + o);
+                else
+                  for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) v[r] += ((const float*)p.res)[o + r];
+              }
+              if (full) *(f32x4*)((float*)p.y + o) = v;
+              else
+                for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) ((float*)p.y)[o + r] = v[r];
+            }
+          }
+      }
+    } else {
       const SegD sg = p.seg[e_si];
       const int HoWo = sg.Ho * sg.Wo;
       long long orow[2]; float rsv[2]; bool mok[2];
@@ -768,18 +959,22 @@ static int retile(ConvK& k, int bm) {
   return tiles;
 }
 
-template <int WM, int WN, int NS>
+template <int WM, int WN, int NS, int X3 = 0>
 int launch_pers(ConvK& k, hipStream_t st) {
   constexpr int TM = 64 * WM, TN = 64 * WN;
   retile(k, TM);
   k.ntiles = (k.Cout + TN - 1) / TN;
   const size_t lds = (size_t)NS * (TM + TN) * 128;
-  EFFDET_SET_MAX_LDS((conv_igemm_pers_kernel<WM, WN, NS>), lds);
+  if (X3) {           // input side into the bf16 VIEW of the split layout (see the kernel): element = 2 bytes, twice the counts
+    k.ldx *= 2;       // (cpt / Kc count 16-byte chunks: the same in both views)
+    for (int s = 0; s < k.nseg; ++s) { k.seg[s].in_off *= 2; k.seg[s].in_bs *= 2; }
+  }
+  EFFDET_SET_MAX_LDS((conv_igemm_pers_kernel<WM, WN, NS, X3>), lds);
   static int ncu = 0;                                   // CUs of the current device (all devices of a node are alike)
   if (ncu == 0) { int dev = 0; hipDeviceProp_t pr; ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
   const int total = k.mtiles * k.ntiles;
   const int grid = total < ncu ? total : ncu;          // one workgroup per CU (the LDS footprint allows no second one)
-  hipLaunchKernelGGL((conv_igemm_pers_kernel<WM, WN, NS>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
+  hipLaunchKernelGGL((conv_igemm_pers_kernel<WM, WN, NS, X3>), dim3(grid), dim3(WM * WN * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -787,19 +982,19 @@ int launch_pers(ConvK& k, hipStream_t st) {
 // Tuning knobs (effdet_tuning_set; A/B experiments and tests): which persistent big-tile shape serves an eligible conv
 // (0 = off | 1 = 442 | 242 | 243 | 423; env EFFDET_IGEMM_BIG overrides the built-in default), from how many output pixels
 // per launch, and its K walk.  Speed only: every setting computes the same values.
-static int g_tuning[EFFDET_TUNE_COUNT] = {-1, 16384, 0, 1};
+static int g_tuning[EFFDET_TUNE_COUNT] = {-1, 16384, -1, 1};
 static int big_variant() {
   if (g_tuning[EFFDET_TUNE_IGEMM_BIG] < 0)
     g_tuning[EFFDET_TUNE_IGEMM_BIG] = getenv("EFFDET_IGEMM_BIG") ? atoi(getenv("EFFDET_IGEMM_BIG")) : EFFDET_IGEMM_BIG_DEFAULT;
   return g_tuning[EFFDET_TUNE_IGEMM_BIG];
 }
 
-template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2>
+template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2, int M32 = 0>
 int launch(const ConvK& k, hipStream_t st) {
   const size_t lds = (size_t)NS * (BM + BN) * 8 * sizeof(uint4);                    // NS-stage operand tiles
   const int grid = k.mtiles * k.ntiles;
-  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS>), lds);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
+  if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS, M32>), lds);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS, M32>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -915,7 +1110,20 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   }
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
-  if (p->dtype == EFFDET_F32_SPLIT) return 8 + (bt > 1 ? 1 : bt);                        // (block tiles of 128 / 64 output channels)
+  if (p->dtype == EFFDET_F32_SPLIT) {
+    // persistent 256 x 256 / 32x32x16 form for the long-K head convs (tuning knob EFFDET_TUNE_SPLIT_PERS / env EFFDET_SPLIT_PERS)
+    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] < 0) g_tuning[EFFDET_TUNE_SPLIT_PERS] = getenv("EFFDET_SPLIT_PERS") ? atoi(getenv("EFFDET_SPLIT_PERS")) : 0;
+    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
+      long long mtot = 0;
+      bool fits = true;
+      for (int s = 0; s < p->nseg; ++s) {
+        mtot += k.seg[s].M;
+        if ((long long)k.seg[s].x_bytes + 2LL * ((long long)p->KH * p->seg[s].W + p->KW) * p->ldx * 4 >= 0x70000000LL) fits = false;
+      }
+      if (fits && mtot >= g_tuning[EFFDET_TUNE_IGEMM_BIG_MIN_M] && (long long)k.Kc * 4 >= 1152) return 10000 + 442;
+    }
+    return 8 + (bt > 1 ? 1 : bt);                        // (block tiles of 128 / 64 output channels)
+  }
   return bt;
 }
 
@@ -936,11 +1144,14 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     case 10 + 423: return launch_pers<4, 2, 3>(k, st);
     case 10 + 4220: return launch_pers<4, 2, 2>(k, st);
     case 10 + 4230: return launch_pers<4, 2, 3>(k, st);
+    case 10000 + 442: return launch_pers<4, 4, 2, 1>(k, st);
     default: break;
   }
   if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
   if (id == 8 || id == 9) {
     k.ntiles = (k.Cout + (id == 8 ? 127 : 63)) / (id == 8 ? 128 : 64);
+    static const int m32 = getenv("EFFDET_SPLIT_M32") ? atoi(getenv("EFFDET_SPLIT_M32")) : 0;      // A/B switch: 32x32x16 tiles (measured 342-360 TFLOP/s) vs 16x16x32 (370-390)
+    if (m32) return id == 8 ? launch<float, 128, 2, 8, 2, 2, 1>(k, st) : launch<float, 64, 1, 4, 2, 2, 1>(k, st);
     return id == 8 ? launch<float, 128, 2, 8, 2>(k, st) : launch<float, 64, 1, 4, 2>(k, st);
   }
   return p->dtype == EFFDET_BF16 ? dispatch<bf16_t>(k, st) : dispatch<float>(k, st);

@@ -700,10 +700,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
   const int tap = jok ? jq / p.cpt : 0, cc = jok ? jq - tap * p.cpt : 0;
   const int kh = tap / p.KW, kw = tap - kh * p.KW;
   const int dkh = kh - p.pad_t, dkw = kw - p.pad_l;
-  const int off_x = ((dkh * sg.W + dkw + r) * p.ldx + cc * 4) * 4;
+  // (stride s: output pixel (ho, wo) reads input pixel (ho*s + dkh, wo*s + dkw); s = 2 is the stem, X3 form only -- see f32dma_eligible)
+  const int off_x = (((dkh + dho * p.stride) * sg.W + dkw + dwo * p.stride) * p.ldx + cc * 4) * 4;
   const unsigned long long mx_inv = __ballot(!jok);
-  const unsigned long long mx_up = __ballot(dkh < 0 && dho == 0), mx_dn = __ballot(dkh > 0 && dho == RP - 1);
-  const unsigned long long mx_lf = __ballot(dkw < 0 && dwo == 0), mx_rt = __ballot(dkw > 0 && dwo == Wr - 1);
+  const unsigned long long mx_up = __ballot(dkh < 0 && dho == 0), mx_dn = __ballot((sg.Ho - 1) * p.stride + dkh >= sg.H && dho == RP - 1);
+  const unsigned long long mx_lf = __ballot(dkw < 0 && dwo == 0), mx_rt = __ballot((sg.Wo - 1) * p.stride + dkw >= sg.W && dwo == Wr - 1);
   const u32x4_t srd_x = make_srd_raw((const float*)p.x + sg.in_off, sg.x_bytes);
   const u32x4_t srd_z = make_srd_raw((const float*)p.dz + sg.out_off, sg.dz_bytes);
   const unsigned x_bs = (unsigned)(sg.in_bs * 4), x_ld = (unsigned)(p.ldx * 4), z_bs = (unsigned)(sg.out_bs * 4), z_ld = (unsigned)(p.lddz * 4);
@@ -721,8 +722,8 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
       const unsigned long long past = (cm >= m_end) ? ~0ull : 0ull;
       const unsigned long long c_up = (cho == 0) ? ~0ull : 0ull, c_dn = (cho == sg.Ho - RP) ? ~0ull : 0ull;
       const unsigned long long c_lf = (cwo == 0) ? ~0ull : 0ull, c_rt = (cwo == sg.Wo - Wr) ? ~0ull : 0ull;
-      const unsigned pix = (unsigned)(cho * sg.Wo + cwo);
-      const unsigned zb = (unsigned)cb * z_bs + pix * z_ld, xb = (unsigned)cb * x_bs + pix * x_ld;
+      const unsigned pix = (unsigned)(cho * sg.Wo + cwo), pix_in = (unsigned)((cho * sg.W + cwo) * p.stride);
+      const unsigned zb = (unsigned)cb * z_bs + pix * z_ld, xb = (unsigned)cb * x_bs + pix_in * x_ld;
       const unsigned dst = dst0 + (unsigned)buf * BUFB + (unsigned)(i * NW) * 1024u;
       dma16_async(srd_z, dst, oob_if(mz_inv | past, zb + (unsigned)off_z));
       const unsigned long long inv = mx_inv | past | (c_up & mx_up) | (c_dn & mx_dn) | (c_lf & mx_lf) | (c_rt & mx_rt);
@@ -1038,11 +1039,15 @@ bool tr_eligible(const effdet_wgrad_t* p, const WgradK& k, int s) {
   return g.Wo % 8 == 0 || (8 % g.Wo == 0 && (g.Ho * g.Wo) % 8 == 0);
 }
 // Does pyramid level s qualify for the fp32 DMA kernel?
-bool f32dma_eligible(const effdet_wgrad_t* p, const WgradK& k, int s) {
+bool f32dma_eligible(const effdet_wgrad_t* p, const WgradK& k, int s, bool x3 = false) {
   if (p->dtype != EFFDET_F32) return false;
   const effdet_seg_t& g = p->seg[s];
-  if (p->stride != 1 || g.Ho != g.H || g.Wo != g.W) return false;
-  if (p->KH > 3 || p->KW > 3 || p->pad_t > 1 || p->pad_l > 1 || p->KH - 1 - p->pad_t > 1 || p->KW - 1 - p->pad_l > 1) return false;
+  // stride 2 (the stem: 3x3, pad (0, 1), 4 channels) only in the bf16x3 form: 97 % of a 128 x 128 tile is padding there, which
+  // costs the 16x16x32 pipe 0.08 ms but the exact-fp32 pipe (8 passes per 4 pixels) 0.9 ms -- more than the register-transpose kernel
+  if (p->stride == 2) {
+    if (!x3 || p->pad_t != 0 || p->pad_l != 0 || p->KH != 3 || p->KW != 3 || g.Ho != (g.H + 1) / 2 || g.Wo != (g.W + 1) / 2 || (g.H & 1) || (g.W & 1)) return false;
+  } else if (p->stride != 1 || g.Ho != g.H || g.Wo != g.W) return false;
+  if (p->KH > 3 || p->KW > 3 || p->pad_t > 1 || p->pad_l > 1 || (p->stride == 1 && (p->KH - 1 - p->pad_t > 1 || p->KW - 1 - p->pad_l > 1))) return false;
   if (p->ldx % 4 || p->lddz % 4 || g.in_off % 4 || g.out_off % 4 || g.in_bstride % 4 || g.out_bstride % 4) return false;
   if (((p->Cout + 3) / 4 * 4) > p->lddz) return false;
   const long long M = (long long)p->B * g.Ho * g.Wo;
@@ -1114,7 +1119,7 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   int nf = 0, ns = 0, sf = 0, ss = 0;
   for (int s = 0; s < p->nseg; ++s) {
     const int cnt = (int)((k.seg[s].M + k.mchunk - 1) / k.mchunk);
-    if (tr_eligible(p, k, s) || (f32dma && f32dma_eligible(p, k, s))) {
+    if (tr_eligible(p, k, s) || (f32dma && f32dma_eligible(p, k, s, pn_x3))) {
       WSeg d = k.seg[s]; d.split_start = sf; sf += cnt;
       if (p->KH == 1 && p->KW == 1 && d.in_bs == (long long)d.H * d.W * p->ldx && d.out_bs == (long long)d.Ho * d.Wo * p->lddz) {
         d.H = d.Ho = 1; d.W = d.Wo = d.M;           // contiguous pointwise: one long image row, no wrap, no borders

@@ -83,15 +83,15 @@ def _mma_dtype_code(dtype, K=None, N=None):
 def _igemm_symbol(dtype, desc):
     """Kernel symbol the library will launch for this descriptor (profiling attribution only)."""
     kid = int(L.lib().effdet_conv2d_kernel(C.byref(desc)))
+    if kid >= 10000:
+        return 'conv_igemm_pers_kernel<split,bf16x3>'
     if kid >= 10:
         v = str(kid - 10)
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % (v[0], v[1], v[2])
-    if 4 <= kid < 8:
-        return 'conv_igemm_kernel<f32,%d,bf16x3>' % (128, 64, 32, 16)[kid - 4]
     if kid in (8, 9):
         return 'conv_igemm_kernel<split,%d,bf16x3>' % (128, 64)[kid - 8]
-    if kid >= 10000:
-        return 'conv_igemm_pers_kernel<split,bf16x3>'
+    if 4 <= kid < 8:
+        return 'conv_igemm_kernel<f32,%d,bf16x3>' % (128, 64, 32, 16)[kid - 4]
     return 'conv_igemm_kernel<%s,%d>' % ('bf16' if dtype == torch.bfloat16 else 'f32', (128, 64, 32, 16)[max(kid, 0)])
 
 

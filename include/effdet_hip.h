@@ -91,7 +91,8 @@ int effdet_conv2d_kernel(const effdet_conv_t* p);
  *                                 Cout >= 128 convs: 0 off | 1 = 442 (256x256 tile, 16 waves, 2 LDS stages) | 242 | 243 | 423
  *                                 (waves along pixels, waves along channels, LDS stages)
  *   EFFDET_TUNE_IGEMM_BIG_MIN_M : minimum output pixels per launch for that variant */
-enum { EFFDET_TUNE_IGEMM_BIG = 0, EFFDET_TUNE_IGEMM_BIG_MIN_M = 1, EFFDET_TUNE_RESERVED = 2,
+enum { EFFDET_TUNE_IGEMM_BIG = 0, EFFDET_TUNE_IGEMM_BIG_MIN_M = 1,
+       EFFDET_TUNE_SPLIT_PERS = 2 /* EFFDET_F32_SPLIT convs: 1 = persistent 256x256 32x32x16 form for Cout >= 192, long K */,
        EFFDET_TUNE_IGEMM_KORD = 3 /* K walk of the persistent variants: 0 tap-major, 1 channel-group-major */, EFFDET_TUNE_COUNT = 4 };
 int effdet_tuning_set(int key, int value);
 

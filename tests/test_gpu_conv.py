@@ -280,6 +280,8 @@ def test_wgrad_shapes(dtype):
     _run_wgrad(dtype, 2, 12, 12, 96, 24, 1, pad=(0, 0, 0, 0))
     _run_wgrad(dtype, 2, 12, 12, 16, 96, 1, pad=(0, 0, 0, 0))
     _run_wgrad(dtype, 1, 17, 17, 24, 32, 3, stride=2, pad=(0, 1, 0, 1))
+    _run_wgrad(dtype, 2, 32, 32, 4 if dtype == torch.float32 else 8, 32, 3, stride=2, pad=(0, 1, 0, 1))       # the stem's geometry (bf16x3: the DMA kernel's stride-2 form)
+    _run_wgrad(dtype, 3, 16, 24, 8, 40, 3, stride=2, pad=(0, 1, 0, 1))
     _run_wgrad(dtype, 4, 40, 40, 64, 64, 3)          # several K-splits
     _run_wgrad(dtype, 2, 1, 1, 64, 64, 3)
     # bf16: shapes that take the DMA + LDS-transpose-read kernel with 8-pixel pieces made of whole image rows

@@ -51,8 +51,25 @@ def test_to_split_roundtrip_and_precision():
     (3, 8, 16, 256, 64, 0, False, True, False),            # tower-0 data gradient back to the neck (64-wide tile, fp32 out)
     (1, 1, 1, 64, 256, 1, False, False, False),            # 1x1 map
     (2, 2, 128, 64, 128, 1, False, False, False),          # partial tiles, H != W
+    (3, 24, 24, 256, 256, 1, False, False, False),         # several 256-pixel tiles incl. a partial one (persistent form: tile walk)
+    (2, 20, 12, 128, 320, 0, True, False, True),           # partial channel tile (320 = 256 + 64), ReLU mask + row scale
 ])
-def test_conv_split_layout(cfg):
+@pytest.mark.parametrize('pers', [0, 1])
+def test_conv_split_layout(cfg, pers):
+    """pers = 1: eligible shapes (Cout >= 192, K >= 1152) through the persistent 256 x 256 / 32x32x16 form of the kernel."""
+    from efficientdet.pytorch_amd import ops, _lib as L
+    from efficientdet.pytorch_amd.ops import Map
+    B, H, W, Cin, Cout, act, res, out_f32, rowscale = cfg
+    if pers and not (Cout >= 192 and 9 * Cin >= 1152):
+        pytest.skip('shape not served by the persistent form')
+    old = (ops.tuning_set(L.TUNE_SPLIT_PERS, pers), ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, 0))
+    try:
+        _conv_split_case(cfg, pers)
+    finally:
+        ops.tuning_set(L.TUNE_SPLIT_PERS, old[0]); ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, old[1])
+
+
+def _conv_split_case(cfg, pers):
     from efficientdet.pytorch_amd import ops
     from efficientdet.pytorch_amd.ops import Map
     B, H, W, Cin, Cout, act, res, out_f32, rowscale = cfg
@@ -78,10 +95,18 @@ def test_conv_split_layout(cfg):
         wp = ops.pack_weight(w.cuda(), torch.float32, x3=True)
         ym = Map.new(B, H, W, Cout, torch.float32, 'cuda')
         rm = Map.of(ops.to_split(_nhwc(r))) if res else None
-        ops.conv2d(xm, wp, ym, Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1, shift=shift.cuda(), act=act, res=rm,
-                   res_mode=ops.RES_RELU_MASK if res else ops.RES_NONE, rowscale=rs.cuda() if rowscale else None,
-                   out_f32=out_f32, split=True)
-        torch.cuda.synchronize()
+        kw = dict(Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1, shift=shift.cuda(), act=act, res=rm,
+                  res_mode=ops.RES_RELU_MASK if res else ops.RES_NONE, rowscale=rs.cuda() if rowscale else None,
+                  out_f32=out_f32, split=True)
+        if pers:                       # the launch really is the persistent kernel
+            ops.PROFILE = ops.LaunchProfile()
+        try:
+            ops.conv2d(xm, wp, ym, **kw)
+            torch.cuda.synchronize()
+            if pers:
+                assert ops.PROFILE.records[0][0] == 'conv_igemm_pers_kernel<split,bf16x3>', ops.PROFILE.records[0][0]
+        finally:
+            ops.PROFILE = None
     finally:
         ops.set_f32_arith('f32')
     got = ym.tensor().cpu() if out_f32 else from_split(ym.tensor())
