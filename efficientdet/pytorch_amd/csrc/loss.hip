@@ -158,11 +158,16 @@ __global__ __launch_bounds__(256) void loss_cls_kernel(const LossK p) {
 // one workgroup: wave w adds the partials of images w, w + 16, ... (lane-strided, then the fixed shuffle tree), thread 0 the images
 __global__ __launch_bounds__(1024) void loss_final_kernel(const LossK p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // fixed summation pattern (lane-strided with four chains in flight -- the loop is pure L2 latency -- then the shuffle tree)
+  auto lane_sum = [&](const float* q, int n) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = lane;
+    for (; i + 192 < n; i += 256) { s0 += q[i]; s1 += q[i + 64]; s2 += q[i + 128]; s3 += q[i + 192]; }
+    for (; i < n; i += 64) s0 += q[i];
+    return wave_sum((s0 + s1) + (s2 + s3));
+  };
   for (int b = wave; b < p.B; b += 16) {
-    float c = 0.f, r = 0.f;
-    for (int i = lane; i < p.ncb; i += 64) c += p.part_cls[(long long)b * p.ncb + i];
-    for (int i = lane; i < p.na; i += 64) r += p.part_reg[(long long)b * p.na + i];
-    c = wave_sum(c); r = wave_sum(r);
+    const float c = lane_sum(p.part_cls + (long long)b * p.ncb, p.ncb), r = lane_sum(p.part_reg + (long long)b * p.na, p.na);
     if (lane == 0) { p.stat[b * SS + 0] = c; p.stat[b * SS + 1] = r; }
   }
   __syncthreads();
