@@ -396,7 +396,7 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     nbytes = ws.numel() * 4
     # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
     _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else
-           ('conv_wgrad_tr_kernel<4,split,bf16x3>' if split else
+           ('conv_wgrad_split_kernel' if split else
             ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>')), flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),

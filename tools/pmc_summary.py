@@ -39,8 +39,12 @@ def short(name):
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % m.groups()
     m = re.search(r'conv_igemm_kernel<(unsigned short|float), (\d+)(?:, \d+, \d+, (\d+))?', name)
     if m:
+        if m.group(3) == '2':
+            return 'conv_igemm_kernel<split,%s,bf16x3>' % m.group(2)
         return 'conv_igemm_kernel<%s,%s%s>' % ('bf16' if m.group(1) == 'unsigned short' else 'f32', m.group(2),
                                                 ',bf16x3' if m.group(3) == '1' else '')
+    if 'conv_wgrad_split_kernel' in name:
+        return 'conv_wgrad_split_kernel'
     m = re.search(r'conv_wgrad_f32dma_kernel<(\d+), (\d+)>', name)
     if m:
         return 'conv_wgrad_f32dma_kernel<%s%s>' % (m.group(1), ',bf16x3' if m.group(2) == '1' else '')
@@ -89,7 +93,7 @@ def main():
                      'mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)' % dtype,
            'kernels': kernels}
     json.dump(res, open(out_path, 'w'), indent=1)
-    for k in ('conv_igemm_kernel<bf16,128>', 'conv_igemm_kernel<f32,128>', 'conv_wgrad_tr_kernel<8>'):
+    for k in ('conv_igemm_kernel<bf16,128>', 'conv_igemm_kernel<f32,128>', 'conv_wgrad_tr_kernel<8>', 'conv_igemm_kernel<split,128,bf16x3>', 'conv_wgrad_split_kernel'):
         if k in kernels:
             print(k, json.dumps(kernels[k]))
 
