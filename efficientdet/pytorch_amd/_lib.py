@@ -14,7 +14,7 @@ MAX_SEG = 5
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
-TUNE_IGEMM_BIG, TUNE_IGEMM_BIG_MIN_M, TUNE_SPLIT_PERS = 0, 1, 2
+TUNE_IGEMM_BIG, TUNE_IGEMM_BIG_MIN_M, TUNE_SPLIT_PERS, TUNE_IGEMM_KORD, TUNE_SPLIT_KORD = 0, 1, 2, 3, 4
 
 _ERR = {-1: 'EFFDET_EINVAL', -2: 'EFFDET_ELAUNCH', -3: 'EFFDET_EUNSUPPORTED'}
 

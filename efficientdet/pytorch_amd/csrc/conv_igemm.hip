@@ -161,6 +161,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   int kq = kc, tap = 0, cc = kc;
   while (cc >= p.cpt) { cc -= p.cpt; ++tap; }
   int kh = tap / p.KW, kw = tap - kh * p.KW;
+  int tapi = tap;                // (tap index of the channel-group-major walk, SPLIT == 2 only)
   unsigned xcur[XROWS];          // current byte offset per row, or EFFDET_OOB when the tap falls outside the image
   auto retap = [&]() {
 #pragma unroll
@@ -183,6 +184,21 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
         dma16_async(rw, ws_a + (unsigned)(buf * WLD + (wrow0 + RSTEP * j) * 8) * 16u, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     }
     // advance the cursor by one K-step (8 chunks)
+    if constexpr (SPLIT == 2) {
+      if (p.kord == 1) {
+        // channel-group-major walk (cpt % 8 == 0): the 9 taps of one 32-channel group back to back, then the next group.  With
+        // 4-byte elements the tap-major walk re-reads a pixel's 128-byte line 8 K-steps (kw) / 24 K-steps (kh) apart -- the lines
+        // the ~64 tiles of an XCD touch in between (~8 MB) do not fit its 4 MB L2 and the re-reads go out to the fabric (PMC:
+        // 1.38 GB fetched per head launch for 0.18-0.54 GB of input); here the re-use distance is 1-3 K-steps
+        const int taps = p.Kc / p.cpt;
+        ++tapi;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+        if (tapi == taps) { tapi = 0; kh = 0; kw = 0; cc += 8; }
+        kq = (cc < p.cpt) ? tapi * p.cpt + cc : p.Kc;          // past the last group: out of range
+        retap();
+        return;
+      }
+    }
     kq += 8; cc += 8;
     if (cc < p.cpt) {
 #pragma unroll
@@ -982,7 +998,7 @@ int launch_pers(ConvK& k, hipStream_t st) {
 // Tuning knobs (effdet_tuning_set; A/B experiments and tests): which persistent big-tile shape serves an eligible conv
 // (0 = off | 1 = 442 | 242 | 243 | 423; env EFFDET_IGEMM_BIG overrides the built-in default), from how many output pixels
 // per launch, and its K walk.  Speed only: every setting computes the same values.
-static int g_tuning[EFFDET_TUNE_COUNT] = {-1, 16384, -1, 1};
+static int g_tuning[EFFDET_TUNE_COUNT] = {-1, 16384, -1, 1, -1};
 static int big_variant() {
   if (g_tuning[EFFDET_TUNE_IGEMM_BIG] < 0)
     g_tuning[EFFDET_TUNE_IGEMM_BIG] = getenv("EFFDET_IGEMM_BIG") ? atoi(getenv("EFFDET_IGEMM_BIG")) : EFFDET_IGEMM_BIG_DEFAULT;
@@ -1059,6 +1075,15 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt;
   k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32; k.kord = g_tuning[EFFDET_TUNE_IGEMM_KORD];
   k.out_split = (splitfmt && !p->out_f32) ? 1 : 0;
+  if (splitfmt) {
+    // K walk of the split-layout kernels (tuning knob EFFDET_TUNE_SPLIT_KORD / env EFFDET_SPLIT_KORD): 0 tap-major, 1 channel-
+    // group-major, 2 (default) = by measurement: group-major for the 64-channel tile only (256 -> 64 data gradient back to the
+    // neck: 214 -> 261 TFLOP/s -- one n-tile per pixel tile, so nothing else re-uses the staged lines), tap-major for the
+    // 128-channel tile (378 vs 380: the two n-tiles of an XCD's neighbouring workgroups already share the fetches)
+    if (g_tuning[EFFDET_TUNE_SPLIT_KORD] < 0) g_tuning[EFFDET_TUNE_SPLIT_KORD] = getenv("EFFDET_SPLIT_KORD") ? atoi(getenv("EFFDET_SPLIT_KORD")) : 2;
+    const int kv = g_tuning[EFFDET_TUNE_SPLIT_KORD];
+    k.kord = ((kv == 1 || (kv == 2 && p->Cout <= 64)) && k.cpt % 8 == 0) ? 1 : 0;
+  }
   k.nseg = p->nseg;
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);

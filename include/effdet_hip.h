@@ -93,7 +93,8 @@ int effdet_conv2d_kernel(const effdet_conv_t* p);
  *   EFFDET_TUNE_IGEMM_BIG_MIN_M : minimum output pixels per launch for that variant */
 enum { EFFDET_TUNE_IGEMM_BIG = 0, EFFDET_TUNE_IGEMM_BIG_MIN_M = 1,
        EFFDET_TUNE_SPLIT_PERS = 2 /* EFFDET_F32_SPLIT convs: 1 = persistent 256x256 32x32x16 form for Cout >= 192, long K */,
-       EFFDET_TUNE_IGEMM_KORD = 3 /* K walk of the persistent variants: 0 tap-major, 1 channel-group-major */, EFFDET_TUNE_COUNT = 4 };
+       EFFDET_TUNE_IGEMM_KORD = 3 /* K walk of the persistent variants: 0 tap-major, 1 channel-group-major */,
+       EFFDET_TUNE_SPLIT_KORD = 4 /* K walk of the EFFDET_F32_SPLIT convs: 0 tap-major, 1 channel-group-major */, EFFDET_TUNE_COUNT = 5 };
 int effdet_tuning_set(int key, int value);
 
 /* Weight gradient of the same convolution:  dw[n][tap][c] += sum_m dz[m][n] * x[pix(m)+tap][c]

@@ -62,11 +62,13 @@ def test_conv_split_layout(cfg, pers):
     B, H, W, Cin, Cout, act, res, out_f32, rowscale = cfg
     if pers and not (Cout >= 192 and 9 * Cin >= 1152):
         pytest.skip('shape not served by the persistent form')
-    old = (ops.tuning_set(L.TUNE_SPLIT_PERS, pers), ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, 0))
+    old = (ops.tuning_set(L.TUNE_SPLIT_PERS, pers), ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, 0), ops.tuning_set(L.TUNE_SPLIT_KORD, 0))
     try:
-        _conv_split_case(cfg, pers)
+        for kord in (0, 1):            # K walk: tap-major / channel-group-major
+            ops.tuning_set(L.TUNE_SPLIT_KORD, kord)
+            _conv_split_case(cfg, pers)
     finally:
-        ops.tuning_set(L.TUNE_SPLIT_PERS, old[0]); ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, old[1])
+        ops.tuning_set(L.TUNE_SPLIT_PERS, old[0]); ops.tuning_set(L.TUNE_IGEMM_BIG_MIN_M, old[1]); ops.tuning_set(L.TUNE_SPLIT_KORD, old[2])
 
 
 def _conv_split_case(cfg, pers):
