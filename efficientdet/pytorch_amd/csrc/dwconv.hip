@@ -24,6 +24,7 @@ struct DwK {
   int ppt;        // pixels per thread (direct kernels) / tiles per workgroup (LDS kernels)
   int nbuf;       // LDS tile buffers of the forward / data-gradient kernels: 2 = prefetch the next tile under the taps
   int nslab;      // channel slabs (LDS kernels, 1-D grid of tile groups x slabs); 0 = legacy 2-D grid (x = groups, y = slabs)
+  int in_act;     // forward / weight gradient: x holds the PRE-activation of the producing expand conv; Swish is applied to the staged tile
 };
 
 // (tile group, slab) of this workgroup.  A pixel row of C channels is cut into slabs of 64 / 128 B, and unless C * 2 B is
@@ -120,6 +121,20 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     const int cur = (p.nbuf == 2) ? ((tile - t0) & 1) : 0;
     __syncthreads();                                    // tile `tile` is in LDS for every wave; the other buffer is free
     if (p.nbuf == 2 && tile + 1 < t1) stage(tile + 1, cur ^ 1);
+    if (p.in_act) {
+      // z-only storage of the expand conv (training): the staged tile holds pre-activations -- Swish them ONCE, in place (the
+      // zero padding stays zero: swish(0) = 0), instead of the conv writing a second, activated copy (-1 of its 2 output streams;
+      // these kernels are HBM-bound with ~100 VALU slots per output to spare)
+      uint4* xw = xt + cur * TILE;
+      for (int i = tid; i < TILE; i += 256) {
+        float v[CE];
+        Chunk<T>::unpack(xw[i], v);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = swishf_(v[e]);
+        xw[i] = Chunk<T>::pack(v);
+      }
+      __syncthreads();
+    }
     const uint4* xb = xt + cur * TILE;
     float acc[NOUT][CE];
 #pragma unroll
@@ -373,7 +388,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const DwK p) {
       for (int kw = 0; kw < K; ++kw) {
         const int wi = wi0 + kw;
         const bool ok = hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-        g[kh * K + kw] += d * srd_load4<T>(rx, ok ? img_off + (unsigned)((hi * p.W + wi) * p.C) * ES : EFFDET_OOB);
+        f32x4 xv = srd_load4<T>(rx, ok ? img_off + (unsigned)((hi * p.W + wi) * p.C) * ES : EFFDET_OOB);
+        if (p.in_act) { xv[0] = swishf_(xv[0]); xv[1] = swishf_(xv[1]); xv[2] = swishf_(xv[2]); xv[3] = swishf_(xv[3]); }
+        g[kh * K + kw] += d * xv;
       }
     }
   }
@@ -491,6 +508,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
       for (int e = 0; e < CPT; ++e) ds[e] += d[o][e];
     }
     __syncthreads();                                      // (hipcc drains the DMA ahead of the barrier)
+    if (p.in_act) {                                       // x = pre-activation of the expand conv: Swish the staged tile in place
+      for (int i = tid; i < NPIECE * 64; i += 256) {
+        float v[CE];
+        Chunk<T>::unpack(xt[i], v);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = swishf_(v[e]);
+        xt[i] = Chunk<T>::pack(v);
+      }
+      __syncthreads();
+    }
     if (S == 1) {
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
@@ -705,13 +732,13 @@ extern "C" int effdet_dwconv_fwd_pool_groups(int dtype, int B, int C, int stride
 
 extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* scale, const float* shift, void* y,
                                  void* z, float* pool, int dtype, int B, int H, int W, int C, int k, int stride,
-                                 int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
-  if (!x || !w || (!y && !z)) return EFFDET_EINVAL;
+                                 int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream) {
+  if (!x || !w || (!y && !z) || (in_act != EFFDET_ACT_NONE && in_act != EFFDET_ACT_SWISH)) return EFFDET_EINVAL;
   DwK a{}; dim3 grid;
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, ce, Ho * Wo, grid);
   if (rc) return rc;
-  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y; a.z = z; a.pool = pool;
+  a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.y = y; a.z = z; a.pool = pool; a.in_act = in_act;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_fwd_lds, dtype, k, stride, a, st);
@@ -775,13 +802,13 @@ extern "C" long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H
 
 extern "C" int effdet_dwconv_wgrad(const void* x, const void* dz, float* g, float* dsum, void* workspace,
                                    long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
-                                   int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
-  if (!x || !dz || !g || !workspace) return EFFDET_EINVAL;
+                                   int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream) {
+  if (!x || !dz || !g || !workspace || (in_act != EFFDET_ACT_NONE && in_act != EFFDET_ACT_SWISH)) return EFFDET_EINVAL;
   DwK a{}; dim3 grid;
   int rc = wgrad_plan(a, grid, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo);
   if (rc) return rc;
   if (workspace_bytes < (long long)grid.x * (k * k + 1) * C * (long long)sizeof(float)) return EFFDET_EINVAL;
-  a.x = x; a.aux = dz; a.y = workspace;
+  a.x = x; a.aux = dz; a.y = workspace; a.in_act = in_act;
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if ((long long)B * Ho * Wo * C * (dtype == EFFDET_F32 ? 4 : 2) >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;

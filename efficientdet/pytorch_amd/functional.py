@@ -18,6 +18,7 @@ from .config import BN_EPS, conv_out
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE, RES_RELU_MASK, Map
 
 DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: also store the depthwise Swish output in training
+EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 
 
 def chunk_elems(dtype):
@@ -85,12 +86,21 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     dev = x.t.device
     B, H, W = x.B, x.H, x.W
     sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale}
+    dw_in_act = ACT_NONE
     if blk.expand != 1:
         s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
-        xe = Map.new(B, H, W, blk.cexp, dtype, dev)
-        ze = Map.new(B, H, W, blk.cexp, dtype, dev) if train else None
-        ops.conv2d(x, ops.pack_weight(P['expand.weight'], dtype), xe, Cin=blk.cin, Cout=blk.cexp, KH=1, KW=1,
-                   scale=s0, shift=t0, act=ACT_SWISH, zs=ze)
+        if train and EXPAND_Z_ONLY:
+            # training stores ONE tensor for the expand conv, its pre-activation: the depthwise forward / weight-gradient kernels
+            # Swish their staged tiles (the two streams y_e, z_e were 35 % of the backbone's forward writes)
+            ze = Map.new(B, H, W, blk.cexp, dtype, dev)
+            ops.conv2d(x, ops.pack_weight(P['expand.weight'], dtype), ze, Cin=blk.cin, Cout=blk.cexp, KH=1, KW=1,
+                       scale=s0, shift=t0, act=ACT_NONE)
+            xe, dw_in_act = ze, ACT_SWISH
+        else:
+            xe = Map.new(B, H, W, blk.cexp, dtype, dev)
+            ze = Map.new(B, H, W, blk.cexp, dtype, dev) if train else None
+            ops.conv2d(x, ops.pack_weight(P['expand.weight'], dtype), xe, Cin=blk.cin, Cout=blk.cexp, KH=1, KW=1,
+                       scale=s0, shift=t0, act=ACT_SWISH, zs=ze)
         sv.update(s0=s0, i0=i0, ze=ze)
     else:
         xe = x
@@ -101,7 +111,7 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     # the gate multiply and the backward of the gate recompute Swish from it
     z_only = train and not DW_SAVE_Y
     xd, zd, pool_part = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=True,
-                                       save_y=not z_only)
+                                       save_y=not z_only, in_act=dw_in_act)
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
     gate, mid, pool = ops.se_gate_fwd(pool_part, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
@@ -113,7 +123,7 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
                res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
     if train:
         sv.update(xe=xe, s1=s1, i1=i1, wk=wk, xd=xd, zd=zd, pool=pool, gate=gate, mid=mid, xs=xs, s2=s2, i2=i2,
-                  inv_hw=inv_hw)
+                  inv_hw=inv_hw, dw_in_act=dw_in_act)
     return y, sv
 
 
@@ -141,7 +151,7 @@ def mbconv_bwd(sv, dy):
     g['se_expand.weight'], g['se_expand.bias'] = dw2.view(Ce, Cs, 1, 1), db2
     dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
     # ---- depthwise ----
-    gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0])
+    gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0], in_act=sv['dw_in_act'])
     g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,
                                                                              P['bn1.running_mean'], sv['i1'])
     dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else None, H, W, blk.k, blk.stride,

@@ -537,9 +537,10 @@ def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
     return dw, dgb[0], dgb[1]
 
 
-def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=False, save_y=True):
+def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=False, pool=False, save_y=True, in_act=ACT_NONE):
     """-> (y, z, pool_part); save_y=False (needs save_z) stores the pre-activation only: consumers recompute Swish (act=ACT_SWISH).
-    pool=True: pool_part [B][G][C] fp32 = per-(image, tile group) partial sums of the Swish output for se_gate_fwd."""
+    pool=True: pool_part [B][G][C] fp32 = per-(image, tile group) partial sums of the Swish output for se_gate_fwd.
+    in_act=ACT_SWISH: x is the pre-activation of the expand conv (z-only storage); Swish is applied to the staged tiles."""
     assert save_y or save_z
     if pool:
         G = int(L.lib().effdet_dwconv_fwd_pool_groups(L.dtype_code(x.dtype), x.B, x.C, stride, Ho, Wo))
@@ -553,7 +554,7 @@ def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=F
     nbytes = x.t.element_size() * x.B * x.C * (x.H * x.W + Ho * Wo * (int(save_y) + int(save_z)))
     _timed('dw_fwd_lds_kernel', nbytes, lambda: L.check(L.lib().effdet_dwconv_fwd(
         L.ptr(x.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(shift), L.ptr(y.t if y else None), L.ptr(z.t if z else None), L.ptr(pool),
-        L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_dwconv_fwd'),
+        L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, Ho, Wo, in_act, L.stream_ptr()), 'effdet_dwconv_fwd'),
         'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return y, z, pool
 
@@ -568,7 +569,7 @@ def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
     return dx
 
 
-def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
+def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l, in_act=ACT_NONE):
     g = torch.empty((k * k + 1, x.C), dtype=torch.float32, device=x.t.device)       # taps | dsum (overwritten by the slab reduction)
     geo = (L.dtype_code(x.dtype), x.B, x.H, x.W, x.C, k, stride, pad_t, pad_l, dz.H, dz.W)
     nbytes = int(L.lib().effdet_dwconv_wgrad_workspace_bytes(*geo))
@@ -577,7 +578,7 @@ def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=x.t.device)
     traffic = x.t.element_size() * x.B * x.C * (x.H * x.W + dz.H * dz.W)
     _timed('dw_wgrad_lds_kernel', traffic, lambda: L.check(L.lib().effdet_dwconv_wgrad(
-        L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws), C.c_longlong(nbytes), *geo, L.stream_ptr()),
+        L.ptr(x.tensor()), L.ptr(dz.tensor()), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws), C.c_longlong(nbytes), *geo, in_act, L.stream_ptr()),
         'effdet_dwconv_wgrad'), 'BYTES k%d s%d C%d %dx%d' % (k, stride, x.C, x.H, x.W))
     return g[:k * k], g[k * k]
 

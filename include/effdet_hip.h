@@ -187,11 +187,14 @@ int effdet_bn_param_grad(const float* wsum, const float* dsum, const float* mean
  * rows of an image in a fixed order, so the pooled sum -- and everything downstream -- is bitwise reproducible.
  * y (Swish output) and z (pre-activation, for backward) are each optional but not both NULL; with
  * y == NULL the pooled sum is that of Swish(stored z), i.e. exactly what the consumers recompute.
+ * in_act = EFFDET_ACT_SWISH (forward and weight gradient): x holds the PRE-activation of the producing expand conv (training
+ * stores that tensor once: effdet_conv2d with act = NONE) and Swish is applied to the staged input tile; EFFDET_ACT_NONE: x is
+ * the activated tensor.
  * ------------------------------------------------------------------------------------------- */
 int effdet_dwconv_fwd_pool_groups(int dtype, int B, int C, int stride, int Ho, int Wo);
 int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, const float* shift,
                       void* y, void* z, float* pool, int dtype, int B, int H, int W, int C, int k,
-                      int stride, int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
+                      int stride, int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream);
 /* data gradient: dx[b,h,w,c] = sum_taps dz[b,ho,wo,c] * w[tap][c] * scale[c];  optionally
  * multiplied by swish'(zprev) (the expand conv's saved pre-activation) in the epilogue. */
 int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,
@@ -204,7 +207,7 @@ long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, in
                                               int pad_l, int Ho, int Wo);
 int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, void* workspace,
                         long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
-                        int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
+                        int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream);
 /* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
  * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);

@@ -71,6 +71,18 @@ def test_dwconv_fwd_bwd(dtype, cfg):
     assert_close(dw.cpu(), w.grad, 5 * TOL[dtype], 'dw wgrad')
     assert_close(dsum.cpu(), dz.sum(dim=(0, 2, 3)), 5 * TOL[dtype], 'dw dsum')
     assert_close(wsum.cpu(), (w.detach() * (w.grad / scale.view(-1, 1, 1, 1))).sum(dim=(1, 2, 3)), 1e-2, 'dw wsum')
+    # z-only storage of the producing expand conv (training): handed the PRE-activation, forward and weight gradient Swish their
+    # staged tiles themselves == the same kernels on the activated tensor
+    pre = q(torch.randn(B, C, H, W, generator=g))
+    am, pm = nhwc(q(pre * torch.sigmoid(pre)), dtype), nhwc(pre, dtype)
+    _, za, pa = ops.dwconv_fwd(am, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=True, save_y=False)
+    _, zb, pb = ops.dwconv_fwd(pm, wk, scale.to(dev), shift.to(dev), k, s, plo, plo, Ho, Wo, save_z=True, pool=True, save_y=False,
+                               in_act=ops.ACT_SWISH)
+    assert_close_scale(nchw(zb), nchw(za), 2 * TOL[dtype], 'dw z from the pre-activation')
+    assert_close_scale(pb.sum(dim=1).cpu(), pa.sum(dim=1).cpu(), 2 * TOL[dtype], 'se pool from the pre-activation')
+    ga, da = ops.dwconv_wgrad(am, dzm, k, s, plo, plo)
+    gb, dbb = ops.dwconv_wgrad(pm, dzm, k, s, plo, plo, in_act=ops.ACT_SWISH)
+    assert_close_scale(gb.cpu(), ga.cpu(), 2 * TOL[dtype], 'dw wgrad from the pre-activation'); assert torch.equal(dbb, da)
     # fused swish'(zprev) epilogue
     zp = q(torch.randn(B, C, H, W, generator=g))
     dxm2 = ops.dwconv_dgrad(dzm, wk, scale.to(dev), nhwc(zp, dtype), H, W, k, s, plo, plo)
