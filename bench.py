@@ -52,7 +52,8 @@ def parse():
     ap.add_argument('--extra-steps', type=int, default=20, help='timed steps of each extra-mode train leg')
     ap.add_argument('--extra-warmup', type=int, default=3)
     ap.add_argument('--ddp-graph', action='store_true',
-                    help='N > 1: try to capture the DDP step (RCCL collectives included) as a hipGraph; falls back to eager launches')
+                    help='N > 1, EXPERIMENTAL (never run on multi-GPU hardware): capture the DDP step, RCCL collectives included, as a '
+                         'hipGraph; a failed capture aborts the run.  Default: eager launches under DDP')
     ap.add_argument('--torch-optim', action='store_true', help='stock clip_grad_norm_ + torch.optim.AdamW(fused) instead of the HIP ClipAdamW')
     return ap.parse_args()
 
@@ -200,6 +201,8 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
                 graphed()
             sync_all()
         except Exception as e:        # report and fall back to eager launches
+            if world > 1:             # a failed capture with collectives in flight cannot be recovered from (measured with gloo, which
+                raise                 # is not capturable at all: the process is left with an invalidated stream) -- fail loudly
             sys.stderr.write('hipGraph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
             graphed = None
     if world > 1:                     # all ranks must take the same path (a collective inside / outside a graph)
