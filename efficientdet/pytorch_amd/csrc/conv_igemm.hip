@@ -1076,11 +1076,12 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   k.act = p->act; k.res_mode = p->res_mode; k.out_f32 = p->out_f32; k.kord = g_tuning[EFFDET_TUNE_IGEMM_KORD];
   k.out_split = (splitfmt && !p->out_f32) ? 1 : 0;
   if (splitfmt) {
-    // K walk of the split-layout kernels (tuning knob EFFDET_TUNE_SPLIT_KORD / env EFFDET_SPLIT_KORD): 0 tap-major, 1 channel-
-    // group-major, 2 (default) = by measurement: group-major for the 64-channel tile only (256 -> 64 data gradient back to the
-    // neck: 214 -> 261 TFLOP/s -- one n-tile per pixel tile, so nothing else re-uses the staged lines), tap-major for the
-    // 128-channel tile (378 vs 380: the two n-tiles of an XCD's neighbouring workgroups already share the fetches)
-    if (g_tuning[EFFDET_TUNE_SPLIT_KORD] < 0) g_tuning[EFFDET_TUNE_SPLIT_KORD] = getenv("EFFDET_SPLIT_KORD") ? atoi(getenv("EFFDET_SPLIT_KORD")) : 2;
+    // K walk of the split-layout kernels (tuning knob EFFDET_TUNE_SPLIT_KORD / env EFFDET_SPLIT_KORD): 0 tap-major, 1 (default)
+    // channel-group-major, 2 = group-major for the 64-channel tile only.  Measured (profiles/r03_kord_fetch.txt): the group-major
+    // walk cuts the L2 -> fabric fetches of a head launch from 1377 to 514 MB (algorithmic: 374 MB) at the SAME duration on the
+    // 128-channel tile (601 us either way: those misses were served by the Infinity Cache and hidden), and from 1547 to 204 MB with
+    // 231 -> 194 us on the 64-channel tile (256 -> 64 data gradient back to the neck: 214 -> 261 TFLOP/s)
+    if (g_tuning[EFFDET_TUNE_SPLIT_KORD] < 0) g_tuning[EFFDET_TUNE_SPLIT_KORD] = getenv("EFFDET_SPLIT_KORD") ? atoi(getenv("EFFDET_SPLIT_KORD")) : 1;
     const int kv = g_tuning[EFFDET_TUNE_SPLIT_KORD];
     k.kord = ((kv == 1 || (kv == 2 && p->Cout <= 64)) && k.cpt % 8 == 0) ? 1 : 0;
   }
