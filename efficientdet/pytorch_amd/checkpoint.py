@@ -54,10 +54,17 @@ def load_checkpoint(path, model=None, optimizer=None, map_location='cpu'):
     return ck
 
 
-def load_pretrained_backbone(model, source=None, load_fc=False, directory=None):
+def load_pretrained_backbone(model, source=None, load_fc=False, directory=None, reference_semantics=False):
     """Load ImageNet EfficientNet weights into ``model.backbone`` (what ``EfficientNet.from_pretrained`` does in the
     reference, models/efficientnet.py:222-226 -> models/utils.py:317-328).  ``source``: a state_dict, a .pth path, or None =
-    ``PRETRAINED_FILES[backbone name]`` inside ``directory`` / $EFFDET_PRETRAINED_DIR / ~/.cache/torch/hub/checkpoints."""
+    ``PRETRAINED_FILES[backbone name]`` inside ``directory`` / $EFFDET_PRETRAINED_DIR / ~/.cache/torch/hub/checkpoints.
+
+    ``reference_semantics``: the reference calls ``from_pretrained`` FIRST and then runs its initialisation loop over
+    ``self.modules()`` (models/efficientdet.py:33, 47-53), which redraws EVERY ``nn.Conv2d`` weight -- the backbone's included --
+    from N(0, sqrt(2/n)) and resets every BatchNorm weight / bias to 1 / 0.  What survives of the pretrained file in the
+    reference's model is therefore only: the BatchNorm running statistics, the conv BIASES (the squeeze-excite convs) and the
+    unused ``_fc``.  ``False`` (default) keeps the loaded weights -- what a user loading pretrained weights wants;
+    ``True`` reproduces the reference's effective behaviour by re-running that loop over the backbone after loading."""
     m = unwrap(model)
     name = m.backbone.model_name
     if source is None:
@@ -76,5 +83,14 @@ def load_pretrained_backbone(model, source=None, load_fc=False, directory=None):
         res = m.backbone.load_state_dict(sd, strict=False)
         assert set(res.missing_keys) == {'_fc.weight', '_fc.bias'}, 'issue loading pretrained weights'
         assert not res.unexpected_keys, res.unexpected_keys
+    if reference_semantics:
+        import math
+        for mod in m.backbone.modules():                        # models/efficientdet.py:47-53, restricted to the backbone
+            if isinstance(mod, torch.nn.Conv2d):
+                n = mod.kernel_size[0] * mod.kernel_size[1] * mod.out_channels
+                mod.weight.data.normal_(0, math.sqrt(2. / n))
+            elif isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.data.fill_(1)
+                mod.bias.data.zero_()
     m._prep = {}
     return name

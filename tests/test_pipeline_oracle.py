@@ -116,6 +116,15 @@ def test_checkpoint_roundtrip_prefix_and_pretrained(tmp_path):
     bad = dict(bsd); bad.pop('_blocks.0._bn1.weight')
     with pytest.raises(AssertionError):
         ck.load_pretrained_backbone(m2, source=bad)
+    # reference_semantics=True: the reference's __init__ redraws every Conv2d weight and resets every BatchNorm
+    # weight / bias AFTER from_pretrained (models/efficientdet.py:33, 47-53): only running statistics and conv biases survive
+    m3 = EfficientDet(4, network='efficientdet-d0', W_bifpn=64, D_bifpn=2)
+    ck.load_pretrained_backbone(m3, directory=str(tmp_path), reference_semantics=True)
+    b3 = m3.backbone
+    assert torch.equal(b3._blocks[3]._bn1.running_mean, bsd['_blocks.3._bn1.running_mean'])
+    assert torch.equal(b3._blocks[3]._se_reduce.bias, bsd['_blocks.3._se_reduce.bias'])
+    assert not torch.equal(b3._blocks[3]._project_conv.weight, bsd['_blocks.3._project_conv.weight'])
+    assert bool((b3._blocks[3]._bn2.weight == 1).all()) and bool((b3._blocks[3]._bn2.bias == 0).all())
 
 
 def test_dropin_import_paths():
