@@ -28,6 +28,7 @@ class Seg(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('x', C.c_void_p), ('w', C.c_void_p), ('y', C.c_void_p), ('z', C.c_void_p), ('res', C.c_void_p),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('rowscale', C.c_void_p),
+                ('bc_scale', C.c_void_p), ('bc_shift', C.c_void_p),
                 ('dtype', C.c_int), ('out_f32', C.c_int),
                 ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
                 ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
@@ -40,7 +41,7 @@ class WgradDesc(C.Structure):
                 ('dtype', C.c_int),
                 ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
                 ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
-                ('ldx', C.c_int), ('lddz', C.c_int), ('nseg', C.c_int), ('seg', Seg * MAX_SEG)]
+                ('ldx', C.c_int), ('lddz', C.c_int), ('nseg', C.c_int), ('image_splits', C.c_int), ('seg', Seg * MAX_SEG)]
 
 
 class PrepJob(C.Structure):      # effdet_prep_job_t
@@ -56,7 +57,7 @@ SYMBOLS = [
     'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
-    'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
+    'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
     'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_bwd',
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
     'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',

@@ -41,6 +41,7 @@ struct SegD {
 struct ConvK {
   const void* x; const void* w; void* y; void* z; const void* res;
   const float* scale; const float* shift; const float* rowscale;
+  const float* bc_scale; const float* bc_shift;      // per (image, output channel) affine [B][Cout], applied after rowscale, before res
   int Cin, Cout, KW, stride, pad_t, pad_l;
   int ldx, ldy;
   int Kc;    // K in 16-byte chunks (= KH*KW*Cin/CE)
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   //  HBM-bound pointwise convs VALU-bound (~1100 VALU per wave for 16 MFMAs), not store-bound; hence the hoisted
   //  16-byte scale/shift loads here and the v_rcp_f32 / v_cvt_pk_bf16_f32 helpers in common.h.)
   // emit(n0, accumulators of channels n0..n0+3, scale, shift, output row, row scale): the fused epilogue of one lane's 4-channel group
-  auto emit = [&](int n0, f32x4 v, const f32x4& sc, const f32x4& sh, long long orow, float rs) {
+  auto emit = [&](int n0, f32x4 v, const f32x4& sc, const f32x4& sh, long long orow, float rs, int bi) {
     v = v * sc + sh;
     const bool full = p.vec_ok && (n0 + 3 < p.Cout);
     const long long o = orow + n0;
@@ -415,6 +416,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
     else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
     if (p.rowscale) v *= rs;
+    if (p.bc_scale) {
+      // per-(image, channel) affine: the squeeze-excite backward fused into the project conv's data gradient --
+      // dz_d = (dxs * gate[b][c] + dpool[b][c]) * swish'(z_d) with res = z_d, RES_SWISH_GRAD (functional.mbconv_bwd)
+      const long long bo = (long long)bi * p.Cout + n0;
+      for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) v[r] = fmaf(v[r], p.bc_scale[bo + r], p.bc_shift[bo + r]);
+    }
     if constexpr (SPLIT == 2) {
       if (p.out_split) {
         // split layout: channel n of a pixel row sits at byte (n >> 5) * 128 + (n & 31) * 2 (hi) and + 64 (lo); the lane's 4
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
           if (n0 >= p.Cout) continue;
           f32x4 sc, sh;
           scale_shift(n0, sc, sh);
-          emit(n0, f32x4{acc32[a][b][4 * gq], acc32[a][b][4 * gq + 1], acc32[a][b][4 * gq + 2], acc32[a][b][4 * gq + 3]}, sc, sh, orow, rs);
+          emit(n0, f32x4{acc32[a][b][4 * gq], acc32[a][b][4 * gq + 1], acc32[a][b][4 * gq + 2], acc32[a][b][4 * gq + 3]}, sc, sh, orow, rs, bi);
         }
     }
     return;
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     for (int a = 0; a < NT; ++a) {
       const int n0 = n_base + wn0 + a * 16 + lq * 4;
       if (n0 >= p.Cout) continue;
-      emit(n0, acc[a][b], scv[a], shv[a], orow, rs);
+      emit(n0, acc[a][b], scv[a], shv[a], orow, rs, bi);
     }
   }
 }
@@ -1070,6 +1077,8 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   } else if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
   k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res;
   k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
+  k.bc_scale = p->bc_scale; k.bc_shift = p->bc_shift;
+  if ((p->bc_scale != nullptr) != (p->bc_shift != nullptr)) return EFFDET_EINVAL;
   k.Cin = p->Cin; k.Cout = p->Cout; k.KW = p->KW; k.stride = p->stride; k.pad_t = p->pad_t; k.pad_l = p->pad_l;
   k.ldx = p->ldx; k.ldy = p->ldy;
   k.cpt = p->Cin / ce; k.Kc = p->KH * p->KW * k.cpt;
@@ -1113,7 +1122,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   const long long wb = (long long)p->Cout * k.Kc * 16;
   if (wb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
   k.w_bytes = (unsigned)wb;
-  if (p->dtype == EFFDET_BF16 && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
+  if (p->dtype == EFFDET_BF16 && !p->bc_scale && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
     long long mtot = 0;
     bool fits = true;        // offsets + the tap walk's SGPR offset must stay below the 2-GiB sentinel
     for (int s = 0; s < p->nseg; ++s) {
@@ -1139,7 +1148,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   if (p->dtype == EFFDET_F32_SPLIT) {
     // persistent 256 x 256 / 32x32x16 form for the long-K head convs (tuning knob EFFDET_TUNE_SPLIT_PERS / env EFFDET_SPLIT_PERS)
     if (g_tuning[EFFDET_TUNE_SPLIT_PERS] < 0) g_tuning[EFFDET_TUNE_SPLIT_PERS] = getenv("EFFDET_SPLIT_PERS") ? atoi(getenv("EFFDET_SPLIT_PERS")) : 0;
-    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
+    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && !p->bc_scale && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
       long long mtot = 0;
       bool fits = true;
       for (int s = 0; s < p->nseg; ++s) {

@@ -954,6 +954,22 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits, int tile = 128) {
     if (eff > best_eff + 0.02) { best_eff = eff; best_mc = mc; }
   }
   long long mchunk = best_mc;
+  if (p->image_splits) {
+    // split boundaries on IMAGE boundaries (q splits per image, slab s belongs to image s / q): the per-image partial gradients
+    // M_b = dz_b^T x_b are what the squeeze-excite backward and the drop_connect row scale need (effdet_se_dgate_slabs,
+    // slab_scale of effdet_unpack_conv_wgrad*).  One level only; the image must be whole K-steps.
+    const long long hw = (long long)p->seg[0].Ho * p->seg[0].Wo;
+    if (p->nseg != 1 || hw % bkm) return EFFDET_EUNSUPPORTED;
+    long long q = 1;
+    const long long qmax = hw / bkm >= 8 ? hw / (8LL * bkm) : 1;          // keep >= 8 K-steps per block where the image allows
+    while (q < qmax && tiles * p->B * q < 512) {
+      long long nq = q + 1;
+      while (nq <= qmax && ((hw % nq) || ((hw / nq) % bkm))) ++nq;
+      if (nq > qmax) break;
+      q = nq;
+    }
+    mchunk = hw / q;
+  }
   k.mchunk = (int)mchunk;
   splits = 0;
   for (int s = 0; s < p->nseg; ++s) {

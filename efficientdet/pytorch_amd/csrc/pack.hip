@@ -85,7 +85,11 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
                                                            int Cin_pad, int nslabs, long long slab_stride,
                                                            const float* __restrict__ dsum_part, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ dbias_out) {
+                                                           float* __restrict__ dbeta, float* __restrict__ dbias_out,
+                                                           const float* __restrict__ slab_scale, int slabs_per_scale) {
+  // slab_scale (optional): slab sl is multiplied by slab_scale[sl / slabs_per_scale] while summing -- per-image slabs
+  // (effdet_wgrad_t.image_splits) x the drop_connect row scale of that image: dW = sum_b rs_b * M_b without a scaled copy of dz
+  auto fac = [&](int sl) -> float { return slab_scale ? slab_scale[sl / slabs_per_scale] : 1.0f; };
   const int co = blockIdx.x, taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
   // sum_m dz[m][co]: the weight-gradient launch left one partial per split-K slab ([nslabs][Cout]); wave 0 adds them in a fixed
@@ -93,7 +97,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   __shared__ float dsum_sh;
   if (dsum_part && blockIdx.y == 0 && threadIdx.x < 64) {
     float t = 0.f;
-    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * gridDim.x + co];
+    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * gridDim.x + co] * fac(sl);
     t = wave_sum(t);
     if (threadIdx.x == 0) { dsum_sh = t; if (dbias_out) dbias_out[co] = t; }
   }
@@ -120,10 +124,10 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     if (slice < SL) {
       int sl = slice;
       for (; sl + SL < nslabs; sl += 2 * SL) {
-        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride);
-        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride);
+        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
+        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride) * fac(sl + SL);
       }
-      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride);
+      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
     }
     sred[threadIdx.x] = a0 + a1;
     __syncthreads();
@@ -137,15 +141,15 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   // slab loop unrolled x4 so the loads of different slabs are in flight together
   for (int q4 = blockIdx.y * 256 + threadIdx.x; q4 * 4 < np; q4 += gridDim.y * 256) {
     const int pidx = q4 * 4;
-    f32x4 a0 = *(const f32x4*)(grow + pidx), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    f32x4 a0 = *(const f32x4*)(grow + pidx) * fac(0), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     int sl = 1;
     for (; sl + 3 < nslabs; sl += 4) {
-      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride);
-      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride);
-      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride);
-      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride);
+      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
+      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride) * fac(sl + 1);
+      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride) * fac(sl + 2);
+      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride) * fac(sl + 3);
     }
-    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride);
+    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
     emit(pidx, (a0 + a1) + (a2 + a3));
   }
   }
@@ -250,24 +254,29 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
 
 extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w, float* dw, float* wsum,
                                         int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
-                                        const float* dbias_part, float* dbias_out, effdet_stream_t stream) {
+                                        const float* dbias_part, float* dbias_out, const float* slab_scale, int slabs_per_scale,
+                                        effdet_stream_t stream) {
+  if (slab_scale && (slabs_per_scale < 1 || nslabs % slabs_per_scale)) return EFFDET_EINVAL;
   if (!g || !dw || (wsum && !w) || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3) || (!dbias_part != !dbias_out)) return EFFDET_EINVAL;
   const int np = KH * KW * Cin_pad;
   const int gy = wsum ? 1 : (np / 4 + 255) / 256;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, gy), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW,
                      Cin_pad, nslabs, (long long)Cout * np, dbias_part, (const float*)nullptr, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, dbias_out);
+                     (float*)nullptr, (float*)nullptr, dbias_out, slab_scale, slab_scale ? slabs_per_scale : 1);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
 
 extern "C" int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w, float* dw, const float* dsum_part,
                                            const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout,
-                                           int Cin, int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream) {
+                                           int Cin, int KH, int KW, int Cin_pad, int nslabs, const float* slab_scale,
+                                           int slabs_per_scale, effdet_stream_t stream) {
+  if (slab_scale && (slabs_per_scale < 1 || nslabs % slabs_per_scale)) return EFFDET_EINVAL;
   if (!g || !dw || !w || !dsum_part || !mean || !invstd || !dgamma || !dbeta || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
   const int np = KH * KW * Cin_pad;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, 1), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, (float*)nullptr, 0, Cin, KH,
-                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum_part, mean, invstd, dgamma, dbeta, (float*)nullptr);
+                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum_part, mean, invstd, dgamma, dbeta, (float*)nullptr, slab_scale,
+                     slab_scale ? slabs_per_scale : 1);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_split_kernel(const float* __r
 //   du[c]   = dgate[c]*g(1-g)                       (through the sigmoid)
 //   dmid[j] = swish'(mid[j]) * sum_c w2[c][j]*du[c]
 //   dpool[c]= inv_hw * sum_j w1[j][c]*dmid[j]       (gradient wrt the pooled SUM)
-__global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __restrict__ dgate, int slabs, const float* __restrict__ gate,
+__global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __restrict__ dgate, int slabs, int times_gate, const float* __restrict__ gate,
                                                              const float* __restrict__ mid, const float* __restrict__ w1,
                                                              const float* __restrict__ w2, float* __restrict__ dpool,
                                                              float* __restrict__ ws_du, float* __restrict__ ws_dmid,
@@ -152,7 +152,8 @@ __global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __rest
     int sl = 0;
     for (; sl + 3 < slabs; sl += 4) { t0 += dq[(long long)sl * C]; t1 += dq[(long long)(sl + 1) * C]; t2 += dq[(long long)(sl + 2) * C]; t3 += dq[(long long)(sl + 3) * C]; }
     for (; sl < slabs; ++sl) t0 += dq[(long long)sl * C];
-    const float d = ((t0 + t1) + (t2 + t3)) * g * (1.f - g);
+    // times_gate: the incoming rows already are (d loss / d gate) * gate (effdet_se_dgate_slabs): the sigmoid's g drops out
+    const float d = ((t0 + t1) + (t2 + t3)) * (times_gate ? (1.f - g) : g * (1.f - g));
     du[c] = d; ws_du[(long long)b * C + c] = d;
   }
   __syncthreads();
@@ -295,6 +296,30 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy,
   }
 }
 
+// ---- (d loss / d gate * gate)[b][c] from the PER-IMAGE partial weight gradients of the project conv ----
+// With xs = xd * gate (the project conv's input) and dxs = dz2 * W' (its data gradient, W'[n][c] = W[n][c] * bn_scale[n]):
+//   sum_p dxs[b,p,c] * xs[b,p,c] = sum_n W'[n][c] * (sum_p dz2[b,p,n] * xs[b,p,c]) = sum_n W'[n][c] * M_b[n][c]
+// and the left side is dgate[b][c] * gate[b][c].  M_b is what effdet_conv2d_wgrad leaves per image with image_splits (q slabs per
+// image, summed here in slab order); rowscale[b] (drop_connect) scales the whole image's gradient.  So the gate gradient needs no pass
+// over the activations at all: se_dgate's two full-tensor reads (3 GB per D0 step) become a few MB of slab reads.
+__global__ __launch_bounds__(256) void se_dgate_slabs_kernel(const float* __restrict__ slabs, const float* __restrict__ w,
+                                                             const float* __restrict__ bn_scale, const float* __restrict__ rowscale,
+                                                             float* __restrict__ out, int q, int Co, int Ce) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= Ce) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int i = 0; i < q; ++i) {
+    const float* sl = slabs + ((long long)b * q + i) * Co * Ce + c;
+    int n = 0;
+    for (; n + 1 < Co; n += 2) {
+      s0 = fmaf(sl[(long long)n * Ce], w[(long long)n * Ce + c] * bn_scale[n], s0);
+      s1 = fmaf(sl[(long long)(n + 1) * Ce], w[(long long)(n + 1) * Ce + c] * bn_scale[n + 1], s1);
+    }
+    if (n < Co) s0 = fmaf(sl[(long long)n * Ce], w[(long long)n * Ce + c] * bn_scale[n], s0);
+  }
+  out[(long long)b * Ce + c] = (s0 + s1) * (rowscale ? rowscale[b] : 1.0f);
+}
+
 // ---- dz = (dy*gate + dpool) * swish'(z) ----
 template <typename T>
 __global__ void se_bwd_apply_kernel(const T* __restrict__ dy, const float* __restrict__ gate, const float* __restrict__ dpool,
@@ -432,7 +457,7 @@ extern "C" int effdet_se_gate_fwd_split(const float* pool_part, int G, float* po
 
 extern "C" long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse) { return (long long)B * (C + 2 * Cse); }
 
-extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, const float* gate, const float* mid, const float* pool, const float* w1,
+extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, int dgate_times_gate, const float* gate, const float* mid, const float* pool, const float* w1,
                                   const float* b1, const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                                   float* workspace, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
   (void)b1;
@@ -442,7 +467,7 @@ extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, const flo
   const size_t lds = (size_t)(C + Cse + R * Cse) * sizeof(float);
   if (lds > 60000) return EFFDET_EUNSUPPORTED;
   float* ws_du = workspace; float* ws_dmid = ws_du + (size_t)B * C; float* ws_sw = ws_dmid + (size_t)B * Cse;
-  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, dgate_slabs, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
+  hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, dgate_slabs, dgate_times_gate, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
                      Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
   const long long n = 2LL * C * Cse + C + Cse;
@@ -473,6 +498,15 @@ extern "C" int effdet_channel_scale(const void* x, const float* gate, void* y, i
 }
 
 extern "C" int effdet_se_dgate_slabs(long long HW) { return se_dgate_slabs(HW); }
+
+extern "C" int effdet_se_dgate_from_wgrad(const float* slabs, const float* w_oc, const float* bn_scale, const float* rowscale,
+                                          float* dgate_times_gate, int B, int q, int Cout, int Cexp, effdet_stream_t stream) {
+  if (!slabs || !w_oc || !bn_scale || !dgate_times_gate || B < 1 || q < 1 || Cout < 1 || Cexp < 1) return EFFDET_EINVAL;
+  hipLaunchKernelGGL(se_dgate_slabs_kernel, dim3((Cexp + 255) / 256, B), dim3(256), 0, ST, slabs, w_oc, bn_scale, rowscale, dgate_times_gate, q,
+                     Cout, Cexp);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
 
 extern "C" int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, int dtype, int B, long long HW, int C,
                                effdet_stream_t stream) {

@@ -19,6 +19,7 @@ from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE, 
 
 DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: also store the depthwise Swish output in training
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
+SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 
 
 def chunk_elems(dtype):
@@ -134,22 +135,38 @@ def mbconv_bwd(sv, dy):
     B, H, W = x.B, x.H, x.W
     g = {}
     Ce, Co, Ci, Cs, kk = blk.cexp, blk.cout, blk.cin, blk.cse, blk.k * blk.k
-    # ---- project conv (+ drop_connect scale on the branch) ----
+    # ---- project conv (+ drop_connect scale on the branch) + squeeze-excite backward ----
     rs = sv['rowscale'] if blk.skip else None
-    dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
-    G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dz2, Cin=Ce, Cout=Co, KH=1, KW=1)
     wp = P['project.weight']
-    g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'])
-    dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
-    ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
-    # ---- squeeze-excite ----
-    dgate = ops.se_dgate(dxs, sv['xd']) if sv['xd'] is not None else ops.se_dgate(dxs, sv['zd'], ACT_SWISH)
     w1 = P['se_reduce.weight'].view(Cs, Ce); w2 = P['se_expand.weight'].view(Ce, Cs)
-    dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
-                                                sv['inv_hw'])
+    hw = dy.H * dy.W
+    if SE_FUSED and hw % (64 if dtype == torch.bfloat16 else 32) == 0:
+        # Fused form (no pass over the activations for the gate gradient, dxs never materialised):
+        #   per-image partial weight gradients M_b = dy_b^T xs_b (split-K on image boundaries)
+        #   dW = sum_b rs_b M_b (slab scale in the unpack);  (dgate*gate)[b][c] = rs_b sum_n W'[n][c] M_b[n][c]
+        #   dz_d = (rs_b (dy W') gate[b][c] + dpool[b][c]) * swish'(z_d)   in the epilogue of the project conv's data gradient
+        # -- se_dgate (2 tensor reads), se_bwd_apply (2 reads + 1 write) and the drop_connect act_bwd become one extra read of z_d.
+        G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dy, Cin=Ce, Cout=Co, KH=1, KW=1, image_splits=True)
+        g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'],
+                                                                                 slab_scale=rs)
+        dgg = ops.se_dgate_from_wgrad(G2, wp, sv['s2'], rs, B)
+        dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgg, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
+                                                    sv['inv_hw'], times_gate=True)
+        dzd = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
+        ops.conv2d(dy, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dzd, Cin=Co, Cout=Ce, KH=1, KW=1, rowscale=rs,
+                   bc_scale=sv['gate'], bc_shift=dpool, res=sv['zd'], res_mode=ops.RES_SWISH_GRAD)
+    else:
+        dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
+        G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dz2, Cin=Ce, Cout=Co, KH=1, KW=1)
+        g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'])
+        dxs = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
+        ops.conv2d(dz2, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dxs, Cin=Co, Cout=Ce, KH=1, KW=1)
+        dgate = ops.se_dgate(dxs, sv['xd']) if sv['xd'] is not None else ops.se_dgate(dxs, sv['zd'], ACT_SWISH)
+        dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgate, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
+                                                    sv['inv_hw'])
+        dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
     g['se_reduce.weight'], g['se_reduce.bias'] = dw1.view(Cs, Ce, 1, 1), db1
     g['se_expand.weight'], g['se_expand.bias'] = dw2.view(Ce, Cs, 1, 1), db2
-    dzd = ops.se_bwd_apply(dxs, sv['gate'], dpool, sv['zd'])
     # ---- depthwise ----
     gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0], in_act=sv['dw_in_act'])
     g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,

@@ -329,7 +329,7 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
 
 
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
-           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False):
+           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None):
     """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
     split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
     is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed)."""
@@ -356,6 +356,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
             assert (r.addr() - br) * isy == (y.addr() - base_y) * r.t.element_size() and r.ld == y.ld and r.bstride == y.bstride
         d.res = br
     d.scale, d.shift, d.rowscale = (t.data_ptr() if t is not None else None for t in (scale, shift, rowscale))
+    d.bc_scale, d.bc_shift = (t.data_ptr() if t is not None else None for t in (bc_scale, bc_shift))     # [B][Cout] fp32, after rowscale, before res
     d.dtype, d.out_f32 = (L.F32_SPLIT if split else _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout)), int(out_f32)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
@@ -368,7 +369,8 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
 
-def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False):
+def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False,
+                 image_splits=False):
     """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
     split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
     runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ..."""
@@ -386,6 +388,7 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.lddz = x0.ld, z0.ld
+    d.image_splits = int(image_splits)        # split-K boundaries on image boundaries: slabs [B*q], slab s = image s // q (one level only)
     _segs(d, xs, dzs, base_x, base_z, isz, z0.t.element_size())
     flops = 2.0 * KH * KW * Cin * Cout * sum(z.B * z.H * z.W for z in dzs)
     splits = int(L.lib().effdet_conv2d_wgrad_splits(C.byref(d)))
@@ -406,7 +409,7 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     return slabs, parts
 
 
-def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None, dbias_part=None):
+def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None, dbias_part=None, slab_scale=None):
     """g: packed gradient [Cout][taps][Cin_pad] or unreduced slabs [splits][Cout][taps][Cin_pad] (summed here).
     dbias_part ([splits][Cout], from conv2d_wgrad): -> the bias gradient [Cout] (summed in slab order), else None."""
     Cout, Cin, KH, KW = dw_oihw.shape
@@ -415,12 +418,15 @@ def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=Fals
     assert dbias_part is None or dbias_part.shape == (nslabs, Cout)
     L.check(L.lib().effdet_unpack_conv_wgrad(L.ptr(g), L.ptr(scale), L.ptr(w_oihw), L.ptr(dw_oihw), L.ptr(wsum),
                                              int(accumulate), Cout, Cin, KH, KW, Cin if cin_pad is None else cin_pad,
-                                             nslabs, L.ptr(dbias_part), L.ptr(db), L.stream_ptr()), 'effdet_unpack_conv_wgrad')
+                                             nslabs, L.ptr(dbias_part), L.ptr(db), L.ptr(slab_scale),
+                                             nslabs // slab_scale.numel() if slab_scale is not None else 1, L.stream_ptr()),
+            'effdet_unpack_conv_wgrad')
     return db
 
 
-def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None):
-    """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta); dsum_part: the [splits][Cout] rows of conv2d_wgrad."""
+def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None, slab_scale=None):
+    """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta); dsum_part: the [splits][Cout] rows of conv2d_wgrad.
+    slab_scale [B] (per-image slabs of conv2d_wgrad(image_splits=True)): slab s is multiplied by slab_scale[s // (splits / B)]."""
     Cout, Cin, KH, KW = w_oihw.shape
     nslabs = g.shape[0] if g.dim() == 4 else 1
     if dsum_part.dim() == 1:
@@ -430,7 +436,8 @@ def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None):
     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dw.device)
     L.check(L.lib().effdet_unpack_conv_wgrad_bn(L.ptr(g), L.ptr(scale), L.ptr(w_oihw.detach()), L.ptr(dw), L.ptr(dsum_part), L.ptr(mean),
                                                 L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cout, Cin, KH, KW,
-                                                Cin if cin_pad is None else cin_pad, nslabs, L.stream_ptr()),
+                                                Cin if cin_pad is None else cin_pad, nslabs, L.ptr(slab_scale),
+                                                nslabs // slab_scale.numel() if slab_scale is not None else 1, L.stream_ptr()),
             'effdet_unpack_conv_wgrad_bn')
     return dw, dgb[0], dgb[1]
 
@@ -617,7 +624,17 @@ def se_dgate(dy, x, act=ACT_NONE):
     return dg
 
 
-def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw):
+def se_dgate_from_wgrad(slabs, w_oc, bn_scale, rowscale, B):
+    """(d loss / d gate * gate) [B][Cexp] from the project conv's per-image weight-gradient slabs [B*q][Cout][1][Cexp] (see the header)."""
+    S, Co, _, Ce = slabs.shape
+    assert S % B == 0
+    out = torch.empty((B, Ce), dtype=torch.float32, device=slabs.device)
+    L.check(L.lib().effdet_se_dgate_from_wgrad(L.ptr(slabs), L.ptr(w_oc.detach()), L.ptr(bn_scale), L.ptr(rowscale), L.ptr(out), B, S // B,
+                                               Co, Ce, L.stream_ptr()), 'effdet_se_dgate_from_wgrad')
+    return out
+
+
+def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, times_gate=False):
     """dgate: [B][slabs][C] partial rows of se_dgate (or a plain [B][C] gradient).
     -> (dpool, dw1, db1, dw2, db2); the parameter grads are fresh tensors (overwritten, not accumulated)."""
     if dgate.dim() == 2:
@@ -634,7 +651,7 @@ def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw):
     db2 = out[o:o + Cc]; o += Cc
     ws = out[o:]
     assert ws.numel() >= L.lib().effdet_se_gate_bwd_workspace_floats(B, Cc, Cse)
-    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
+    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], int(times_gate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
                                        L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(ws),
                                        B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
     return dpool, dw1, db1, dw2, db2

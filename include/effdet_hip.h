@@ -63,7 +63,7 @@ typedef struct {
  *   (expand / project conv + BN + swish + skip), models/module.py:495-501 (ConvModule.forward:
  *   BiFPN lateral + 3x3 convs, RetinaHead towers), models/retinahead.py:116-123 (retina_cls +
  *   sigmoid, retina_reg).  Also used for the data gradient of stride-1 convs (flipped weights).
- *   y = act( (conv(x,w)) * scale[n] + shift[n] ) [* rowscale[b]] [res op]
+ *   y = act( (conv(x,w)) * scale[n] + shift[n] ) [* rowscale[b]] [* bc_scale[b][n] + bc_shift[b][n]] [res op]
  *   z (optional) receives the pre-activation value  conv*scale+shift  (saved for backward).
  * w is packed [Cout][KH*KW][Cin] in `dtype` (effdet_pack_conv_weight).
  * Requirements: Cin % (16/sizeof(dtype)) == 0, ldx % (16/sizeof(dtype)) == 0, x 16-byte aligned.
@@ -72,6 +72,9 @@ typedef struct {
   const void* x; const void* w; void* y; void* z; const void* res;
   const float* scale; const float* shift; /* per output channel, may be NULL (=> 1 / 0) */
   const float* rowscale;                  /* per image [B], may be NULL (drop_connect keep mask / keep_prob) */
+  const float* bc_scale; const float* bc_shift; /* both or neither: per (image, output channel) affine [B][Cout], applied after
+                                           * rowscale and before the res op:  v = v*bc_scale[b][n] + bc_shift[b][n]
+                                           * (squeeze-excite backward fused into the project conv's data gradient) */
   int dtype, out_f32;                     /* out_f32: y is written as fp32 regardless of dtype */
   int B, Cin, Cout, KH, KW, stride, pad_t, pad_l;
   int ldx, ldy;                           /* channel strides (elements) of x rows and y/z/res rows */
@@ -114,6 +117,8 @@ typedef struct {
   int B, Cin, Cout, KH, KW, stride, pad_t, pad_l;
   int ldx, lddz;
   int nseg;
+  int image_splits;   /* != 0 (one level only, Ho*Wo a multiple of the kernel's K-step): split-K boundaries fall on image
+                       * boundaries -- effdet_conv2d_wgrad_splits(p) = B * q slabs, slab s holds the partial gradient of image s / q */
   effdet_seg_t seg[EFFDET_MAX_SEG];
 } effdet_wgrad_t;
 /* workspace: effdet_conv2d_wgrad_workspace_bytes(p) bytes of scratch for the split-K partial slabs + bias partial rows. */
@@ -136,13 +141,18 @@ int effdet_pack_conv_weight(const float* w_oihw, const float* scale, void* out, 
  * their sum in slab order (overwritten, not accumulated). */
 int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w_oihw, float* dw_oihw,
                              float* wsum, int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
-                             const float* dbias_part, float* dbias_out, effdet_stream_t stream);
+                             const float* dbias_part, float* dbias_out, const float* slab_scale, int slabs_per_scale,
+                             effdet_stream_t stream);
+/* slab_scale (optional, with slabs_per_scale | nslabs): slab s (and its bias partial row) is multiplied by
+ * slab_scale[s / slabs_per_scale] while summing -- per-image slabs (effdet_wgrad_t.image_splits) x the drop_connect row scale of
+ * the image: dW = sum_b rs[b] * M_b without a scaled copy of dz. */
 /* The same unpack for a conv followed by a frozen BatchNorm, with effdet_bn_param_grad fused in (one launch instead
  * of two per BN conv): dw = scale*g, dgamma = invstd*(sum_k w*g - mean*dsum), dbeta = dsum, where dsum[cout] is the sum of
  * the [nslabs][Cout] partial rows dsum_part (see effdet_conv2d_wgrad). */
 int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w_oihw, float* dw_oihw, const float* dsum_part,
                                 const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout, int Cin,
-                                int KH, int KW, int Cin_pad, int nslabs, effdet_stream_t stream);
+                                int KH, int KW, int Cin_pad, int nslabs, const float* slab_scale, int slabs_per_scale,
+                                effdet_stream_t stream);
 
 /* Batched parameter preparation: every per-step repack of the model's parameters in ONE launch (a D0 train step
  * issued ~190 of these 4-microsecond kernels one by one: 125 weight packs, 48 BN folds, 16 depthwise packs).
@@ -243,6 +253,13 @@ int effdet_channel_scale(const void* x, const float* gate, void* y, int act, int
  *   dgate_part[b][slab][c] = sum over the pixel slab of dy*act(x), slab < effdet_se_dgate_slabs(HW)
  * (every entry overwritten with a plain store; effdet_se_gate_bwd adds the slabs in order: no float atomics)   */
 int effdet_se_dgate_slabs(long long HW);
+/* The same gradient WITHOUT a pass over the activations, from the per-image partial weight gradients of the project conv
+ * (effdet_conv2d_wgrad with image_splits: slabs [B*q][Cout][Cexp], unscaled):
+ *   dgate_times_gate[b][c] = rowscale[b] * sum_{i<q} sum_n slabs[b*q+i][n][c] * w_oc[n][c] * bn_scale[n]  = (d loss/d gate)[b][c] * gate[b][c]
+ * (w_oc: the project conv's OIHW weight = [Cout][Cexp]; rowscale optional).  Feed it to effdet_se_gate_bwd with dgate_slabs = 1,
+ * dgate_times_gate = 1. */
+int effdet_se_dgate_from_wgrad(const float* slabs, const float* w_oc, const float* bn_scale, const float* rowscale,
+                               float* dgate_times_gate, int B, int q, int Cout, int Cexp, effdet_stream_t stream);
 int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, int dtype, int B, long long HW, int C,
                     effdet_stream_t stream);
 /* tiny FC backward: from dgate_part[b][slab][c] (partial grads wrt gate, dgate_slabs rows per image; 1 = a plain
@@ -250,7 +267,7 @@ int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, i
  * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (OVERWRITTEN, fp32; batch reductions with one
  * thread per parameter: no atomics, deterministic).  workspace: effdet_se_gate_bwd_workspace_floats() fp32. */
 long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse);
-int effdet_se_gate_bwd(const float* dgate_part, int dgate_slabs, const float* gate, const float* mid, const float* pool,
+int effdet_se_gate_bwd(const float* dgate_part, int dgate_slabs, int dgate_times_gate, const float* gate, const float* mid, const float* pool,
                        const float* w1, const float* b1, const float* w2, float* dpool, float* dw1, float* db1,
                        float* dw2, float* db2, float* workspace, int B, int C, int Cse, float inv_hw,
                        effdet_stream_t stream);
