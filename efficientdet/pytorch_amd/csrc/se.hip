@@ -305,19 +305,32 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const T* __restrict__ dy,
 __global__ __launch_bounds__(256) void se_dgate_slabs_kernel(const float* __restrict__ slabs, const float* __restrict__ w,
                                                              const float* __restrict__ bn_scale, const float* __restrict__ rowscale,
                                                              float* __restrict__ out, int q, int Co, int Ce) {
-  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (c >= Ce) return;
+  // workgroup = (32 channels, image); thread (channel lane, part) walks every 8th (slab, output-channel) pair with two chains in
+  // flight (the first version, one thread per channel over all q*Co pairs, was a 400-long dependent chain: 34 us per launch);
+  // the 8 parts meet in LDS and are added in part order -- fixed pattern, bitwise reproducible
+  __shared__ float part[8][32];
+  const int cl = threadIdx.x & 31, pt = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl, b = blockIdx.y;
+  const int total = q * Co;
   float s0 = 0.f, s1 = 0.f;
-  for (int i = 0; i < q; ++i) {
-    const float* sl = slabs + ((long long)b * q + i) * Co * Ce + c;
-    int n = 0;
-    for (; n + 1 < Co; n += 2) {
-      s0 = fmaf(sl[(long long)n * Ce], w[(long long)n * Ce + c] * bn_scale[n], s0);
-      s1 = fmaf(sl[(long long)(n + 1) * Ce], w[(long long)(n + 1) * Ce + c] * bn_scale[n + 1], s1);
+  if (c < Ce) {
+    const float* base = slabs + (long long)b * q * Co * Ce + c;         // slab (b*q + i), row n  ->  base + (i*Co + n) * Ce
+    int t = pt;
+    for (; t + 8 < total; t += 16) {
+      const int n0 = t % Co, n1 = (t + 8) % Co;
+      s0 = fmaf(base[(long long)t * Ce], w[(long long)n0 * Ce + c] * bn_scale[n0], s0);
+      s1 = fmaf(base[(long long)(t + 8) * Ce], w[(long long)n1 * Ce + c] * bn_scale[n1], s1);
     }
-    if (n < Co) s0 = fmaf(sl[(long long)n * Ce], w[(long long)n * Ce + c] * bn_scale[n], s0);
+    if (t < total) { const int n0 = t % Co; s0 = fmaf(base[(long long)t * Ce], w[(long long)n0 * Ce + c] * bn_scale[n0], s0); }
   }
-  out[(long long)b * Ce + c] = (s0 + s1) * (rowscale ? rowscale[b] : 1.0f);
+  part[pt][cl] = s0 + s1;
+  __syncthreads();
+  if (pt == 0 && c < Ce) {
+    float t = part[0][cl];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += part[k][cl];
+    out[(long long)b * Ce + c] = t * (rowscale ? rowscale[b] : 1.0f);
+  }
 }
 
 // ---- dz = (dy*gate + dpool) * swish'(z) ----
@@ -502,7 +515,7 @@ extern "C" int effdet_se_dgate_slabs(long long HW) { return se_dgate_slabs(HW); 
 extern "C" int effdet_se_dgate_from_wgrad(const float* slabs, const float* w_oc, const float* bn_scale, const float* rowscale,
                                           float* dgate_times_gate, int B, int q, int Cout, int Cexp, effdet_stream_t stream) {
   if (!slabs || !w_oc || !bn_scale || !dgate_times_gate || B < 1 || q < 1 || Cout < 1 || Cexp < 1) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(se_dgate_slabs_kernel, dim3((Cexp + 255) / 256, B), dim3(256), 0, ST, slabs, w_oc, bn_scale, rowscale, dgate_times_gate, q,
+  hipLaunchKernelGGL(se_dgate_slabs_kernel, dim3((Cexp + 31) / 32, B), dim3(256), 0, ST, slabs, w_oc, bn_scale, rowscale, dgate_times_gate, q,
                      Cout, Cexp);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;

@@ -88,9 +88,10 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
     B, H, W = x.B, x.H, x.W
     sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale}
     dw_in_act = ACT_NONE
+    Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
     if blk.expand != 1:
         s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
-        if train and EXPAND_Z_ONLY:
+        if train and EXPAND_Z_ONLY and Ho * Wo > 64:      # (<= 8x8 maps: the direct weight-gradient kernel would Swish every tap load)
             # training stores ONE tensor for the expand conv, its pre-activation: the depthwise forward / weight-gradient kernels
             # Swish their staged tiles (the two streams y_e, z_e were 35 % of the backbone's forward writes)
             ze = Map.new(B, H, W, blk.cexp, dtype, dev)
@@ -107,7 +108,6 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
         xe = x
     s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
     wk = ops.dw_pack_weight(P['dw.weight'])
-    Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
     # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):
     # the gate multiply and the backward of the gate recompute Swish from it
     z_only = train and not DW_SAVE_Y
