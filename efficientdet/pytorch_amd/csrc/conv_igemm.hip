@@ -420,7 +420,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
       // per-(image, channel) affine: the squeeze-excite backward fused into the project conv's data gradient --
       // dz_d = (dxs * gate[b][c] + dpool[b][c]) * swish'(z_d) with res = z_d, RES_SWISH_GRAD (functional.mbconv_bwd)
       const long long bo = (long long)bi * p.Cout + n0;
-      for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) v[r] = fmaf(v[r], p.bc_scale[bo + r], p.bc_shift[bo + r]);
+      if (n0 + 3 < p.Cout && (p.Cout & 3) == 0) v = v * *(const f32x4*)(p.bc_scale + bo) + *(const f32x4*)(p.bc_shift + bo);     // (16-byte loads: 8 dword loads per group made the epilogue latency-bound)
+      else
+        for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) v[r] = fmaf(v[r], p.bc_scale[bo + r], p.bc_shift[bo + r]);
     }
     if constexpr (SPLIT == 2) {
       if (p.out_split) {
@@ -973,6 +975,90 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Skinny pointwise conv for fp32 storage: y[m][n] = epilogue(sum_k x[m][k] * w[n][k]) with K = Cin in {16, 24} and 32..1024 output
+// channels over >= 64 k pixels -- the MBConv expand convs of the high-resolution blocks and (same shape class) the project convs'
+// data gradients.  On the 128 x 128 MFMA tile those launches are ONE K-step behind a DMA round trip and an epilogue whose stores
+// are 64-byte pieces of a pixel row (16 pixels x 4 channel groups per instruction): 1.5-2.6 TB/s of the 0.6-0.9 GB they move.
+// Here the matrix pipe is not used at all (1.5-3.5 k MACs per pixel: VALU work of the same order as the HBM time): a thread owns 4
+// consecutive output channels -- its 4 x K weights live in registers for the whole launch -- and walks pixels; lanes are laid out
+// (channel group fastest, then pixel slot) so that a wave's 16-byte stores cover whole consecutive pixel rows (fully coalesced 1 KiB
+// per instruction) and its x loads collapse to one or two cache lines per pixel.  Same fused epilogue as the MFMA kernels.
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_pw_f32_kernel(const ConvK p, long long M, int G, int NPS, int ppw) {
+  const int t = threadIdx.x, g = t % G, ps = t / G;
+  if (ps >= NPS) return;
+  const int n0 = 4 * g;
+  const SegD sg = p.seg[0];
+  const int HoWo = sg.Ho * sg.Wo;
+  float w[4][CIN];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < CIN; k += 4) {
+      const f32x4 v = *(const f32x4*)((const float*)p.w + (long long)(n0 + c) * CIN + k);
+      w[c][k] = v[0]; w[c][k + 1] = v[1]; w[c][k + 2] = v[2]; w[c][k + 3] = v[3];
+    }
+  f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.scale) sc = *(const f32x4*)(p.scale + n0);
+  if (p.shift) sh = *(const f32x4*)(p.shift + n0);
+  const float* xb = (const float*)p.x + sg.in_off;
+  const long long m0 = (long long)blockIdx.x * ppw, m1 = m0 + ppw < M ? m0 + ppw : M;
+  auto ldx = [&](long long m, f32x4 (&xv)[CIN / 4]) {
+#pragma unroll
+    for (int k = 0; k < CIN / 4; ++k) xv[k] = *(const f32x4*)(xb + m * CIN + 4 * k);
+  };
+  f32x4 xa[CIN / 4], xn[CIN / 4];
+  long long m = m0 + ps;
+  if (m < m1) ldx(m, xa);
+  for (; m < m1; m += NPS) {
+    const long long mn = m + NPS;
+    if (mn < m1) ldx(mn, xn);                     // next pixel's row in flight under this pixel's FMAs
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < CIN / 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xs_ = xa[k][j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = fmaf(w[c][4 * k + j], xs_, v[c]);
+      }
+    v = v * sc + sh;
+    const long long o = sg.out_off + m * p.ldy + n0;
+    if (p.z) *(f32x4*)((float*)p.z + o) = v;
+    if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+    else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+    else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+    if (p.rowscale || p.bc_scale) {
+      const int bi = (int)(m / HoWo);
+      if (p.rowscale) v *= p.rowscale[bi];
+      if (p.bc_scale) { const long long bo = (long long)bi * p.Cout + n0; v = v * *(const f32x4*)(p.bc_scale + bo) + *(const f32x4*)(p.bc_shift + bo); }
+    }
+    if (p.res_mode != EFFDET_RES_NONE) {
+      const f32x4 q = *(const f32x4*)((const float*)p.res + o);
+      if (p.res_mode == EFFDET_RES_ADD) { v += q; }
+      else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
+      else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
+    }
+    *(f32x4*)((float*)p.y + o) = v;
+#pragma unroll
+    for (int k = 0; k < CIN / 4; ++k) xa[k] = xn[k];
+  }
+}
+
+// Is this descriptor one for the skinny kernel?  (plain fp32 1x1 stride-1 conv over ONE contiguous level, Cin 16 or 24, whole
+// 4-channel groups, >= 64 k pixels; A/B switch: env EFFDET_CONV_PW=0)
+static bool pw_eligible(const effdet_conv_t* p) {
+  static const int on = getenv("EFFDET_CONV_PW") ? atoi(getenv("EFFDET_CONV_PW")) : 1;
+  if (!on || p->dtype != EFFDET_F32 || p->out_f32 || p->nseg != 1 || p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad_t || p->pad_l) return false;
+  if ((p->Cin != 16 && p->Cin != 24) || p->Cout % 4 || p->Cout < 32 || p->Cout > 1024) return false;
+  const effdet_seg_t& g = p->seg[0];
+  if (g.H != g.Ho || g.W != g.Wo || p->ldx != p->Cin || p->ldy != p->Cout) return false;
+  if (g.in_bstride != (long long)g.H * g.W * p->ldx || g.out_bstride != (long long)g.Ho * g.Wo * p->ldy) return false;
+  if (g.in_off % 4 || g.out_off % 4) return false;
+  return (long long)p->B * g.H * g.W >= 65536;
+}
+
 // tile_start of every segment in units of BM-row tiles; returns the total
 static int retile(ConvK& k, int bm) {
   int tiles = 0;
@@ -1143,6 +1229,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       }
     }
   }
+  if (pw_eligible(p)) return 20;
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
   if (p->dtype == EFFDET_F32_SPLIT) {
@@ -1183,6 +1270,15 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     default: break;
   }
   if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
+  if (id == 20) {
+    const long long M = (long long)k.seg[0].M;
+    const int G = k.Cout / 4, NPS = 256 / G, ppw = NPS * 32;          // 32 pixels per thread and workgroup
+    const unsigned grid = (unsigned)((M + ppw - 1) / ppw);
+    if (k.Cin == 16) hipLaunchKernelGGL(conv_pw_f32_kernel<16>, dim3(grid), dim3(256), 0, st, k, M, G, NPS, ppw);
+    else hipLaunchKernelGGL(conv_pw_f32_kernel<24>, dim3(grid), dim3(256), 0, st, k, M, G, NPS, ppw);
+    EFFDET_CHECK_LAUNCH();
+    return EFFDET_OK;
+  }
   if (id == 8 || id == 9) {
     k.ntiles = (k.Cout + (id == 8 ? 127 : 63)) / (id == 8 ? 128 : 64);
     static const int m32 = getenv("EFFDET_SPLIT_M32") ? atoi(getenv("EFFDET_SPLIT_M32")) : 0;      // A/B switch: 32x32x16 tiles (measured 342-360 TFLOP/s) vs 16x16x32 (370-390)

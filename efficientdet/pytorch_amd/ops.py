@@ -85,6 +85,8 @@ def _igemm_symbol(dtype, desc):
     kid = int(L.lib().effdet_conv2d_kernel(C.byref(desc)))
     if kid >= 10000:
         return 'conv_igemm_pers_kernel<split,bf16x3>'
+    if kid == 20:
+        return 'conv_pw_f32_kernel'
     if kid >= 10:
         v = str(kid - 10)
         return 'conv_igemm_pers_kernel<%s,%s,%s>' % (v[0], v[1], v[2])

@@ -345,3 +345,48 @@ def test_dgrad_via_flipped_weights(dtype):
     ops.conv2d(dzm, wd, dxm, Cin=Cout, Cout=Cin, KH=3, KW=3, pad_t=1, pad_l=1)
     torch.cuda.synchronize()
     assert_close(dxm.tensor().float().cpu().permute(0, 3, 1, 2), x.grad, _tol(dtype), 'dgrad')
+
+
+@pytest.mark.parametrize('Cin,Cout', [(16, 96), (24, 144), (16, 32), (24, 96)])
+def test_conv_pw_skinny_kernel(Cin, Cout):
+    """The VALU 'skinny' pointwise kernel (fp32, Cin 16 / 24, >= 64 k pixels: MBConv expand convs of the high-resolution blocks and
+    the project convs' data gradients) == torch on every epilogue it serves: BN + Swish with the saved pre-activation, z-only
+    (act NONE), and the fused squeeze-excite backward form (row scale, per-(image, channel) affine, Swish' of a residual)."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    B, H, W = 5, 128, 104                                       # 66 560 pixels, not a multiple of the per-workgroup pixel count
+    g = torch.Generator().manual_seed(Cin * 1000 + Cout)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    scale = 0.5 + torch.rand(Cout, generator=g); shift = torch.randn(Cout, generator=g) * 0.3
+    c = (x.reshape(-1, Cin) @ w.view(Cout, Cin).t()).view(B, H, W, Cout)
+    z = c * scale + shift
+    dev = 'cuda'
+    xm = Map.of(x.to(dev)); wp = ops.pack_weight(w.to(dev), torch.float32)
+
+    def run(**kw):
+        ym = Map.new(B, H, W, Cout, torch.float32, dev)
+        ops.PROFILE = ops.LaunchProfile()
+        try:
+            ops.conv2d(xm, wp, ym, Cin=Cin, Cout=Cout, KH=1, KW=1, **kw)
+            torch.cuda.synchronize()
+            assert ops.PROFILE.records[0][0] == 'conv_pw_f32_kernel', ops.PROFILE.records[0][0]
+        finally:
+            ops.PROFILE = None
+        return ym.tensor().cpu()
+    # (a) inference / save-y training form: BN affine + Swish, pre-activation saved
+    zm = Map.new(B, H, W, Cout, torch.float32, dev)
+    y = run(scale=scale.to(dev), shift=shift.to(dev), act=ops.ACT_SWISH, zs=zm)
+    assert_close(y, z * torch.sigmoid(z), 2e-4, 'pw swish'); assert_close(zm.tensor().cpu(), z, 2e-4, 'pw z')
+    # (b) z-only training form
+    assert_close(run(scale=scale.to(dev), shift=shift.to(dev), act=ops.ACT_NONE), z, 2e-4, 'pw z-only')
+    # (c) fused squeeze-excite backward: (rs_b * conv * gate[b][n] + dpool[b][n]) * swish'(res)
+    rs = torch.rand(B, generator=g) + 0.5
+    gate = torch.rand(B, Cout, generator=g); dpool = torch.randn(B, Cout, generator=g) * 0.1
+    res = torch.randn(B, H, W, Cout, generator=g)
+    sg = torch.sigmoid(res)
+    ref = (c * rs.view(B, 1, 1, 1) * gate.view(B, 1, 1, Cout) + dpool.view(B, 1, 1, Cout)) * (sg * (1 + res * (1 - sg)))
+    got = run(rowscale=rs.to(dev), bc_scale=gate.to(dev), bc_shift=dpool.to(dev), res=Map.of(res.to(dev)), res_mode=ops.RES_SWISH_GRAD)
+    assert_close(got, ref, 2e-4, 'pw fused se backward')
+    # (d) identity-skip residual add
+    assert_close(run(res=Map.of(res.to(dev)), res_mode=ops.RES_ADD), c + res, 2e-4, 'pw res add')
