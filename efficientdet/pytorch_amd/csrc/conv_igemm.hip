@@ -985,64 +985,88 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
 // (channel group fastest, then pixel slot) so that a wave's 16-byte stores cover whole consecutive pixel rows (fully coalesced 1 KiB
 // per instruction) and its x loads collapse to one or two cache lines per pixel.  Same fused epilogue as the MFMA kernels.
 template <int CIN>
-__global__ __launch_bounds__(256) void conv_pw_f32_kernel(const ConvK p, long long M, int G, int NPS, int ppw) {
+__global__ __launch_bounds__(256) void conv_pw_f32_kernel(const ConvK p, int M, int G, int NPS, int ppw) {
+  // x tiles of TP pixels go through LDS, double-buffered: the next tile's global loads are issued BEFORE this tile's FMAs (one
+  // or two 16-byte loads per thread, coalesced) and written to LDS after them, so HBM latency hides under a whole tile of work;
+  // the threads of a pixel then read its row as LDS broadcasts.  (The first version read x straight from global, one pixel ahead:
+  // 15.8 TFLOP/s of VALU work at 2-3 waves / SIMD -- latency-bound.)
+  constexpr int TP = 64, C4 = CIN / 4, TQ = TP * C4;               // pixels per tile, 16-byte chunks per pixel / per tile
+  constexpr int LPT = (TQ + 255) / 256;                            // chunks a thread stages per tile
+  __shared__ f32x4 xt[2][TQ];
+  typedef float f32x2v __attribute__((ext_vector_type(2)));
   const int t = threadIdx.x, g = t % G, ps = t / G;
-  if (ps >= NPS) return;
-  const int n0 = 4 * g;
+  const bool active = ps < NPS;
+  const int n0 = active ? 4 * g : 0;
   const SegD sg = p.seg[0];
   const int HoWo = sg.Ho * sg.Wo;
-  float w[4][CIN];
+  // weights of channels n0..n0+3 as two packed pairs per k (v_pk_fma_f32: two FMAs per lane and instruction)
+  f32x2v w01[CIN], w23[CIN];
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int k = 0; k < CIN; k += 4) {
+    const f32x4 a0 = *(const f32x4*)((const float*)p.w + (long long)(n0 + 0) * CIN + k), a1 = *(const f32x4*)((const float*)p.w + (long long)(n0 + 1) * CIN + k);
+    const f32x4 a2 = *(const f32x4*)((const float*)p.w + (long long)(n0 + 2) * CIN + k), a3 = *(const f32x4*)((const float*)p.w + (long long)(n0 + 3) * CIN + k);
 #pragma unroll
-    for (int k = 0; k < CIN; k += 4) {
-      const f32x4 v = *(const f32x4*)((const float*)p.w + (long long)(n0 + c) * CIN + k);
-      w[c][k] = v[0]; w[c][k + 1] = v[1]; w[c][k + 2] = v[2]; w[c][k + 3] = v[3];
-    }
+    for (int j = 0; j < 4; ++j) { w01[k + j] = f32x2v{a0[j], a1[j]}; w23[k + j] = f32x2v{a2[j], a3[j]}; }
+  }
   f32x4 sc = f32x4{1.f, 1.f, 1.f, 1.f}, sh = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.scale) sc = *(const f32x4*)(p.scale + n0);
   if (p.shift) sh = *(const f32x4*)(p.shift + n0);
-  const float* xb = (const float*)p.x + sg.in_off;
-  const long long m0 = (long long)blockIdx.x * ppw, m1 = m0 + ppw < M ? m0 + ppw : M;
-  auto ldx = [&](long long m, f32x4 (&xv)[CIN / 4]) {
+  const f32x4* xb = (const f32x4*)((const float*)p.x + sg.in_off);
+  const int m0 = blockIdx.x * ppw, m1 = min(M, m0 + ppw);
+  const int ntile = (m1 - m0 + TP - 1) / TP;
+  f32x4 stg[LPT];
+  auto gload = [&](int tile) {                                     // tile's chunks -> registers (zeros past the end)
 #pragma unroll
-    for (int k = 0; k < CIN / 4; ++k) xv[k] = *(const f32x4*)(xb + m * CIN + 4 * k);
+    for (int i = 0; i < LPT; ++i) {
+      const int q = t + 256 * i, mq = m0 + tile * TP + q / C4;
+      stg[i] = (q < TQ && mq < m1) ? xb[(long long)mq * C4 + (q % C4)] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   };
-  f32x4 xa[CIN / 4], xn[CIN / 4];
-  long long m = m0 + ps;
-  if (m < m1) ldx(m, xa);
-  for (; m < m1; m += NPS) {
-    const long long mn = m + NPS;
-    if (mn < m1) ldx(mn, xn);                     // next pixel's row in flight under this pixel's FMAs
-    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto sstore = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < CIN / 4; ++k)
+    for (int i = 0; i < LPT; ++i) { const int q = t + 256 * i; if (q < TQ) xt[buf][q] = stg[i]; }
+  };
+  gload(0); sstore(0);
+  __syncthreads();
+  for (int tile = 0; tile < ntile; ++tile) {
+    const int cur = tile & 1;
+    if (tile + 1 < ntile) gload(tile + 1);
+    if (active) {
+      const int mt = m0 + tile * TP;
+      for (int pl = ps; pl < TP && mt + pl < m1; pl += NPS) {
+        const int m = mt + pl;
+        const long long o = sg.out_off + (long long)m * p.ldy + n0;
+        f32x4 q = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.res_mode != EFFDET_RES_NONE) q = *(const f32x4*)((const float*)p.res + o);      // issued ahead of the FMAs
+        f32x2v a01 = f32x2v{0.f, 0.f}, a23 = f32x2v{0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float xs_ = xa[k][j];
+        for (int k = 0; k < C4; ++k) {
+          const f32x4 xv = xt[cur][pl * C4 + k];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = fmaf(w[c][4 * k + j], xs_, v[c]);
+          for (int j = 0; j < 4; ++j) {
+            const f32x2v xx = f32x2v{xv[j], xv[j]};
+            a01 = __builtin_elementwise_fma(w01[4 * k + j], xx, a01);
+            a23 = __builtin_elementwise_fma(w23[4 * k + j], xx, a23);
+          }
+        }
+        f32x4 v = f32x4{a01[0], a01[1], a23[0], a23[1]} * sc + sh;
+        if (p.z) *(f32x4*)((float*)p.z + o) = v;
+        if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
+        else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
+        else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
+        if (p.rowscale || p.bc_scale) {
+          const int bi = m / HoWo;
+          if (p.rowscale) v *= p.rowscale[bi];
+          if (p.bc_scale) { const int bo = bi * p.Cout + n0; v = v * *(const f32x4*)(p.bc_scale + bo) + *(const f32x4*)(p.bc_shift + bo); }
+        }
+        if (p.res_mode == EFFDET_RES_ADD) { v += q; }
+        else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
+        else if (p.res_mode == EFFDET_RES_SWISH_GRAD) { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
+        *(f32x4*)((float*)p.y + o) = v;
       }
-    v = v * sc + sh;
-    const long long o = sg.out_off + m * p.ldy + n0;
-    if (p.z) *(f32x4*)((float*)p.z + o) = v;
-    if (p.act == EFFDET_ACT_RELU) { for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f); }
-    else if (p.act == EFFDET_ACT_SWISH) { for (int r = 0; r < 4; ++r) v[r] = swishf_(v[r]); }
-    else if (p.act == EFFDET_ACT_SIGMOID) { for (int r = 0; r < 4; ++r) v[r] = sigmoidf_(v[r]); }
-    if (p.rowscale || p.bc_scale) {
-      const int bi = (int)(m / HoWo);
-      if (p.rowscale) v *= p.rowscale[bi];
-      if (p.bc_scale) { const long long bo = (long long)bi * p.Cout + n0; v = v * *(const f32x4*)(p.bc_scale + bo) + *(const f32x4*)(p.bc_shift + bo); }
     }
-    if (p.res_mode != EFFDET_RES_NONE) {
-      const f32x4 q = *(const f32x4*)((const float*)p.res + o);
-      if (p.res_mode == EFFDET_RES_ADD) { v += q; }
-      else if (p.res_mode == EFFDET_RES_RELU_MASK) { for (int r = 0; r < 4; ++r) v[r] = q[r] > 0.f ? v[r] : 0.f; }
-      else { for (int r = 0; r < 4; ++r) v[r] *= swish_gradf_(q[r]); }
-    }
-    *(f32x4*)((float*)p.y + o) = v;
-#pragma unroll
-    for (int k = 0; k < CIN / 4; ++k) xa[k] = xn[k];
+    if (tile + 1 < ntile) sstore(cur ^ 1);
+    __syncthreads();
   }
 }
 
@@ -1271,8 +1295,8 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
   }
   if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
   if (id == 20) {
-    const long long M = (long long)k.seg[0].M;
-    const int G = k.Cout / 4, NPS = 256 / G, ppw = NPS * 32;          // 32 pixels per thread and workgroup
+    const int M = k.seg[0].M;
+    const int G = k.Cout / 4, NPS = 256 / G, ppw = 1024;               // 16 tiles of 64 pixels per workgroup
     const unsigned grid = (unsigned)((M + ppw - 1) / ppw);
     if (k.Cin == 16) hipLaunchKernelGGL(conv_pw_f32_kernel<16>, dim3(grid), dim3(256), 0, st, k, M, G, NPS, ppw);
     else hipLaunchKernelGGL(conv_pw_f32_kernel<24>, dim3(grid), dim3(256), 0, st, k, M, G, NPS, ppw);
