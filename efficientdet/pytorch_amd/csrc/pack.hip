@@ -76,28 +76,29 @@ __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_j
   }
 }
 
-// grid (Cout, chunks of the packed [tap][Cin_pad] row).  Threads walk the PACKED index so the (split-K) slab reads
-// are coalesced; the OIHW writes scatter inside one channel's few-KiB row (merged in L2).  With wsum the row is
-// handled by a single block (gridDim.y == 1) so the dot product needs no atomics.
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ g, const float* __restrict__ scale,
-                                                           const float* __restrict__ w, float* __restrict__ dw,
-                                                           float* __restrict__ wsum, int accumulate, int Cin, int KH, int KW,
-                                                           int Cin_pad, int nslabs, long long slab_stride,
-                                                           const float* __restrict__ dsum_part, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, float* __restrict__ dbias_out,
-                                                           const float* __restrict__ slab_scale, int slabs_per_scale) {
+// One workgroup = (output channel co, chunk `by` of `gy` of the packed [tap][Cin_pad] row) of one unpack job.  Threads walk the
+// PACKED index so the (split-K) slab reads are coalesced; the OIHW writes scatter inside one channel's few-KiB row (merged in
+// L2).  With wsum / dgamma the row is handled by a single workgroup (gy == 1) so the dot product needs no atomics.
+__device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const int co, const int by, const int gy) {
+  const float* __restrict__ g = j.g; const float* __restrict__ scale = j.scale; const float* __restrict__ w = j.w_oihw;
+  float* __restrict__ dw = j.dw_oihw; float* __restrict__ wsum = j.wsum;
+  const float* __restrict__ dsum_part = j.dsum_part; const float* __restrict__ mean = j.mean; const float* __restrict__ invstd = j.invstd;
+  float* __restrict__ dgamma = j.dgamma; float* __restrict__ dbeta = j.dbeta; float* __restrict__ dbias_out = j.dbias_out;
+  const float* __restrict__ slab_scale = j.slab_scale;
+  const int accumulate = j.accumulate, Cin = j.Cin, KH = j.KH, KW = j.KW, Cin_pad = j.Cin_pad, nslabs = j.nslabs;
+  const int slabs_per_scale = j.slabs_per_scale > 0 ? j.slabs_per_scale : 1, Cout = j.Cout;
+  const long long slab_stride = (long long)Cout * KH * KW * Cin_pad;
   // slab_scale (optional): slab sl is multiplied by slab_scale[sl / slabs_per_scale] while summing -- per-image slabs
   // (effdet_wgrad_t.image_splits) x the drop_connect row scale of that image: dW = sum_b rs_b * M_b without a scaled copy of dz
   auto fac = [&](int sl) -> float { return slab_scale ? slab_scale[sl / slabs_per_scale] : 1.0f; };
-  const int co = blockIdx.x, taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
+  const int taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
   // sum_m dz[m][co]: the weight-gradient launch left one partial per split-K slab ([nslabs][Cout]); wave 0 adds them in a fixed
   // pattern (lane-strided, then the shuffle tree): no float atomics upstream or here, so the result is bitwise reproducible
   __shared__ float dsum_sh;
-  if (dsum_part && blockIdx.y == 0 && threadIdx.x < 64) {
+  if (dsum_part && by == 0 && threadIdx.x < 64) {
     float t = 0.f;
-    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * gridDim.x + co] * fac(sl);
+    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * Cout + co] * fac(sl);
     t = wave_sum(t);
     if (threadIdx.x == 0) { dsum_sh = t; if (dbias_out) dbias_out[co] = t; }
   }
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
     }
   };
   const int G = np >> 2;                                 // 16-byte groups per row (Cin_pad % 4 == 0)
-  if (G <= 128 && nslabs >= 8 && gridDim.y == 1) {
+  if (G <= 128 && nslabs >= 8 && gy == 1) {
     // Short rows with many split-K slabs (the high-resolution 1x1 convs: K = 16..144 against ~500 slabs): one thread
     // per group summing every slab serially left 4..36 lanes of the workgroup walking a 500-long dependent chain
     // (45 us for a few KiB).  Spread the slabs over 256/G thread slices and combine the slices through LDS.
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
   } else {
   // 4 consecutive packed elements (same tap, 4 channels: Cin_pad % 4 == 0) per thread, 16-byte slab loads,
   // slab loop unrolled x4 so the loads of different slabs are in flight together
-  for (int q4 = blockIdx.y * 256 + threadIdx.x; q4 * 4 < np; q4 += gridDim.y * 256) {
+  for (int q4 = by * 256 + threadIdx.x; q4 * 4 < np; q4 += gy * 256) {
     const int pidx = q4 * 4;
     f32x4 a0 = *(const f32x4*)(grow + pidx) * fac(0), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     int sl = 1;
@@ -167,6 +168,21 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
       }
     }
   }
+}
+
+// one job per launch: grid (Cout, gy)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const effdet_unpack_job_t j) { unpack_row(j, blockIdx.x, blockIdx.y, gridDim.y); }
+
+// Up to UNPACK_MAXJ jobs per launch, the descriptors passed BY VALUE in the kernel arguments (no table upload, nothing to keep
+// alive): a backward node of the model used to end with 2..34 of the launches above, each a few KiB of work behind a chain of
+// dependent slab loads (8-10 us apiece for ~1 us of traffic); batched, the chains of all jobs overlap.
+constexpr int UNPACK_MAXJ = 24;
+struct UnpackBatch { int njobs; int first[UNPACK_MAXJ + 1]; int gy[UNPACK_MAXJ]; effdet_unpack_job_t job[UNPACK_MAXJ]; };
+__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch bt) {
+  int ji = 0;
+  for (int q = 1; q < bt.njobs; ++q) if ((int)blockIdx.x >= bt.first[q]) ji = q;
+  const int local = blockIdx.x - bt.first[ji], gy = bt.gy[ji];
+  unpack_row(bt.job[ji], local / gy, local - (local / gy) * gy, gy);
 }
 
 template <typename T>
@@ -252,33 +268,59 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
   return EFFDET_OK;
 }
 
+namespace {
+int unpack_job_check(const effdet_unpack_job_t& j) {
+  if (j.slab_scale && (j.slabs_per_scale < 1 || j.nslabs % j.slabs_per_scale)) return EFFDET_EINVAL;
+  if (!j.g || !j.dw_oihw || ((j.wsum || j.dgamma) && !j.w_oihw) || j.Cout < 1 || j.Cin < 1 || j.KH < 1 || j.KW < 1 || j.Cin_pad < j.Cin ||
+      j.nslabs < 1 || (j.Cin_pad & 3)) return EFFDET_EINVAL;
+  if (!j.dgamma && j.dsum_part && !j.dbias_out) return EFFDET_EINVAL;          // partial rows without a consumer
+  if (j.dgamma && (!j.dbeta || !j.dsum_part || !j.mean || !j.invstd)) return EFFDET_EINVAL;
+  if (j.dbias_out && !j.dsum_part) return EFFDET_EINVAL;
+  return EFFDET_OK;
+}
+inline int unpack_gy(const effdet_unpack_job_t& j) { return (j.wsum || j.dgamma) ? 1 : (j.KH * j.KW * j.Cin_pad / 4 + 255) / 256; }
+}  // namespace
+
+extern "C" int effdet_unpack_conv_wgrad_batch(const effdet_unpack_job_t* jobs, int njobs, effdet_stream_t stream) {
+  if (!jobs || njobs < 1) return EFFDET_EINVAL;
+  for (int i = 0; i < njobs; ++i) { const int rc = unpack_job_check(jobs[i]); if (rc != EFFDET_OK) return rc; }
+  for (int i0 = 0; i0 < njobs; i0 += UNPACK_MAXJ) {
+    const int nj = njobs - i0 < UNPACK_MAXJ ? njobs - i0 : UNPACK_MAXJ;
+    if (nj == 1) {
+      hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(jobs[i0].Cout, unpack_gy(jobs[i0])), dim3(256), 0, (hipStream_t)stream, jobs[i0]);
+    } else {
+      UnpackBatch bt; bt.njobs = nj; int blocks = 0;
+      for (int q = 0; q < nj; ++q) { bt.job[q] = jobs[i0 + q]; bt.gy[q] = unpack_gy(jobs[i0 + q]); bt.first[q] = blocks; blocks += jobs[i0 + q].Cout * bt.gy[q]; }
+      bt.first[nj] = blocks;
+      hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+    }
+    EFFDET_CHECK_LAUNCH();
+  }
+  return EFFDET_OK;
+}
+
 extern "C" int effdet_unpack_conv_wgrad(const float* g, const float* scale, const float* w, float* dw, float* wsum,
                                         int accumulate, int Cout, int Cin, int KH, int KW, int Cin_pad, int nslabs,
                                         const float* dbias_part, float* dbias_out, const float* slab_scale, int slabs_per_scale,
                                         effdet_stream_t stream) {
-  if (slab_scale && (slabs_per_scale < 1 || nslabs % slabs_per_scale)) return EFFDET_EINVAL;
-  if (!g || !dw || (wsum && !w) || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3) || (!dbias_part != !dbias_out)) return EFFDET_EINVAL;
-  const int np = KH * KW * Cin_pad;
-  const int gy = wsum ? 1 : (np / 4 + 255) / 256;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, gy), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, wsum, accumulate, Cin, KH, KW,
-                     Cin_pad, nslabs, (long long)Cout * np, dbias_part, (const float*)nullptr, (const float*)nullptr,
-                     (float*)nullptr, (float*)nullptr, dbias_out, slab_scale, slab_scale ? slabs_per_scale : 1);
-  EFFDET_CHECK_LAUNCH();
-  return EFFDET_OK;
+  if (!dbias_part != !dbias_out) return EFFDET_EINVAL;
+  effdet_unpack_job_t j = {};
+  j.g = g; j.scale = scale; j.w_oihw = w; j.dw_oihw = dw; j.wsum = wsum; j.dsum_part = dbias_part; j.dbias_out = dbias_out;
+  j.slab_scale = slab_scale; j.accumulate = accumulate; j.Cout = Cout; j.Cin = Cin; j.KH = KH; j.KW = KW; j.Cin_pad = Cin_pad;
+  j.nslabs = nslabs; j.slabs_per_scale = slab_scale ? slabs_per_scale : 1;
+  return effdet_unpack_conv_wgrad_batch(&j, 1, stream);
 }
 
 extern "C" int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float* w, float* dw, const float* dsum_part,
                                            const float* mean, const float* invstd, float* dgamma, float* dbeta, int Cout,
                                            int Cin, int KH, int KW, int Cin_pad, int nslabs, const float* slab_scale,
                                            int slabs_per_scale, effdet_stream_t stream) {
-  if (slab_scale && (slabs_per_scale < 1 || nslabs % slabs_per_scale)) return EFFDET_EINVAL;
-  if (!g || !dw || !w || !dsum_part || !mean || !invstd || !dgamma || !dbeta || Cin_pad < Cin || nslabs < 1 || (Cin_pad & 3)) return EFFDET_EINVAL;
-  const int np = KH * KW * Cin_pad;
-  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(Cout, 1), dim3(256), 0, (hipStream_t)stream, g, scale, w, dw, (float*)nullptr, 0, Cin, KH,
-                     KW, Cin_pad, nslabs, (long long)Cout * np, dsum_part, mean, invstd, dgamma, dbeta, (float*)nullptr, slab_scale,
-                     slab_scale ? slabs_per_scale : 1);
-  EFFDET_CHECK_LAUNCH();
-  return EFFDET_OK;
+  if (!w || !dsum_part || !mean || !invstd || !dgamma || !dbeta) return EFFDET_EINVAL;
+  effdet_unpack_job_t j = {};
+  j.g = g; j.scale = scale; j.w_oihw = w; j.dw_oihw = dw; j.dsum_part = dsum_part; j.mean = mean; j.invstd = invstd; j.dgamma = dgamma;
+  j.dbeta = dbeta; j.slab_scale = slab_scale; j.Cout = Cout; j.Cin = Cin; j.KH = KH; j.KW = KW; j.Cin_pad = Cin_pad;
+  j.nslabs = nslabs; j.slabs_per_scale = slab_scale ? slabs_per_scale : 1;
+  return effdet_unpack_conv_wgrad_batch(&j, 1, stream);
 }
 
 extern "C" int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream) {

@@ -154,6 +154,19 @@ int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float*
                                 int KH, int KW, int Cin_pad, int nslabs, const float* slab_scale, int slabs_per_scale,
                                 effdet_stream_t stream);
 
+/* The two calls above as ONE descriptor, and any number of them in one launch (the descriptors travel in the kernel arguments,
+ * 24 per launch): a backward node of the model ends with 2 (MBConv) .. 34 (the BiFPN stack) of these few-KiB unpacks, each a
+ * chain of dependent slab loads -- batched, the chains overlap (63 -> 20 launches per D0 train step).
+ * Fields as in effdet_unpack_conv_wgrad / _bn: dgamma != NULL selects the frozen-BN form (dsum_part, mean, invstd, dbeta, w_oihw
+ * required), dbias_out != NULL the bias form (dsum_part = the [nslabs][Cout] partial rows), wsum as above; unused pointers NULL. */
+typedef struct {
+  const float* g; const float* scale; const float* w_oihw; float* dw_oihw; float* wsum;
+  const float* dsum_part; const float* mean; const float* invstd; float* dgamma; float* dbeta; float* dbias_out;
+  const float* slab_scale;
+  int accumulate, Cout, Cin, KH, KW, Cin_pad, nslabs, slabs_per_scale;
+} effdet_unpack_job_t;
+int effdet_unpack_conv_wgrad_batch(const effdet_unpack_job_t* jobs, int njobs, effdet_stream_t stream);
+
 /* Batched parameter preparation: every per-step repack of the model's parameters in ONE launch (a D0 train step
  * issued ~190 of these 4-microsecond kernels one by one: 125 weight packs, 48 BN folds, 16 depthwise packs).
  * A job is one of

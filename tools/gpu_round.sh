@@ -33,7 +33,7 @@ for s in $STEPS; do
             python tools/pmc_summary.py $OUT/pmc_bf16x3.json f32_bf16x3 $OUT/none $OUT/none $OUT/pmcx_SQ > $OUT/pmcx_summary.log 2>&1; cat $OUT/pmcx_summary.log; rm -rf $OUT/pmcx_SQ ;;
     statsx3) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_x3 -o run -- python /root/repo/bench.py --dtype f32_bf16x3 --no-cpu-baseline --no-inference --no-parity-mode --no-roofline --steps 6 --warmup 2 > /root/repo/$OUT/stats_x3.log 2>&1); echo "stats_x3 rc=$?" | tee -a $OUT/rc.txt ;;
     statsinf) (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /root/repo/$OUT/stats_infer -o run -- python /root/repo/tools/infer_bench.py --network efficientdet-d0 --batch 32 --size 512 --reps 5 > /root/repo/$OUT/stats_infer.log 2>&1); echo "stats_infer rc=$?" | tee -a $OUT/rc.txt ;;
-    bw)     timeout 300 python tools/bw_calib.py > $OUT/bw_calib.txt 2>&1; cat $OUT/bw_calib.txt
+    bw)     hipcc --offload-arch=gfx950 -O3 -o /tmp/stream_bw tools/probe/stream_bw.hip > /dev/null 2>&1 && timeout 120 /tmp/stream_bw > $OUT/stream_bw.txt 2>&1; cat $OUT/stream_bw.txt
             hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/probe/mfma_peak.hip > /dev/null 2>&1 && timeout 120 /tmp/mfma_peak > $OUT/mfma_peak.txt 2>&1; cat $OUT/mfma_peak.txt ;;
     *)      echo "unknown step $s" ;;
   esac
