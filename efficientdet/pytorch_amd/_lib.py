@@ -50,11 +50,17 @@ class PrepJob(C.Structure):      # effdet_prep_job_t
                 ('n4', C.c_int), ('eps', C.c_float)]
 
 
+class UnpackJob(C.Structure):    # effdet_unpack_job_t
+    _fields_ = [(n, C.c_void_p) for n in ('g', 'scale', 'w_oihw', 'dw_oihw', 'wsum', 'dsum_part', 'mean', 'invstd', 'dgamma', 'dbeta',
+                                          'dbias_out', 'slab_scale')] + \
+               [(n, C.c_int) for n in ('accumulate', 'Cout', 'Cin', 'KH', 'KW', 'Cin_pad', 'nslabs', 'slabs_per_scale')]
+
+
 _lib = None
 
 # every symbol include/effdet_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
+    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',

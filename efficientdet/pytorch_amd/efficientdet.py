@@ -184,7 +184,8 @@ class _MBConvFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
-        dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
+        with ops.unpack_batch():                                   # the node's weight-gradient unpacks leave as one launch
+            dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
             ops.add_inplace(dx, Map.of(dy.contiguous()))
         keys = ctx.keys
@@ -220,10 +221,11 @@ class _NeckFn(torch.autograd.Function):
         feats, lw, saved_mods, dtype, nlev, stack = ctx.saved
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
-        for sv in reversed(saved_mods):
-            d, dw1, dw2, dcw, dcb = Fn.bifpn_module_bwd(sv, d, dtype)
-            mod_grads.append((dw1, dw2) + tuple(dcw) + tuple(dcb))
-        dfs, dlw, dlb = Fn.lateral_bwd(feats, lw, d, dtype)
+        with ops.unpack_batch():                                   # 8 unpacks per module + 5 laterals: two launches for the node
+            for sv in reversed(saved_mods):
+                d, dw1, dw2, dcw, dcb = Fn.bifpn_module_bwd(sv, d, dtype)
+                mod_grads.append((dw1, dw2) + tuple(dcw) + tuple(dcb))
+            dfs, dlw, dlb = Fn.lateral_bwd(feats, lw, d, dtype)
         ctx.saved = None
         out = (None, None, None, None) + tuple(_t(m) for m in dfs) + tuple(dlw) + tuple(dlb)
         for mg in reversed(mod_grads):
@@ -254,7 +256,8 @@ class _HeadFn(torch.autograd.Function):
         ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
         saved, cls, dtype = ctx.saved
         dlogit, dr = ops.head_out_bwd(dcls.contiguous().float(), cls, dreg.contiguous().float(), dtype)
-        dp, g = Fn.head_bwd(saved, dlogit, dr, dtype)
+        with ops.unpack_batch():
+            dp, g = Fn.head_bwd(saved, dlogit, dr, dtype)
         ctx.saved = None
         return (None, None, None) + tuple(Fn.level_tensor(m) for m in dp) + tuple(g[k] for k in _HEAD_KEYS)
 
@@ -293,7 +296,8 @@ class _HeadLossFn(torch.autograd.Function):
             split = saved[5]
             rld = 64 if split else 0                # split layout: d(reg) pixel-major, 36 -> 64 channels (two [hi|lo] groups)
             dreg = ops.focal_loss_bwd_reg(reg, anchors, annots, gscale, ws, dtype, reg_ld=rld, split=split)
-            dp, g = Fn.head_bwd(saved, dpix, dreg, dtype, dcls_ld=dld, cls_gscale=gscale[0:1], dreg_ld=rld, in_split=split)
+            with ops.unpack_batch():                               # the head's 10 weight-gradient unpacks: one launch
+                dp, g = Fn.head_bwd(saved, dpix, dreg, dtype, dcls_ld=dld, cls_gscale=gscale[0:1], dreg_ld=rld, in_split=split)
         else:
             nc = cls.shape[2]
             if nc % 4 == 0:      # d(logits) straight into the pixel-major, 64-channel-padded rows the head's gradient convs read
@@ -302,7 +306,8 @@ class _HeadLossFn(torch.autograd.Function):
             else:
                 dld = 0
                 dcls, dreg = ops.focal_loss_bwd(cls, reg, anchors, annots, gscale, ws, dtype)
-            dp, g = Fn.head_bwd(saved, dcls, dreg, dtype, dcls_ld=dld)
+            with ops.unpack_batch():
+                dp, g = Fn.head_bwd(saved, dcls, dreg, dtype, dcls_ld=dld)
         ctx.saved = None
         return (None, None, None, None, None) + tuple(Fn.level_tensor(m) for m in dp) + tuple(g[k] for k in _HEAD_KEYS)
 

@@ -409,11 +409,11 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
             elif Cfp != Cf:          # 9*num_classes (or 36) channels are not whole 16-byte chunks: zero-pad the rows
                 dzmaps = [ops.pad_rows(m, Cfp) for m in dzmaps]
         G, dbp = ops.conv2d_wgrad(acts[tower][3], dzmaps, Cin=256, Cout=Cf, KH=3, KW=3, pad_t=1, pad_l=1, split=split)
-        dw = torch.empty_like(wf); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
-        rows = None
-        if tower == 'cls' and cls_gscale is not None:
-            dw = dw * cls_gscale; db = db * cls_gscale
-            rows = cls_gscale.expand(B).contiguous()
+        # (cls_gscale: the class-loss gradient was written for an upstream gradient of one -- the upstream scalar multiplies the
+        #  slabs and bias partial rows inside the unpack, and the rows of the data gradient)
+        gs = cls_gscale if tower == 'cls' else None
+        dw = torch.empty_like(wf); db = ops.unpack_wgrad(G, dw, dbias_part=dbp, slab_scale=gs)
+        rows = gs.expand(B).contiguous() if gs is not None else None
         g[fin + '.weight'], g[fin + '.bias'] = dw, db
         # data gradient with the ReLU mask of the producing tower layer fused into the epilogue
         _, dz = pyramid_alloc(B, sizes, 256, dtype, dev)

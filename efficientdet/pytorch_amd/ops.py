@@ -4,6 +4,7 @@ Plumbing only: PyTorch owns the memory and the stream; every numeric op is a HIP
 libeffdet_hip.so.  No function here has a CPU path.
 """
 import ctypes as C
+import os
 import threading
 
 import torch
@@ -411,18 +412,78 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     return slabs, parts
 
 
+class _UnpackBatch:
+    """Deferred weight-gradient unpacks of one backward node (effdet_unpack_conv_wgrad_batch): inside ``with unpack_batch():``
+    unpack_wgrad / unpack_wgrad_bn only record a job (outputs are allocated right away, inputs stay referenced here) and the
+    whole list goes out as one launch per 24 jobs when the block exits.  Nothing inside the block may READ an unpack's outputs."""
+
+    def __init__(self):
+        self.jobs, self.keep = [], []
+
+    def add(self, job, *tensors):
+        self.jobs.append(job); self.keep.append(tensors)
+
+    def flush(self):
+        if self.jobs:
+            arr = (L.UnpackJob * len(self.jobs))(*self.jobs)
+            L.check(L.lib().effdet_unpack_conv_wgrad_batch(arr, len(self.jobs), L.stream_ptr()), 'effdet_unpack_conv_wgrad_batch')
+        self.jobs, self.keep = [], []
+
+
+_UNPACK_BATCH = None
+UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'
+
+
+class unpack_batch:
+    """Context manager: batch every unpack_wgrad / unpack_wgrad_bn issued inside into one launch at exit (re-entrant: an inner
+    block joins the outer one)."""
+
+    def __enter__(self):
+        global _UNPACK_BATCH
+        self.owner = _UNPACK_BATCH is None and UNPACK_BATCHED
+        if self.owner:
+            _UNPACK_BATCH = _UnpackBatch()
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _UNPACK_BATCH
+        if self.owner:
+            b, _UNPACK_BATCH = _UNPACK_BATCH, None
+            if et is None:
+                b.flush()
+        return False
+
+
+def _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, **ptrs):
+    j = L.UnpackJob()
+    j.g, j.dw_oihw, j.slab_scale = g.data_ptr(), dw.data_ptr(), (slab_scale.data_ptr() if slab_scale is not None else None)
+    for k, t in ptrs.items():
+        setattr(j, k, t.data_ptr() if t is not None else None)
+    j.Cout, j.Cin, j.KH, j.KW, j.Cin_pad, j.nslabs = Cout, Cin, KH, KW, (Cin if cin_pad is None else cin_pad), nslabs
+    j.slabs_per_scale = nslabs // slab_scale.numel() if slab_scale is not None else 1
+    return j
+
+
+def _unpack_submit(job, *tensors):
+    if _UNPACK_BATCH is not None:
+        _UNPACK_BATCH.add(job, *tensors)
+    else:
+        L.check(L.lib().effdet_unpack_conv_wgrad_batch(C.byref(job), 1, L.stream_ptr()), 'effdet_unpack_conv_wgrad_batch')
+
+
 def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=False, cin_pad=None, dbias_part=None, slab_scale=None):
     """g: packed gradient [Cout][taps][Cin_pad] or unreduced slabs [splits][Cout][taps][Cin_pad] (summed here).
-    dbias_part ([splits][Cout], from conv2d_wgrad): -> the bias gradient [Cout] (summed in slab order), else None."""
+    dbias_part ([splits][Cout], from conv2d_wgrad): -> the bias gradient [Cout] (summed in slab order), else None.
+    Inside ``with unpack_batch():`` the launch is deferred to the end of the block."""
     Cout, Cin, KH, KW = dw_oihw.shape
     nslabs = g.shape[0] if g.dim() == 4 else 1
     db = torch.empty(Cout, dtype=torch.float32, device=dw_oihw.device) if dbias_part is not None else None
     assert dbias_part is None or dbias_part.shape == (nslabs, Cout)
-    L.check(L.lib().effdet_unpack_conv_wgrad(L.ptr(g), L.ptr(scale), L.ptr(w_oihw), L.ptr(dw_oihw), L.ptr(wsum),
-                                             int(accumulate), Cout, Cin, KH, KW, Cin if cin_pad is None else cin_pad,
-                                             nslabs, L.ptr(dbias_part), L.ptr(db), L.ptr(slab_scale),
-                                             nslabs // slab_scale.numel() if slab_scale is not None else 1, L.stream_ptr()),
-            'effdet_unpack_conv_wgrad')
+    assert slab_scale is None or nslabs % slab_scale.numel() == 0
+    job = _unpack_job(g, dw_oihw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, scale=scale, w_oihw=w_oihw, wsum=wsum,
+                      dsum_part=dbias_part, dbias_out=db)
+    job.accumulate = int(accumulate)
+    _unpack_submit(job, g, dw_oihw, scale, w_oihw, wsum, dbias_part, db, slab_scale)
     return db
 
 
@@ -434,13 +495,13 @@ def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None, sla
     if dsum_part.dim() == 1:
         dsum_part = dsum_part.view(1, Cout)
     assert dsum_part.shape == (nslabs, Cout) and dsum_part.is_contiguous()
+    assert slab_scale is None or nslabs % slab_scale.numel() == 0
     dw = torch.empty_like(w_oihw)
     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dw.device)
-    L.check(L.lib().effdet_unpack_conv_wgrad_bn(L.ptr(g), L.ptr(scale), L.ptr(w_oihw.detach()), L.ptr(dw), L.ptr(dsum_part), L.ptr(mean),
-                                                L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cout, Cin, KH, KW,
-                                                Cin if cin_pad is None else cin_pad, nslabs, L.ptr(slab_scale),
-                                                nslabs // slab_scale.numel() if slab_scale is not None else 1, L.stream_ptr()),
-            'effdet_unpack_conv_wgrad_bn')
+    wd = w_oihw.detach()
+    job = _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, scale=scale, w_oihw=wd, dsum_part=dsum_part, mean=mean,
+                      invstd=invstd, dgamma=dgb[0], dbeta=dgb[1])
+    _unpack_submit(job, g, dw, scale, wd, dsum_part, mean, invstd, dgb, slab_scale)
     return dw, dgb[0], dgb[1]
 
 

@@ -390,3 +390,43 @@ def test_conv_pw_skinny_kernel(Cin, Cout):
     assert_close(got, ref, 2e-4, 'pw fused se backward')
     # (d) identity-skip residual add
     assert_close(run(res=Map.of(res.to(dev)), res_mode=ops.RES_ADD), c + res, 2e-4, 'pw res add')
+
+
+def test_batched_unpack_is_bitwise_the_single_launches():
+    """effdet_unpack_conv_wgrad_batch: 30 jobs of the three forms (bias rows, frozen-BN parameter gradients, per-image slab
+    scale; short and long rows, 1..40 slabs) in two launches == the same jobs launched one by one, bit for bit."""
+    torch.manual_seed(5)
+    dev = 'cuda'
+    shapes = [(64, 64, 3, 1), (64, 64, 3, 6), (256, 256, 3, 8), (24, 96, 1, 32), (96, 16, 1, 40), (40, 144, 1, 64), (36, 256, 3, 5),
+              (88, 40, 1, 3), (720, 256, 3, 2), (16, 32, 1, 128)] * 3
+    jobs = []
+    for i, (co, ci, k, ns) in enumerate(shapes):
+        cp = (ci + 3) // 4 * 4
+        g = torch.randn(ns, co, k * k, cp, device=dev)
+        w = torch.randn(co, ci, k, k, device=dev)
+        part = torch.randn(ns, co, device=dev)
+        kind = i % 3
+        rs = (torch.rand(ns // 2 if ns % 2 == 0 and kind == 2 else 1, device=dev) + 0.5) if kind != 0 else None
+        jobs.append((kind, g, w, part, torch.rand(co, device=dev) + 0.5, torch.randn(co, device=dev), torch.rand(co, device=dev) + 0.5, rs, cp))
+
+    def run():
+        outs = []
+        for kind, g, w, part, scale, mean, inv, rs, cp in jobs:
+            if kind == 1:
+                outs.append(ops.unpack_wgrad_bn(g, w, scale, part, mean, inv, cin_pad=cp, slab_scale=rs))
+            else:
+                dw = torch.empty_like(w)
+                db = ops.unpack_wgrad(g, dw, dbias_part=part, cin_pad=cp, slab_scale=rs)
+                outs.append((dw, db))
+        return outs
+    single = run()
+    with ops.unpack_batch():
+        batched = run()
+    torch.cuda.synchronize()
+    for a, b in zip(single, batched):
+        for ta, tb in zip(a, b):
+            assert torch.equal(ta, tb)
+    # the first job against plain torch
+    kind, g, w, part, *_ = jobs[0]
+    ref = g.sum(0)[:, :, :w.shape[1]].permute(0, 2, 1).reshape(w.shape[0], w.shape[1], 3, 3)
+    assert torch.allclose(single[0][0], ref, atol=1e-5) and torch.allclose(single[0][1], part.sum(0), atol=1e-5)
