@@ -394,7 +394,8 @@ def test_conv_pw_skinny_kernel(Cin, Cout):
 
 def test_batched_unpack_is_bitwise_the_single_launches():
     """effdet_unpack_conv_wgrad_batch: 30 jobs of the three forms (bias rows, frozen-BN parameter gradients, per-image slab
-    scale; short and long rows, 1..40 slabs) in two launches == the same jobs launched one by one, bit for bit."""
+    scale; short and long rows, 1..128 slabs) in two launches == the same jobs launched one by one, bit for bit."""
+    from efficientdet.pytorch_amd import ops
     torch.manual_seed(5)
     dev = 'cuda'
     shapes = [(64, 64, 3, 1), (64, 64, 3, 6), (256, 256, 3, 8), (24, 96, 1, 32), (96, 16, 1, 40), (40, 144, 1, 64), (36, 256, 3, 5),
