@@ -96,7 +96,7 @@ template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2
 __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
   static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
   static_assert(!M32 || SPLIT == 2, "the 32x32x16 form is built for the split layout");
-  static_assert(NS == 2 || !SPLIT, "deep staging is implemented for the plain loop");
+  static_assert(NS == 2 || !M32, "deep staging is not built for the 32x32 tile loop");
   constexpr int CE = Elem<T>::CE;
   constexpr int NTHREADS = NWAVES * 64;
   constexpr int WAVES_M = NWAVES / WAVES_N;
@@ -240,6 +240,15 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
       for (int b = 0; b < MT; ++b) Mma<T>::run(wf[a], xf[b], acc[a][b]);
   };
+  constexpr int PPS = XROWS + WROWS;       // DMA instructions per wave and stage (uniform: NS > 2 is only built for BN >= RSTEP)
+  auto wait_tile = [&](int ahead) {        // `ahead` tiles were issued after the one needed: only their pieces may be in flight
+    if constexpr (NS == 2) { (void)ahead; dma_wait_all(); }
+    else {
+      if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPS) : "memory");
+      else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPS) : "memory");
+      else dma_wait_all();
+    }
+  };
   constexpr int NT32 = M32 ? WTN / 32 : 1, MT32 = M32 ? WTM / 32 : 1;
   f32x16 acc32[NT32][MT32];
   const int l31 = lane & 31, lh = lane >> 5;
@@ -351,31 +360,22 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     // workgroup's waves cover the LDS round trip + split better than software pipelining inside one wave does.  The same
     // loop on v_mfma_f32_32x32x16_bf16 tiles (higher instruction ceiling) measured 267-327: the matrix pipe is not the limiter.
     Frags f;
-    stage(0);
-    if (nk > 1) stage(1);
-    dma_wait_all();
+    int issued = 0;
+    for (; issued < NS && issued < nk; ++issued) stage(issued);
+    wait_tile(issued - 1);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-      const int c = kt & 1;
+      const int c = kt % NS;
       loadsp(c, f);
       mmasp(f);
       if (kt + 1 < nk) {
-        dma_wait_all();                    // tile kt+1 has landed (issued one whole K-step ago) ...
+        wait_tile(issued - (kt + 2));      // tile kt+1 has landed (NS == 2: issued one whole K-step ago; NS == 4: three) ...
         __syncthreads();                   // ... for everyone, and every wave has read tile kt out of buffer c
-        if (kt + 2 < nk) stage(c);
+        if (issued < nk) { stage(c); ++issued; }
       }
     }
   } else {
     uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
-    constexpr int PPS = XROWS + WROWS;       // DMA instructions per wave and stage (uniform: NS > 2 is only built for BN >= RSTEP)
-    auto wait_tile = [&](int ahead) {        // `ahead` tiles were issued after the one needed: only their pieces may be in flight
-      if constexpr (NS == 2) { (void)ahead; dma_wait_all(); }
-      else {
-        if (NS >= 4 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPS) : "memory");
-        else if (ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPS) : "memory");
-        else dma_wait_all();
-      }
-    };
     int issued = 0;
     for (; issued < NS && issued < nk; ++issued) stage(issued);
     wait_tile(issued - 1);
@@ -1137,12 +1137,14 @@ int dispatch(ConvK& k, hipStream_t st) {
   int bn;
   if (k.Cout > 64) bn = 128; else if (k.Cout > 32) bn = 64; else if (k.Cout > 16) bn = 32; else bn = 16;
   k.ntiles = (k.Cout + bn - 1) / bn;
-  if constexpr (!SPLIT) {
-    // at most one tile per CU and a K loop worth pipelining: deep staging (see the kernel's NS note)
-    static const int deep_env = getenv("EFFDET_IGEMM_DEEP") ? atoi(getenv("EFFDET_IGEMM_DEEP")) : 1;      // A/B switch
-    if (deep_env && (long long)k.mtiles * k.ntiles <= 256 && k.Kc >= 6 * 8) {
-      if (bn == 128) return launch<T, 128, 2, 8, 0, 4>(k, st);
-      if (bn == 64) return launch<T, 64, 1, 4, 0, 4>(k, st);
+  {
+    // at most one tile per CU and a K loop worth pipelining: deep staging (see the kernel's NS note).  (EFFDET_IGEMM_DEEP: 0 off,
+    // 1 exact-fp32 / bf16 only, 2 (default) also the bf16x3 register-split form -- the 8x8 / 4x4 stages of the backbone and the
+    // coarse BiFPN levels are 16..144 workgroups walking 18..36 K-steps at one DMA round trip each)
+    static const int deep_env = getenv("EFFDET_IGEMM_DEEP") ? atoi(getenv("EFFDET_IGEMM_DEEP")) : 2;      // A/B switch
+    if ((SPLIT ? deep_env >= 2 : deep_env >= 1) && (long long)k.mtiles * k.ntiles <= 256 && k.Kc >= 6 * 8) {
+      if (bn == 128) return launch<T, 128, 2, 8, SPLIT, 4>(k, st);
+      if (bn == 64) return launch<T, 64, 1, 4, SPLIT, 4>(k, st);
     }
   }
   switch (bn) {

@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
   extern __shared__ __attribute__((aligned(16))) uint4 sm[];
   uint4* xt = sm;                                       // [nbuf][NPIECE*PX][CQ] chunks
   float* wt = (float*)(sm + p.nbuf * TILE);             // [K*K][CQ*CE] weights of this slab
-  __shared__ float red[4][8 * 8];
+  // (the 1 KiB of the final pooled-sum reduction aliases the tile buffer: as a static array it pushed the k3 / stride-2 launch,
+  //  2 x 39 KiB of tiles + weights, 256 bytes past half of the CU's 160 KiB -- one workgroup per CU instead of two)
+  float (*red)[8 * 8] = (float (*)[8 * 8])sm;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
   // a workgroup walks `ppt` consecutive tiles of ONE image (so the squeeze-excite partial sums stay in registers)
@@ -203,6 +205,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
       for (int o = 32; o >= CQ; o >>= 1) v += __shfl_xor(v, o, 64);
       psum[e] = v;
     }
+    __syncthreads();                                    // every wave is done with the last tile: its buffer becomes `red`
     if (lane < CQ) {
 #pragma unroll
       for (int e = 0; e < CE; ++e) red[wave][lane * 8 + e] = psum[e];

@@ -21,6 +21,19 @@ template <int NT>
 __device__ __forceinline__ void pool_reduce(const float* __restrict__ part, int G, int C, float inv_hw, float* mean,
                                             float* scratch, float* __restrict__ pool_out) {
   constexpr int NSL = NT / 64;
+  if (G <= 4) {
+    // few tile groups (the 16x16 and smaller maps: 1..2 rows): one thread per channel adds them directly.  The sliced walk below
+    // would spend C / 64 sequential rounds (18 for C = 1152), two barriers and one load round trip each, with 15 of the 16
+    // slices idle -- 18 of the 39 us this kernel took on the last four blocks of a D0 step.
+    for (int c = threadIdx.x; c < C; c += NT) {
+      float t = part[c];
+      for (int g = 1; g < G; ++g) t += part[(long long)g * C + c];
+      mean[c] = t * inv_hw;
+      if (pool_out) pool_out[c] = t;
+    }
+    __syncthreads();
+    return;
+  }
   const int cl = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int per = (G + NSL - 1) / NSL, g0 = min(G, sl * per), g1 = min(G, g0 + per);
   for (int c0 = 0; c0 < C; c0 += 64) {
