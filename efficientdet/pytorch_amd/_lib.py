@@ -56,11 +56,31 @@ class UnpackJob(C.Structure):    # effdet_unpack_job_t
                [(n, C.c_int) for n in ('accumulate', 'Cout', 'Cin', 'KH', 'KW', 'Cin_pad', 'nslabs', 'slabs_per_scale')]
 
 
+class SeParamJob(C.Structure):   # effdet_se_param_job_t
+    _fields_ = [(n, C.c_void_p) for n in ('du', 'dmid', 'sw', 'pool', 'dw1', 'db1', 'dw2', 'db2')] + \
+               [('B', C.c_int), ('C', C.c_int), ('Cse', C.c_int), ('inv_hw', C.c_float)]
+
+
+class DwUnpackJob(C.Structure):  # effdet_dw_unpack_job_t
+    _fields_ = [(n, C.c_void_p) for n in ('g_kkc', 'scale', 'w_c1kk', 'dw_c1kk', 'wsum', 'dsum', 'mean', 'invstd', 'dgamma', 'dbeta')] + \
+               [('C', C.c_int), ('kk', C.c_int)]
+
+
+class _TailUnion(C.Union):
+    _fields_ = [('conv', UnpackJob), ('se', SeParamJob), ('dw', DwUnpackJob)]
+
+
+class TailJob(C.Structure):      # effdet_tail_job_t
+    _fields_ = [('kind', C.c_int), ('u', _TailUnion)]
+
+
+TAIL_UNPACK, TAIL_SE_PARAMS, TAIL_DW_UNPACK = 0, 1, 2
+
 _lib = None
 
 # every symbol include/effdet_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
+    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_backward_tail', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',

@@ -1,5 +1,6 @@
 // Weight packing / gradient unpacking and layout conversion kernels (HBM-bound, tiny).
 #include "common.h"
+#include "tail_jobs.h"
 
 namespace {
 
@@ -76,113 +77,22 @@ __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_j
   }
 }
 
-// One workgroup = (output channel co, chunk `by` of `gy` of the packed [tap][Cin_pad] row) of one unpack job.  Threads walk the
-// PACKED index so the (split-K) slab reads are coalesced; the OIHW writes scatter inside one channel's few-KiB row (merged in
-// L2).  With wsum / dgamma the row is handled by a single workgroup (gy == 1) so the dot product needs no atomics.
-__device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const int co, const int by, const int gy) {
-  const float* __restrict__ g = j.g; const float* __restrict__ scale = j.scale; const float* __restrict__ w = j.w_oihw;
-  float* __restrict__ dw = j.dw_oihw; float* __restrict__ wsum = j.wsum;
-  const float* __restrict__ dsum_part = j.dsum_part; const float* __restrict__ mean = j.mean; const float* __restrict__ invstd = j.invstd;
-  float* __restrict__ dgamma = j.dgamma; float* __restrict__ dbeta = j.dbeta; float* __restrict__ dbias_out = j.dbias_out;
-  const float* __restrict__ slab_scale = j.slab_scale;
-  const int accumulate = j.accumulate, Cin = j.Cin, KH = j.KH, KW = j.KW, Cin_pad = j.Cin_pad, nslabs = j.nslabs;
-  const int slabs_per_scale = j.slabs_per_scale > 0 ? j.slabs_per_scale : 1, Cout = j.Cout;
-  const long long slab_stride = (long long)Cout * KH * KW * Cin_pad;
-  // slab_scale (optional): slab sl is multiplied by slab_scale[sl / slabs_per_scale] while summing -- per-image slabs
-  // (effdet_wgrad_t.image_splits) x the drop_connect row scale of that image: dW = sum_b rs_b * M_b without a scaled copy of dz
-  auto fac = [&](int sl) -> float { return slab_scale ? slab_scale[sl / slabs_per_scale] : 1.0f; };
-  const int taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
-  const float s = scale ? scale[co] : 1.0f;
-  // sum_m dz[m][co]: the weight-gradient launch left one partial per split-K slab ([nslabs][Cout]); wave 0 adds them in a fixed
-  // pattern (lane-strided, then the shuffle tree): no float atomics upstream or here, so the result is bitwise reproducible
-  __shared__ float dsum_sh;
-  if (dsum_part && by == 0 && threadIdx.x < 64) {
-    float t = 0.f;
-    for (int sl = threadIdx.x; sl < nslabs; sl += 64) t += dsum_part[(long long)sl * Cout + co] * fac(sl);
-    t = wave_sum(t);
-    if (threadIdx.x == 0) { dsum_sh = t; if (dbias_out) dbias_out[co] = t; }
-  }
-  const float* grow = g + (long long)co * np;
-  float part = 0.f;
-  auto emit = [&](int pidx, const f32x4& gv) {          // 4 consecutive packed elements (same tap, 4 channels) -> OIHW
-    const int tap = pidx / Cin_pad, ci = pidx - tap * Cin_pad;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (ci + e >= Cin) continue;
-      const long long o = (long long)co * n + (ci + e) * taps + tap;
-      if (wsum || dgamma) part += w[o] * gv[e];
-      dw[o] = accumulate ? dw[o] + s * gv[e] : s * gv[e];
-    }
-  };
-  const int G = np >> 2;                                 // 16-byte groups per row (Cin_pad % 4 == 0)
-  if (G <= 128 && nslabs >= 8 && gy == 1) {
-    // Short rows with many split-K slabs (the high-resolution 1x1 convs: K = 16..144 against ~500 slabs): one thread
-    // per group summing every slab serially left 4..36 lanes of the workgroup walking a 500-long dependent chain
-    // (45 us for a few KiB).  Spread the slabs over 256/G thread slices and combine the slices through LDS.
-    __shared__ f32x4 sred[256];
-    const int SL = 256 / G, slice = threadIdx.x / G, grp = threadIdx.x - slice * G;
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
-    if (slice < SL) {
-      int sl = slice;
-      for (; sl + SL < nslabs; sl += 2 * SL) {
-        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
-        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride) * fac(sl + SL);
-      }
-      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
-    }
-    sred[threadIdx.x] = a0 + a1;
-    __syncthreads();
-    if ((int)threadIdx.x < G) {
-      f32x4 gv = sred[threadIdx.x];
-      for (int q = 1; q < SL; ++q) gv += sred[q * G + threadIdx.x];
-      emit((int)threadIdx.x * 4, gv);
-    }
-  } else {
-  // 4 consecutive packed elements (same tap, 4 channels: Cin_pad % 4 == 0) per thread, 16-byte slab loads,
-  // slab loop unrolled x4 so the loads of different slabs are in flight together
-  for (int q4 = by * 256 + threadIdx.x; q4 * 4 < np; q4 += gy * 256) {
-    const int pidx = q4 * 4;
-    f32x4 a0 = *(const f32x4*)(grow + pidx) * fac(0), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
-    int sl = 1;
-    for (; sl + 3 < nslabs; sl += 4) {
-      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
-      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride) * fac(sl + 1);
-      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride) * fac(sl + 2);
-      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride) * fac(sl + 3);
-    }
-    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
-    emit(pidx, (a0 + a1) + (a2 + a3));
-  }
-  }
-  if (wsum || dgamma) {
-    __shared__ float red[4];
-    part = wave_sum(part);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const float ws = red[0] + red[1] + red[2] + red[3];
-      if (wsum) wsum[co] = ws;
-      if (dgamma) {            // frozen-BN parameter gradients (same arithmetic as bn_param_grad_kernel), no extra launch
-        dgamma[co] = invstd[co] * (ws - mean[co] * dsum_sh);       // (dsum_sh: written by this thread above)
-        dbeta[co] = dsum_sh;
-      }
-    }
-  }
-}
-
 // one job per launch: grid (Cout, gy)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const effdet_unpack_job_t j) { unpack_row(j, blockIdx.x, blockIdx.y, gridDim.y); }
 
-// Up to UNPACK_MAXJ jobs per launch, the descriptors passed BY VALUE in the kernel arguments (no table upload, nothing to keep
-// alive): a backward node of the model used to end with 2..34 of the launches above, each a few KiB of work behind a chain of
-// dependent slab loads (8-10 us apiece for ~1 us of traffic); batched, the chains of all jobs overlap.
-constexpr int UNPACK_MAXJ = 24;
-struct UnpackBatch { int njobs; int first[UNPACK_MAXJ + 1]; int gy[UNPACK_MAXJ]; effdet_unpack_job_t job[UNPACK_MAXJ]; };
-__global__ __launch_bounds__(256) void unpack_wgrad_batch_kernel(const UnpackBatch bt) {
+// Up to TAIL_MAXJ jobs per launch, the descriptors passed BY VALUE in the kernel arguments (no table upload, nothing to keep
+// alive): a backward node of the model used to end with 2..34 of these few-KiB launches, each a chain of dependent loads (8-12 us
+// apiece for ~1 us of traffic); batched, the chains of all jobs overlap.
+constexpr int TAIL_MAXJ = 24;
+struct TailBatch { int njobs; int first[TAIL_MAXJ + 1]; int gy[TAIL_MAXJ]; effdet_tail_job_t job[TAIL_MAXJ]; };
+__global__ __launch_bounds__(256) void backward_tail_kernel(const TailBatch bt) {
   int ji = 0;
   for (int q = 1; q < bt.njobs; ++q) if ((int)blockIdx.x >= bt.first[q]) ji = q;
-  const int local = blockIdx.x - bt.first[ji], gy = bt.gy[ji];
-  unpack_row(bt.job[ji], local / gy, local - (local / gy) * gy, gy);
+  const int local = blockIdx.x - bt.first[ji];
+  const effdet_tail_job_t& j = bt.job[ji];
+  if (j.kind == EFFDET_TAIL_UNPACK) { const int gy = bt.gy[ji]; unpack_row(j.u.conv, local / gy, local - (local / gy) * gy, gy); }
+  else if (j.kind == EFFDET_TAIL_SE_PARAMS) se_param_grads(j.u.se, local * 256 + (int)threadIdx.x);
+  else dw_unpack_one(j.u.dw, local * 256 + (int)threadIdx.x);
 }
 
 template <typename T>
@@ -279,22 +189,55 @@ int unpack_job_check(const effdet_unpack_job_t& j) {
   return EFFDET_OK;
 }
 inline int unpack_gy(const effdet_unpack_job_t& j) { return (j.wsum || j.dgamma) ? 1 : (j.KH * j.KW * j.Cin_pad / 4 + 255) / 256; }
+// -> number of workgroups of the job (and its gy), or a negative status
+int tail_job_blocks(const effdet_tail_job_t& t, int& gy) {
+  gy = 1;
+  if (t.kind == EFFDET_TAIL_UNPACK) {
+    const int rc = unpack_job_check(t.u.conv); if (rc != EFFDET_OK) return rc;
+    gy = unpack_gy(t.u.conv);
+    return t.u.conv.Cout * gy;
+  }
+  if (t.kind == EFFDET_TAIL_SE_PARAMS) {
+    const effdet_se_param_job_t& q = t.u.se;
+    if (!q.du || !q.dmid || !q.sw || !q.pool || !q.dw1 || !q.db1 || !q.dw2 || !q.db2 || q.B < 1 || q.C < 1 || q.Cse < 1) return EFFDET_EINVAL;
+    return (int)((2LL * q.C * q.Cse + q.C + q.Cse + 255) / 256);
+  }
+  if (t.kind == EFFDET_TAIL_DW_UNPACK) {
+    const effdet_dw_unpack_job_t& q = t.u.dw;
+    if (!q.g_kkc || !q.w_c1kk || !q.dw_c1kk || q.C < 1 || q.kk < 1) return EFFDET_EINVAL;
+    if (q.dgamma && (!q.dbeta || !q.dsum || !q.mean || !q.invstd)) return EFFDET_EINVAL;
+    return (q.C + 255) / 256;
+  }
+  return EFFDET_EINVAL;
+}
 }  // namespace
+
+extern "C" int effdet_backward_tail(const effdet_tail_job_t* jobs, int njobs, effdet_stream_t stream) {
+  if (!jobs || njobs < 1) return EFFDET_EINVAL;
+  for (int i = 0; i < njobs; ++i) { int gy; const int nb = tail_job_blocks(jobs[i], gy); if (nb < 0) return nb; }
+  for (int i0 = 0; i0 < njobs; i0 += TAIL_MAXJ) {
+    const int nj = njobs - i0 < TAIL_MAXJ ? njobs - i0 : TAIL_MAXJ;
+    if (nj == 1 && jobs[i0].kind == EFFDET_TAIL_UNPACK) {
+      hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(jobs[i0].u.conv.Cout, unpack_gy(jobs[i0].u.conv)), dim3(256), 0, (hipStream_t)stream, jobs[i0].u.conv);
+    } else {
+      TailBatch bt; bt.njobs = nj; int blocks = 0;
+      for (int q = 0; q < nj; ++q) { bt.job[q] = jobs[i0 + q]; bt.first[q] = blocks; blocks += tail_job_blocks(jobs[i0 + q], bt.gy[q]); }
+      bt.first[nj] = blocks;
+      hipLaunchKernelGGL(backward_tail_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
+    }
+    EFFDET_CHECK_LAUNCH();
+  }
+  return EFFDET_OK;
+}
 
 extern "C" int effdet_unpack_conv_wgrad_batch(const effdet_unpack_job_t* jobs, int njobs, effdet_stream_t stream) {
   if (!jobs || njobs < 1) return EFFDET_EINVAL;
-  for (int i = 0; i < njobs; ++i) { const int rc = unpack_job_check(jobs[i]); if (rc != EFFDET_OK) return rc; }
-  for (int i0 = 0; i0 < njobs; i0 += UNPACK_MAXJ) {
-    const int nj = njobs - i0 < UNPACK_MAXJ ? njobs - i0 : UNPACK_MAXJ;
-    if (nj == 1) {
-      hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(jobs[i0].Cout, unpack_gy(jobs[i0])), dim3(256), 0, (hipStream_t)stream, jobs[i0]);
-    } else {
-      UnpackBatch bt; bt.njobs = nj; int blocks = 0;
-      for (int q = 0; q < nj; ++q) { bt.job[q] = jobs[i0 + q]; bt.gy[q] = unpack_gy(jobs[i0 + q]); bt.first[q] = blocks; blocks += jobs[i0 + q].Cout * bt.gy[q]; }
-      bt.first[nj] = blocks;
-      hipLaunchKernelGGL(unpack_wgrad_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, bt);
-    }
-    EFFDET_CHECK_LAUNCH();
+  effdet_tail_job_t t[TAIL_MAXJ];
+  for (int i0 = 0; i0 < njobs; i0 += TAIL_MAXJ) {
+    const int nj = njobs - i0 < TAIL_MAXJ ? njobs - i0 : TAIL_MAXJ;
+    for (int q = 0; q < nj; ++q) { t[q].kind = EFFDET_TAIL_UNPACK; t[q].u.conv = jobs[i0 + q]; }
+    const int rc = effdet_backward_tail(t, nj, stream);
+    if (rc != EFFDET_OK) return rc;
   }
   return EFFDET_OK;
 }

@@ -1,6 +1,7 @@
 // Squeeze-excite micro-kernels and the small elementwise / reduction helpers of the MBConv
 // backward pass.  All HBM-bound or latency-bound; wave-level (64-lane) reductions, 16-byte I/O.
 #include "common.h"
+#include "tail_jobs.h"
 
 namespace {
 
@@ -200,47 +201,8 @@ __global__ __launch_bounds__(SE_T) void se_gate_bwd_a_kernel(const float* __rest
   }
 }
 
-// ---- phase B: parameter gradients as batch reductions, one thread per parameter (no atomics, deterministic) ----
-//   dw2[c][j] = sum_b du[b][c]*sw[b][j]   dw1[j][c] = sum_b dmid[b][j]*mean[b][c]   db2[c] = sum_b du   db1[j] = sum_b dmid
-__global__ __launch_bounds__(256) void se_gate_bwd_b_kernel(const float* __restrict__ ws_du, const float* __restrict__ ws_dmid,
-                                                            const float* __restrict__ ws_sw, const float* __restrict__ pool,
-                                                            float* __restrict__ dw1, float* __restrict__ db1,
-                                                            float* __restrict__ dw2, float* __restrict__ db2, int B, int C,
-                                                            int Cse, float inv_hw) {
-  const int n = C * Cse;
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {                                   // dw2[c][j]
-    const int c = i / Cse, j = i - c * Cse;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 4 independent chains: the batch loop is pure load latency
-    int b = 0;
-    for (; b + 3 < B; b += 4) {
-      s0 = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s0);
-      s1 = fmaf(ws_du[(long long)(b + 1) * C + c], ws_sw[(long long)(b + 1) * Cse + j], s1);
-      s2 = fmaf(ws_du[(long long)(b + 2) * C + c], ws_sw[(long long)(b + 2) * Cse + j], s2);
-      s3 = fmaf(ws_du[(long long)(b + 3) * C + c], ws_sw[(long long)(b + 3) * Cse + j], s3);
-    }
-    for (; b < B; ++b) s0 = fmaf(ws_du[(long long)b * C + c], ws_sw[(long long)b * Cse + j], s0);
-    dw2[i] = (s0 + s1) + (s2 + s3); return;
-  }
-  i -= n;
-  if (i < n) {                                   // dw1[j][c]
-    const int j = i / C, c = i - j * C;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int b = 0;
-    for (; b + 3 < B; b += 4) {
-      s0 = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s0);
-      s1 = fmaf(ws_dmid[(long long)(b + 1) * Cse + j], pool[(long long)(b + 1) * C + c], s1);
-      s2 = fmaf(ws_dmid[(long long)(b + 2) * Cse + j], pool[(long long)(b + 2) * C + c], s2);
-      s3 = fmaf(ws_dmid[(long long)(b + 3) * Cse + j], pool[(long long)(b + 3) * C + c], s3);
-    }
-    for (; b < B; ++b) s0 = fmaf(ws_dmid[(long long)b * Cse + j], pool[(long long)b * C + c], s0);
-    dw1[i] = ((s0 + s1) + (s2 + s3)) * inv_hw; return;
-  }
-  i -= n;
-  if (i < C) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_du[(long long)b * C + i]; db2[i] = s; return; }
-  i -= C;
-  if (i < Cse) { float s = 0.f; for (int b = 0; b < B; ++b) s += ws_dmid[(long long)b * Cse + i]; db1[i] = s; }
-}
+// ---- phase B: parameter gradients as batch reductions (tail_jobs.h: se_param_grads) ----
+__global__ __launch_bounds__(256) void se_gate_bwd_b_kernel(const effdet_se_param_job_t q) { se_param_grads(q, blockIdx.x * 256 + threadIdx.x); }
 
 // ---- y = act(x) * gate[b][c]   (act = Swish when x is the depthwise PRE-activation: z-only storage) ----
 template <typename T>
@@ -439,17 +401,7 @@ __global__ void dw_pack_kernel(const float* w, float* out, int C, int kk) {
   const int t = i / C, c = i - t * C;
   out[i] = w[c * kk + t];
 }
-__global__ void dw_unpack_grad_kernel(const float* g, const float* scale, const float* w, float* dw, float* wsum, int C, int kk,
-                                      const float* dsum, const float* mean, const float* invstd, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float s = scale ? scale[c] : 1.f;
-  float acc = 0.f;
-#pragma unroll 5
-  for (int t = 0; t < kk; ++t) { const float gv = g[t * C + c]; dw[c * kk + t] = s * gv; acc = fmaf(w[c * kk + t], gv, acc); }
-  if (wsum) wsum[c] = acc;
-  if (dgamma) { dgamma[c] = invstd[c] * (acc - mean[c] * dsum[c]); dbeta[c] = dsum[c]; }     // = bn_param_grad_kernel
-}
+__global__ void dw_unpack_grad_kernel(const effdet_dw_unpack_job_t q) { dw_unpack_one(q, blockIdx.x * blockDim.x + threadIdx.x); }
 
 }  // namespace
 
@@ -487,7 +439,9 @@ extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, int dgate
                                   const float* b1, const float* w2, float* dpool, float* dw1, float* db1, float* dw2, float* db2,
                                   float* workspace, int B, int C, int Cse, float inv_hw, effdet_stream_t stream) {
   (void)b1;
-  if (!dgate || dgate_slabs < 1 || !gate || !mid || !pool || !w1 || !w2 || !dpool || !dw1 || !db1 || !dw2 || !db2 || !workspace) return EFFDET_EINVAL;
+  const bool params = dw1 || db1 || dw2 || db2;          // all four, or none (phase B left to an effdet_backward_tail job)
+  if (!dgate || dgate_slabs < 1 || !gate || !mid || !pool || !w1 || !w2 || !dpool || !workspace) return EFFDET_EINVAL;
+  if (params && (!dw1 || !db1 || !dw2 || !db2)) return EFFDET_EINVAL;
   if (Cse < 1 || Cse > SE_T) return EFFDET_EUNSUPPORTED;
   const int R = SE_T / Cse;
   const size_t lds = (size_t)(C + Cse + R * Cse) * sizeof(float);
@@ -496,9 +450,12 @@ extern "C" int effdet_se_gate_bwd(const float* dgate, int dgate_slabs, int dgate
   hipLaunchKernelGGL(se_gate_bwd_a_kernel, dim3(B), dim3(SE_T), lds, ST, dgate, dgate_slabs, dgate_times_gate, gate, mid, w1, w2, dpool, ws_du, ws_dmid, ws_sw, C,
                      Cse, inv_hw);
   EFFDET_CHECK_LAUNCH();
+  if (!params) return EFFDET_OK;
+  effdet_se_param_job_t q = {};
+  q.du = ws_du; q.dmid = ws_dmid; q.sw = ws_sw; q.pool = pool; q.dw1 = dw1; q.db1 = db1; q.dw2 = dw2; q.db2 = db2;
+  q.B = B; q.C = C; q.Cse = Cse; q.inv_hw = inv_hw;
   const long long n = 2LL * C * Cse + C + Cse;
-  hipLaunchKernelGGL(se_gate_bwd_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, ws_du, ws_dmid, ws_sw, pool, dw1, db1,
-                     dw2, db2, B, C, Cse, inv_hw);
+  hipLaunchKernelGGL(se_gate_bwd_b_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ST, q);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -613,8 +570,9 @@ extern "C" int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C,
 extern "C" int effdet_dw_unpack_wgrad(const float* g_kkc, const float* scale, const float* w_c1kk, float* dw_c1kk, float* wsum,
                                       int C, int k, effdet_stream_t stream) {
   if (!g_kkc || !w_c1kk || !dw_c1kk) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, wsum, C, k * k,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+  effdet_dw_unpack_job_t q = {};
+  q.g_kkc = g_kkc; q.scale = scale; q.w_c1kk = w_c1kk; q.dw_c1kk = dw_c1kk; q.wsum = wsum; q.C = C; q.kk = k * k;
+  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, q);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }
@@ -622,8 +580,10 @@ extern "C" int effdet_dw_unpack_wgrad_bn(const float* g_kkc, const float* scale,
                                          const float* dsum, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                                          int C, int k, effdet_stream_t stream) {
   if (!g_kkc || !w_c1kk || !dw_c1kk || !dsum || !mean || !invstd || !dgamma || !dbeta) return EFFDET_EINVAL;
-  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, g_kkc, scale, w_c1kk, dw_c1kk, (float*)nullptr, C,
-                     k * k, dsum, mean, invstd, dgamma, dbeta);
+  effdet_dw_unpack_job_t q = {};
+  q.g_kkc = g_kkc; q.scale = scale; q.w_c1kk = w_c1kk; q.dw_c1kk = dw_c1kk; q.dsum = dsum; q.mean = mean; q.invstd = invstd;
+  q.dgamma = dgamma; q.dbeta = dbeta; q.C = C; q.kk = k * k;
+  hipLaunchKernelGGL(dw_unpack_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, q);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

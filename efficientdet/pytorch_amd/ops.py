@@ -412,37 +412,46 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     return slabs, parts
 
 
-class _UnpackBatch:
-    """Deferred weight-gradient unpacks of one backward node (effdet_unpack_conv_wgrad_batch): inside ``with unpack_batch():``
-    unpack_wgrad / unpack_wgrad_bn only record a job (outputs are allocated right away, inputs stay referenced here) and the
-    whole list goes out as one launch per 24 jobs when the block exits.  Nothing inside the block may READ an unpack's outputs."""
+class _TailBatch:
+    """Deferred leaf work of one backward node (effdet_backward_tail): inside ``with unpack_batch():`` unpack_wgrad /
+    unpack_wgrad_bn / dw_unpack_wgrad_bn / the parameter-gradient half of se_gate_bwd only record a job (outputs are allocated
+    right away, inputs stay referenced here) and the whole list goes out as one launch per 24 jobs when the block exits.
+    Nothing inside the block may READ these outputs."""
 
     def __init__(self):
         self.jobs, self.keep = [], []
 
-    def add(self, job, *tensors):
-        self.jobs.append(job); self.keep.append(tensors)
+    def add(self, kind, job, *tensors):
+        t = L.TailJob()
+        t.kind = kind
+        if kind == L.TAIL_UNPACK:
+            t.u.conv = job
+        elif kind == L.TAIL_SE_PARAMS:
+            t.u.se = job
+        else:
+            t.u.dw = job
+        self.jobs.append(t); self.keep.append(tensors)
 
     def flush(self):
         if self.jobs:
-            arr = (L.UnpackJob * len(self.jobs))(*self.jobs)
-            L.check(L.lib().effdet_unpack_conv_wgrad_batch(arr, len(self.jobs), L.stream_ptr()), 'effdet_unpack_conv_wgrad_batch')
+            arr = (L.TailJob * len(self.jobs))(*self.jobs)
+            L.check(L.lib().effdet_backward_tail(arr, len(self.jobs), L.stream_ptr()), 'effdet_backward_tail')
         self.jobs, self.keep = [], []
 
 
 _UNPACK_BATCH = None
-UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'
+UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'      # A/B switch: 0 = every tail job is its own launch
 
 
 class unpack_batch:
-    """Context manager: batch every unpack_wgrad / unpack_wgrad_bn issued inside into one launch at exit (re-entrant: an inner
-    block joins the outer one)."""
+    """Context manager: batch the tail jobs (see _TailBatch) issued inside into one launch at exit (re-entrant: an inner block
+    joins the outer one)."""
 
     def __enter__(self):
         global _UNPACK_BATCH
         self.owner = _UNPACK_BATCH is None and UNPACK_BATCHED
         if self.owner:
-            _UNPACK_BATCH = _UnpackBatch()
+            _UNPACK_BATCH = _TailBatch()
         return self
 
     def __exit__(self, et, ev, tb):
@@ -466,7 +475,7 @@ def _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, **ptrs):
 
 def _unpack_submit(job, *tensors):
     if _UNPACK_BATCH is not None:
-        _UNPACK_BATCH.add(job, *tensors)
+        _UNPACK_BATCH.add(L.TAIL_UNPACK, job, *tensors)
     else:
         L.check(L.lib().effdet_unpack_conv_wgrad_batch(C.byref(job), 1, L.stream_ptr()), 'effdet_unpack_conv_wgrad_batch')
 
@@ -597,13 +606,20 @@ def dw_unpack_wgrad(g_kkc, scale, w_c1kk, wsum=None):
 
 
 def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
-    """dw_unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta)."""
+    """dw_unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta).  Deferred inside ``with unpack_batch():``."""
     Cc, _, k, _ = w_c1kk.shape
     dw = torch.empty_like(w_c1kk)
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=dw.device)
-    L.check(L.lib().effdet_dw_unpack_wgrad_bn(L.ptr(g_kkc), L.ptr(scale), L.ptr(w_c1kk.detach()), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
-                                              L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cc, k, L.stream_ptr()),
-            'effdet_dw_unpack_wgrad_bn')
+    wd = w_c1kk.detach()
+    if _UNPACK_BATCH is not None:
+        j = L.DwUnpackJob()
+        j.g_kkc, j.scale, j.w_c1kk, j.dw_c1kk, j.dsum, j.mean, j.invstd = (t.data_ptr() for t in (g_kkc, scale, wd, dw, dsum, mean, invstd))
+        j.dgamma, j.dbeta, j.C, j.kk = dgb[0].data_ptr(), dgb[1].data_ptr(), Cc, k * k
+        _UNPACK_BATCH.add(L.TAIL_DW_UNPACK, j, g_kkc, scale, wd, dw, dsum, mean, invstd, dgb)
+    else:
+        L.check(L.lib().effdet_dw_unpack_wgrad_bn(L.ptr(g_kkc), L.ptr(scale), L.ptr(wd), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
+                                                  L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cc, k, L.stream_ptr()),
+                'effdet_dw_unpack_wgrad_bn')
     return dw, dgb[0], dgb[1]
 
 
@@ -714,9 +730,18 @@ def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, times_gate=False):
     db2 = out[o:o + Cc]; o += Cc
     ws = out[o:]
     assert ws.numel() >= L.lib().effdet_se_gate_bwd_workspace_floats(B, Cc, Cse)
-    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], int(times_gate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1.detach()), L.ptr(b1.detach()),
-                                       L.ptr(w2.detach()), L.ptr(dpool), L.ptr(dw1), L.ptr(db1), L.ptr(dw2), L.ptr(db2), L.ptr(ws),
+    defer = _UNPACK_BATCH is not None          # the parameter gradients (phase B) join the node's tail launch
+    w1d, b1d, w2d = w1.detach(), b1.detach(), w2.detach()
+    L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], int(times_gate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1d), L.ptr(b1d),
+                                       L.ptr(w2d), L.ptr(dpool), L.ptr(None if defer else dw1), L.ptr(None if defer else db1),
+                                       L.ptr(None if defer else dw2), L.ptr(None if defer else db2), L.ptr(ws),
                                        B, Cc, Cse, C.c_float(inv_hw), L.stream_ptr()), 'effdet_se_gate_bwd')
+    if defer:
+        j = L.SeParamJob()
+        j.du, j.dmid, j.sw = ws.data_ptr(), ws.data_ptr() + 4 * B * Cc, ws.data_ptr() + 4 * B * (Cc + Cse)
+        j.pool, j.dw1, j.db1, j.dw2, j.db2 = pool.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
+        j.B, j.C, j.Cse, j.inv_hw = B, Cc, Cse, inv_hw
+        _UNPACK_BATCH.add(L.TAIL_SE_PARAMS, j, out, pool)
     return dpool, dw1, db1, dw2, db2
 
 

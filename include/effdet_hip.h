@@ -156,7 +156,7 @@ int effdet_unpack_conv_wgrad_bn(const float* g, const float* scale, const float*
 
 /* The two calls above as ONE descriptor, and any number of them in one launch (the descriptors travel in the kernel arguments,
  * 24 per launch): a backward node of the model ends with 2 (MBConv) .. 34 (the BiFPN stack) of these few-KiB unpacks, each a
- * chain of dependent slab loads -- batched, the chains overlap (63 -> 20 launches per D0 train step).
+ * chain of dependent slab loads -- batched, the chains overlap.
  * Fields as in effdet_unpack_conv_wgrad / _bn: dgamma != NULL selects the frozen-BN form (dsum_part, mean, invstd, dbeta, w_oihw
  * required), dbias_out != NULL the bias form (dsum_part = the [nslabs][Cout] partial rows), wsum as above; unused pointers NULL. */
 typedef struct {
@@ -166,6 +166,31 @@ typedef struct {
   int accumulate, Cout, Cin, KH, KW, Cin_pad, nslabs, slabs_per_scale;
 } effdet_unpack_job_t;
 int effdet_unpack_conv_wgrad_batch(const effdet_unpack_job_t* jobs, int njobs, effdet_stream_t stream);
+
+/* The backward "tail" of a node: every piece of leaf work nothing else in the node waits for, as ONE launch --
+ *   EFFDET_TAIL_UNPACK     a weight-gradient unpack (above);
+ *   EFFDET_TAIL_SE_PARAMS  phase B of effdet_se_gate_bwd: dw1/db1/dw2/db2 of the squeeze-excite FCs as batch reductions over the
+ *                          du [B][C] | dmid [B][Cse] | sw [B][Cse] rows phase A left in its workspace (in that order) and the
+ *                          pooled sums `pool` [B][C];
+ *   EFFDET_TAIL_DW_UNPACK  effdet_dw_unpack_wgrad / _bn (g_kkc [k*k][C] -> [C][1][k][k], + frozen-BN gamma/beta gradients).
+ * An MBConv block's backward ends with four such launches (two conv unpacks, the SE parameters, the depthwise unpack: 8-12 us
+ * of dependent-load latency each); as one launch their chains overlap (D0 train step: 48 launches fewer). */
+enum { EFFDET_TAIL_UNPACK = 0, EFFDET_TAIL_SE_PARAMS = 1, EFFDET_TAIL_DW_UNPACK = 2 };
+typedef struct {
+  const float* du; const float* dmid; const float* sw; const float* pool;
+  float* dw1; float* db1; float* dw2; float* db2;
+  int B, C, Cse; float inv_hw;
+} effdet_se_param_job_t;
+typedef struct {
+  const float* g_kkc; const float* scale; const float* w_c1kk; float* dw_c1kk; float* wsum;
+  const float* dsum; const float* mean; const float* invstd; float* dgamma; float* dbeta;
+  int C, kk;
+} effdet_dw_unpack_job_t;
+typedef struct {
+  int kind;
+  union { effdet_unpack_job_t conv; effdet_se_param_job_t se; effdet_dw_unpack_job_t dw; } u;
+} effdet_tail_job_t;
+int effdet_backward_tail(const effdet_tail_job_t* jobs, int njobs, effdet_stream_t stream);
 
 /* Batched parameter preparation: every per-step repack of the model's parameters in ONE launch (a D0 train step
  * issued ~190 of these 4-microsecond kernels one by one: 125 weight packs, 48 BN folds, 16 depthwise packs).
@@ -278,7 +303,9 @@ int effdet_se_dgate(const void* dy, const void* x, float* dgate_part, int act, i
 /* tiny FC backward: from dgate_part[b][slab][c] (partial grads wrt gate, dgate_slabs rows per image; 1 = a plain
  * [B][C] gradient), gate, mid, pool -> dpool[b][c] (grad wrt the
  * SUM pool, i.e. already multiplied by inv_hw), dw1, db1, dw2, db2 (OVERWRITTEN, fp32; batch reductions with one
- * thread per parameter: no atomics, deterministic).  workspace: effdet_se_gate_bwd_workspace_floats() fp32. */
+ * thread per parameter: no atomics, deterministic).  workspace: effdet_se_gate_bwd_workspace_floats() fp32, left holding
+ * du [B][C] | dmid [B][Cse] | sw [B][Cse].  With dw1 = db1 = dw2 = db2 = NULL only dpool is produced and the parameter
+ * gradients are left to an EFFDET_TAIL_SE_PARAMS job of effdet_backward_tail over that workspace. */
 long long effdet_se_gate_bwd_workspace_floats(int B, int C, int Cse);
 int effdet_se_gate_bwd(const float* dgate_part, int dgate_slabs, int dgate_times_gate, const float* gate, const float* mid, const float* pool,
                        const float* w1, const float* b1, const float* w2, float* dpool, float* dw1, float* db1,

@@ -35,6 +35,31 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.WgradDesc) == 4 * 8 + 13 * 4 + 4 + 5 * C.sizeof(_lib.Seg)        # 4 ptrs, 13 ints (+pad), 5 segs
 
 
+def test_ctypes_structs_match_the_header_as_gcc_sees_it(tmp_path):
+    """Every descriptor struct of include/effdet_hip.h: sizeof as compiled by gcc from the header == the ctypes mirror."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    from efficientdet.pytorch_amd import _lib
+    if shutil.which('gcc') is None:
+        import pytest
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pairs = [('effdet_seg_t', _lib.Seg), ('effdet_conv_t', _lib.ConvDesc), ('effdet_wgrad_t', _lib.WgradDesc), ('effdet_prep_job_t', _lib.PrepJob),
+             ('effdet_unpack_job_t', _lib.UnpackJob), ('effdet_se_param_job_t', _lib.SeParamJob), ('effdet_dw_unpack_job_t', _lib.DwUnpackJob),
+             ('effdet_tail_job_t', _lib.TailJob)]
+    src = tmp_path / 'sz.c'
+    src.write_text('#include <stdio.h>\n#include "effdet_hip.h"\nint main(void){' +
+                   ''.join('printf("%%zu\\n", sizeof(%s));' % n for n, _ in pairs) + 'return 0;}\n')
+    exe = tmp_path / 'sz'
+    subprocess.run(['gcc', '-I', os.path.join(root, 'include'), str(src), '-o', str(exe)], check=True)
+    sizes = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    for (name, ct), sz in zip(pairs, sizes):
+        assert C.sizeof(ct) == sz, (name, C.sizeof(ct), sz)
+    assert C.sizeof(_lib.TailJob) * 24 + 4 * (1 + 25 + 24) < 4096          # a 24-job batch fits the kernel-argument segment
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from efficientdet.pytorch_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -66,7 +66,15 @@ def test_dwconv_fwd_bwd(dtype, cfg):
     assert torch.equal(gk, gk2) and torch.equal(dsum, dsum2)              # slab reduction in a fixed order: bitwise reproducible
     wsum = torch.empty(C, device=dev)
     dw = ops.dw_unpack_wgrad(gk, scale.to(dev), w.detach().to(dev), wsum)
+    # the frozen-BN form, launched directly and as a job of the node's tail batch: same bits
+    mean, inv = torch.randn(C, device=dev), torch.rand(C, device=dev) + 0.5
+    single = ops.dw_unpack_wgrad_bn(gk, scale.to(dev), w.detach().to(dev), dsum, mean, inv)
+    with ops.unpack_batch():
+        batched = ops.dw_unpack_wgrad_bn(gk, scale.to(dev), w.detach().to(dev), dsum, mean, inv)
     torch.cuda.synchronize()
+    for a, b in zip(single, batched):
+        assert torch.equal(a, b)
+    assert torch.equal(single[0], dw)
     assert_close(nchw(dxm), x.grad, TOL[dtype], 'dw dgrad')
     assert_close(dw.cpu(), w.grad, 5 * TOL[dtype], 'dw wgrad')
     assert_close(dsum.cpu(), dz.sum(dim=(0, 2, 3)), 5 * TOL[dtype], 'dw dsum')
@@ -141,7 +149,12 @@ def test_squeeze_excite_fwd_bwd(dtype, cfg):
     assert_close_scale(dg_z.cpu(), dg.cpu(), 1e-4 if dtype == torch.float32 else 1e-2, 'se dgate (from z)')
     dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgp, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
     dzm = ops.se_bwd_apply(dym, gd, dpool, zm)
+    # the same call inside a tail batch: the parameter gradients leave with effdet_backward_tail at the end of the block, same bits
+    with ops.unpack_batch():
+        dpool_t, dw1_t, db1_t, dw2_t, db2_t = ops.se_gate_bwd(dgp, gd, midd, pool, w1d.view(Cse, C), b1d, w2d.view(C, Cse), inv)
     torch.cuda.synchronize()
+    for a, b in ((dpool, dpool_t), (dw1, dw1_t), (db1, db1_t), (dw2, dw2_t), (db2, db2_t)):
+        assert torch.equal(a, b)
     t = 5 * TOL[dtype]
     assert_close(dw1.cpu(), w1.grad.view(Cse, C), t, 'se dw1'); assert_close(db1.cpu(), b1.grad, t, 'se db1')
     assert_close(dw2.cpu(), w2.grad.view(C, Cse), t, 'se dw2'); assert_close(db2.cpu(), b2.grad, t, 'se db2')
