@@ -1083,6 +1083,33 @@ constexpr int F32_NW = EFFDET_WGRAD_F32_WAVES;
 constexpr int X3_NW = EFFDET_WGRAD_X3_WAVES;
 }  // namespace
 
+// Slab range [first, first + count) of every pyramid level, in the order effdet_conv2d_wgrad lays the slabs out: the levels the
+// DMA-staged kernels take first, then the register-transpose kernel's (each launch numbers its own splits from 0 and owns a
+// contiguous range; the split-layout kernel takes every level in order).  -> number of slabs of the fast launch.
+static int seg_slab_ranges(const effdet_wgrad_t* p, const WgradK& k, bool x3, bool splitfmt, int* first, int* count, bool* fast) {
+  static const int f32dma = getenv("EFFDET_WGRAD_F32DMA") ? atoi(getenv("EFFDET_WGRAD_F32DMA")) : 1;      // A/B switch
+  int sf = 0, ss = 0;
+  for (int s = 0; s < p->nseg; ++s) {
+    count[s] = (int)((k.seg[s].M + k.mchunk - 1) / k.mchunk);
+    fast[s] = splitfmt || tr_eligible(p, k, s) || (f32dma && f32dma_eligible(p, k, s, x3));
+    if (fast[s]) { first[s] = sf; sf += count[s]; }
+  }
+  for (int s = 0; s < p->nseg; ++s) if (!fast[s]) { first[s] = sf + ss; ss += count[s]; }
+  return sf;
+}
+
+extern "C" int effdet_conv2d_wgrad_seg_slabs(const effdet_wgrad_t* p, int* first, int* count) {
+  if (!p || !first || !count) return EFFDET_EINVAL;
+  WGRAD_NORMALISE_DTYPE(p, pn);
+  WgradK k; int splits = 0;
+  const int rc = plan(p, k, splits, pn_split ? 256 : 128);
+  if (rc != EFFDET_OK) return rc;
+  if (pn_split && !split_all_eligible(p, k)) return EFFDET_EUNSUPPORTED;
+  bool fast[EFFDET_MAX_SEG];
+  (void)seg_slab_ranges(p, k, pn_x3, pn_split, first, count, fast);
+  return splits;
+}
+
 extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes,
                                    effdet_stream_t stream) {
   if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
@@ -1131,18 +1158,18 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   // Partition the pyramid levels between the two kernels; each launch numbers its own splits from 0 and owns a
   // contiguous range of slabs (the slab order is irrelevant to the reduction).
   WgradK kf = k, ks = k;            // fast (DMA staging: bf16 LDS-transpose-read / fp32 direct-operand) / slow (register transpose)
-  static const int f32dma = getenv("EFFDET_WGRAD_F32DMA") ? atoi(getenv("EFFDET_WGRAD_F32DMA")) : 1;      // A/B switch
-  int nf = 0, ns = 0, sf = 0, ss = 0;
+  int first[EFFDET_MAX_SEG], count[EFFDET_MAX_SEG]; bool fast[EFFDET_MAX_SEG];
+  const int sf = seg_slab_ranges(p, k, pn_x3, false, first, count, fast);
+  int nf = 0, ns = 0, ss = 0;
   for (int s = 0; s < p->nseg; ++s) {
-    const int cnt = (int)((k.seg[s].M + k.mchunk - 1) / k.mchunk);
-    if (tr_eligible(p, k, s) || (f32dma && f32dma_eligible(p, k, s, pn_x3))) {
-      WSeg d = k.seg[s]; d.split_start = sf; sf += cnt;
+    if (fast[s]) {
+      WSeg d = k.seg[s]; d.split_start = first[s];
       if (p->KH == 1 && p->KW == 1 && d.in_bs == (long long)d.H * d.W * p->ldx && d.out_bs == (long long)d.Ho * d.Wo * p->lddz) {
         d.H = d.Ho = 1; d.W = d.Wo = d.M;           // contiguous pointwise: one long image row, no wrap, no borders
       }
       kf.seg[nf++] = d;
     } else {
-      WSeg d = k.seg[s]; d.split_start = ss; ss += cnt;
+      WSeg d = k.seg[s]; d.split_start = first[s] - sf; ss += count[s];
       ks.seg[ns++] = d;
     }
   }

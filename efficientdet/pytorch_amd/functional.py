@@ -18,6 +18,7 @@ from .config import BN_EPS, conv_out
 from .ops import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SWISH, RES_ADD, RES_NONE, RES_RELU_MASK, Map
 
 DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: also store the depthwise Swish output in training
+BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 
@@ -266,17 +267,33 @@ def bifpn_module_bwd(saved, douts, dtype):
         grads[name] = Map.new(like.B, like.H, like.W, like.C, dtype, dev)
         return grads[name], False
 
+    pending = []                                                     # (M, f, dz, conv index): weight gradients, leaf work
     for (mode, col, wsel, a_n, b_n, c_n, out_n, f, ci) in reversed(nodes):
-        dz = grads[out_n]                                            # conv has bias only: dz = dy
-        G, dbp = ops.conv2d_wgrad(f, dz, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
-        dw = torch.empty_like(cw[ci]); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
-        dcw[ci], dcb[ci] = dw, db
+        dz = grads[out_n]                                            # conv has bias only: dz = dy (final: its consumers ran first)
+        if BIFPN_WGRAD_GROUP:
+            pending.append((f.B * f.H * f.W, f, dz, ci))
+        else:
+            G, dbp = ops.conv2d_wgrad(f, dz, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
+            dw = torch.empty_like(cw[ci]); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
+            dcw[ci], dcb[ci] = dw, db
         df = Map.new(f.B, f.H, f.W, Wc, dtype, dev)
         ops.conv2d(dz, ops.pack_weight(cw[ci], dtype, mode=1), df, Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1)
         da, da_acc = target(a_n); dbm, db_acc = target(b_n)
         dc, dc_acc = target(c_n) if c_n is not None else (None, False)
         ops.bifpn_fuse_bwd(df, names[a_n], names[b_n], names[c_n] if c_n else None, da, dbm, dc, da_acc, db_acc, dc_acc,
                            w1 if wsel == 1 else w2, dn1 if wsel == 1 else dn2, col, mode)
+    # The 8 weight gradients of the module as TWO launches of independent problems (one pyramid level each, own weights): launched
+    # one by one they are 19-89 us apiece -- the 4x4 .. 16x16 levels are 5-160 workgroups walking one dependent chain -- 268 us
+    # per module for 27 GFLOP.  The largest level shares its launch with the four smallest, the 32x32 / 16x16 ones share the other.
+    if pending:
+        pending.sort(key=lambda t: -t[0])
+        chunks = [pending[:1] + pending[4:], pending[1:4]] if len(pending) > 5 else [pending]
+        for ch in chunks:
+            if not ch:
+                continue
+            outs = ops.conv2d_wgrad([t[1] for t in ch], [t[2] for t in ch], Cin=Wc, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, group=True)
+            for (_, _, _, ci), (G, dbp) in zip(ch, outs):
+                dw = torch.empty_like(cw[ci]); dcb[ci] = ops.unpack_wgrad(G, dw, dbias_part=dbp); dcw[ci] = dw
     dw1 = ops.zeros(tuple(w1.shape), w1.device); dw2 = ops.zeros(tuple(w2.shape), w2.device)
     ops.bifpn_weight_bwd(w1, dn1, dw1); ops.bifpn_weight_bwd(w2, dn2, dw2)
     dins = [grads[('in', l)] for l in range(len(out_names))]

@@ -373,10 +373,12 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
 
 
 def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False,
-                 image_splits=False):
+                 image_splits=False, group=False):
     """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
     split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
-    runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ..."""
+    runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ...
+    group=True (dw None, <= 5 maps): the maps are INDEPENDENT problems of the same conv geometry (different tensors, different
+    weights) sharing one launch -> a list of (slabs_i, parts_i), one per map (effdet_conv2d_wgrad_seg_slabs)."""
     if isinstance(xs, Map):
         xs, dzs = [xs], [dzs]
     d = L.WgradDesc()
@@ -409,6 +411,13 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
     slabs = ws[:splits * n].view(splits, Cout, KH * KW, Cin)
     parts = ws[splits * n:].view(splits, Cout) if d.dbias else None
+    if group:
+        assert dw is None and not image_splits
+        first, count = (C.c_int * len(xs))(), (C.c_int * len(xs))()
+        tot = int(L.lib().effdet_conv2d_wgrad_seg_slabs(C.byref(d), first, count))
+        assert tot == splits
+        return [(slabs[first[i]:first[i] + count[i]], parts[first[i]:first[i] + count[i]] if parts is not None else None)
+                for i in range(len(xs))]
     return slabs, parts
 
 

@@ -126,6 +126,13 @@ long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p);
 /* number of split-K slabs the launch writes; with p->dw == NULL the slabs are left unreduced in `workspace`
  * ([splits][Cout][KH*KW][Cin] fp32) for effdet_unpack_conv_wgrad(..., nslabs = splits) to sum while unpacking. */
 int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p);
+/* Which slabs belong to which segment: first[s], count[s] (arrays of p->nseg ints) = the slab range of segment s in the
+ * `workspace` layout of effdet_conv2d_wgrad; returns the total (= effdet_conv2d_wgrad_splits) or an error.  With p->dw == NULL
+ * this makes the segments INDEPENDENT problems of one launch: same conv geometry, different x / dz tensors (in_off / out_off are
+ * element offsets from p->x / p->dz and may address other allocations) and different weight gradients -- each unpacked from
+ * its own slab range.  The 8 nodes of a BiFPN module (64 -> 64 3x3 convs on one level each, 19-89 us apiece as single
+ * launches because the small levels are one long dependent chain on 5..30 workgroups) leave as two such launches. */
+int effdet_conv2d_wgrad_seg_slabs(const effdet_wgrad_t* p, int* first, int* count);
 int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes, effdet_stream_t stream);
 
 /* OIHW fp32 master weight -> packed [Cout][KH*KW][Kpad] (mode 0, forward; channels >= Cin are

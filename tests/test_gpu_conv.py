@@ -325,6 +325,38 @@ def test_wgrad_grouped_pyramid(dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_independent_problems_in_one_launch(dtype):
+    """group=True: five maps in SEPARATE allocations, each with its own weight gradient, share one weight-gradient launch; every
+    problem's slab range unpacks to what a launch of its own gives (the BiFPN nodes' form), and to torch's gradient."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(13)
+    B, Cc = 4, 64
+    sizes = [(32, 32), (8, 8), (16, 16), (4, 4), (2, 2)]
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    dev = 'cuda'
+    xs = [torch.randn(B, Cc, h, w, generator=g) for h, w in sizes]
+    dzs = [torch.randn(B, Cc, h, w, generator=g) for h, w in sizes]
+    pad = [torch.empty(1000 * (i + 1), device=dev) for i in range(5)]              # keep the allocations apart
+    xm = [Map.of(t.permute(0, 2, 3, 1).contiguous().to(dev, dtype)) for t in xs]
+    zm = [Map.of(t.permute(0, 2, 3, 1).contiguous().to(dev, dtype)) for t in dzs]
+    outs = ops.conv2d_wgrad(xm, zm, Cin=Cc, Cout=Cc, KH=3, KW=3, pad_t=1, pad_l=1, group=True)
+    assert len(outs) == 5 and len(pad) == 5
+    tol = (_tol(dtype) if _tol(dtype) == TOL_X3 else 3e-4) if dtype == torch.float32 else 1e-2
+    for i, (G, dbp) in enumerate(outs):
+        dw = torch.empty(Cc, Cc, 3, 3, device=dev); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
+        G1, dbp1 = ops.conv2d_wgrad(xm[i], zm[i], Cin=Cc, Cout=Cc, KH=3, KW=3, pad_t=1, pad_l=1)
+        dw1 = torch.empty(Cc, Cc, 3, 3, device=dev); db1 = ops.unpack_wgrad(G1, dw1, dbias_part=dbp1)
+        wt = torch.zeros(Cc, Cc, 3, 3, requires_grad=True)
+        (F.conv2d(q(xs[i]), wt, None, 1, 1) * q(dzs[i])).sum().backward()
+        torch.cuda.synchronize()
+        assert_close(dw.cpu(), wt.grad, tol, 'grouped wgrad %d' % i)
+        assert_close(dw.cpu(), dw1.cpu(), 1e-4 if dtype == torch.float32 else 1e-2, 'grouped vs single %d' % i)    # (other split-K boundaries)
+        assert_close(db.cpu(), q(dzs[i]).sum(dim=(0, 2, 3)), tol, 'grouped dbias %d' % i)
+        assert_close(db.cpu(), db1.cpu(), 1e-4, 'grouped vs single dbias %d' % i)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_dgrad_via_flipped_weights(dtype):
     """Data gradient of a stride-1 conv = forward kernel on the mode-1 packed (flipped, transposed) weights."""
     from efficientdet.pytorch_amd import ops
