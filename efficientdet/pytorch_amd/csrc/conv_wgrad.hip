@@ -877,6 +877,151 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
   }
 }
 
+// ---- thin pointwise weight gradient: G[n][c] = sum_m dz[m][n] * x[m][c], few channels against 10^5..10^6 pixels ----
+// The 1x1 convs of the high-resolution backbone stages (16..144 channels on either side, 0.13..2.1 M pixels) are pure streaming
+// reads with a few-KiB result, but on the 128 x 128-tile kernels above a K-step of 32 pixels moves only 32 x (Cin + Cout) x 4 B
+// = 6..21 KiB behind a full tile's worth of staging instructions and mostly-padding MFMAs: 1.6-3.7 TB/s (D0 B = 32: ten launches,
+// 1.13 ms for 3.2 GB).  Here a stage is P = 64 / 128 whole pixel rows of both operands copied LINEARLY (contiguous NHWC: one byte
+// range each, 1-KiB DMA pieces, no per-row address work), three stages deep; the four waves own the 16 x 16 output tiles round
+// robin and walk the stage in groups of four pixels with exact v_mfma_f32_16x16x4_f32 (lane (i, k) reads dz[pixel k][n0 + i] and
+// x[pixel k][c0 + i] as plain ds_read_b32: the MFMA / LDS work is ~10 % of the HBM time).  fp32 products: used by the bf16x3
+// mode too (exact is at least as good).  Output: this split's slab row block + bias partial row, plain stores.
+// NTA x NTB = the 16 x 16 output tiles (Cout / 16 x Cin / 16, rounded up), compile-time so that a group's fragment reads and MFMAs
+// are straight-line code: every wave takes every 4th group of four pixels for ALL tiles (the first version gave each wave its own
+// tiles behind per-tile branches: one ds_read -> wait -> MFMA chain per basic block, 1.1 TB/s) and the four partial sums of a
+// tile meet in LDS at the end, added in wave order (bitwise reproducible).
+template <int NTA, int NTB>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p, int P, int pps, int NS) {
+  extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const WSeg sg = p.seg[0];
+  const int m_begin = split * p.mchunk, m_end = min(sg.M, m_begin + p.mchunk);
+  const int Cin = p.Cin, Cout = p.Cout;
+  const unsigned xrow = (unsigned)Cin * 4u, zrow = (unsigned)Cout * 4u;
+  const unsigned xstage = (unsigned)P * xrow, zstage = (unsigned)P * zrow;       // multiples of 1 KiB (P % 64 == 0, channels % 4 == 0)
+  const unsigned slot = xstage + zstage + 1024u;                                 // + a dump piece for the padded DMA slots
+  const int xp = (int)(xstage >> 10), np = xp + (int)(zstage >> 10);             // pieces: x first, then dz
+  const u32x4_t srd_x = make_srd_raw((const float*)p.x + sg.in_off, sg.x_bytes);
+  const u32x4_t srd_z = make_srd_raw((const float*)p.dz + sg.out_off, sg.dz_bytes);
+  const unsigned lds0 = lds_addr(smem);
+  const unsigned x_end = (unsigned)m_end * xrow, z_end = (unsigned)m_end * zrow;
+  const int nst = (m_end - m_begin + P - 1) / P;
+  // every wave issues exactly `pps` DMA instructions per stage (vmcnt arithmetic below); slots past the last piece go to the dump
+  auto stage = [&](int it) {
+    const unsigned base = lds0 + (unsigned)(it % NS) * slot;
+    const unsigned m0 = (unsigned)(m_begin + it * P);
+    for (int q = 0; q < pps; ++q) {
+      const int piece = wave + 4 * q;
+      if (piece < xp) {
+        const unsigned src = m0 * xrow + (unsigned)piece * 1024u + (unsigned)lane * 16u;
+        dma16_async(srd_x, base + (unsigned)piece * 1024u, src < x_end ? src : EFFDET_OOB);
+      } else if (piece < np) {
+        const unsigned src = m0 * zrow + (unsigned)(piece - xp) * 1024u + (unsigned)lane * 16u;
+        dma16_async(srd_z, base + (unsigned)piece * 1024u, src < z_end ? src : EFFDET_OOB);
+      } else {
+        dma16_async(srd_x, base + xstage + zstage, EFFDET_OOB);
+      }
+    }
+  };
+  auto wait_pieces = [&](int n) {      // at most n of this wave's DMA instructions still in flight (they return in order)
+    switch (n) {
+#define W_(v) case v: asm volatile("s_waitcnt vmcnt(" #v ")" ::: "memory"); break;
+      W_(1) W_(2) W_(3) W_(4) W_(5) W_(6) W_(7) W_(8) W_(9) W_(10) W_(11) W_(12) W_(13) W_(14) W_(15) W_(16)
+      W_(17) W_(18) W_(19) W_(20) W_(21) W_(22) W_(23) W_(24) W_(25) W_(26) W_(27) W_(28) W_(29) W_(30) W_(31) W_(32)
+      W_(33) W_(34) W_(35) W_(36) W_(37) W_(38) W_(39) W_(40) W_(41) W_(42) W_(43) W_(44) W_(45) W_(46) W_(47) W_(48)
+#undef W_
+      default: dma_wait_all(); break;
+    }
+  };
+  const int li = lane & 15, lk = lane >> 4;      // lane (i, k): row / column i of the operand tiles, pixel k of the group
+  // Lanes past the last channel of a partial tile (Cout = 24: rows 8..15 of tile 1) read ZEROS from the slot's dump piece instead of
+  // being masked after the load: a select behind every ds_read made hipcc wait for each read before issuing the next (seven
+  // serialised LDS round trips per group: 2.4 TB/s on the 16 -> 96 shape).  The dump piece only ever receives zero-filling DMA.
+  for (int i = tid; i < NS * 64; i += 256) ((uint4*)((char*)smem + (size_t)(i / 64) * slot + xstage + zstage))[i % 64] = make_uint4(0u, 0u, 0u, 0u);
+  const unsigned dump = xstage + zstage;         // slot-relative
+  bool oka[NTA], okb[NTB]; unsigned offa[NTA], offb[NTB];
+#pragma unroll
+  for (int a = 0; a < NTA; ++a) { const int n = 16 * a + li; oka[a] = n < Cout; offa[a] = (unsigned)n * 4u; }
+#pragma unroll
+  for (int b = 0; b < NTB; ++b) { const int c = 16 * b + li; okb[b] = c < Cin; offb[b] = (unsigned)c * 4u; }
+  f32x4 acc[NTA][NTB], accd[NTA];
+#pragma unroll
+  for (int a = 0; a < NTA; ++a) {
+    accd[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < NTB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const bool want_ds = p.dbp != nullptr;
+  const char* lds = (const char*)smem;
+  // NS slots, NS - 1 stages in flight: the loaded HBM round trip is 4-5 us here, i.e. ~100 KB per CU must be under way to stream at
+  // 20 GB/s per CU (three slots of a 112-channel stage, 57 KB in flight, gave 2.6 TB/s; two workgroups x two 24-KB stages 5.2)
+  for (int i = 0; i < NS - 1 && i < nst; ++i) stage(i);
+  for (int it = 0; it < nst; ++it) {
+    const int ahead = min(NS - 2, nst - 1 - it);
+    wait_pieces(ahead * pps);                    // stage `it` has landed (only the `ahead` later stages' pieces may still fly) ...
+    __syncthreads();                             // ... for every wave; everyone is done with stage it-1: its slot is free
+    if (it + NS - 1 < nst) stage(it + NS - 1);
+    const char* sl = lds + (size_t)(it % NS) * slot;
+    // groups of 4 pixels (one MFMA K-step), round robin over the waves, two groups per trip: all fragment reads, then the MFMAs
+    for (int g = wave; g < P / 4; g += 8) {
+      float fa[2][NTA], fb[2][NTB];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const unsigned px = (unsigned)(4 * (g + 4 * u) + lk);
+        const unsigned xr = px * xrow, zr = xstage + px * zrow;
+#pragma unroll
+        for (int a = 0; a < NTA; ++a) fa[u][a] = *(const float*)(sl + (oka[a] ? zr + offa[a] : dump));
+#pragma unroll
+        for (int b = 0; b < NTB; ++b) fb[u][b] = *(const float*)(sl + (okb[b] ? xr + offb[b] : dump));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int a = 0; a < NTA; ++a) {
+#pragma unroll
+          for (int b = 0; b < NTB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][a], fb[u][b], acc[a][b], 0, 0, 0);
+        }
+        // (unconditionally: a runtime branch around these made hipcc carry every accumulator through VGPR copies -- v_accvgpr_read
+        //  right behind each MFMA, i.e. a drained matrix pipe: 3x the MFMA time)
+#pragma unroll
+        for (int a = 0; a < NTA; ++a) accd[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u][a], 1.0f, accd[a], 0, 0, 0);
+      }
+    }
+  }
+  // ---- the four waves' partial tiles meet in LDS, TB tiles at a time ([wave][tile][lane] float4, 32 KiB: never more than the stage
+  //      ring, so the ring alone sets the occupancy), and are added in wave order by the batch's owner wave ----
+  constexpr int NT = NTA * NTB + NTA;             // + the bias tiles
+  constexpr int TB = 8;
+  f32x4* red = (f32x4*)smem;
+  float* slab = p.slab + (long long)split * Cout * Cin;
+#pragma unroll
+  for (int t0 = 0; t0 < NT; t0 += TB) {
+    __syncthreads();                              // (first trip: every wave is out of the last stage; later: the batch before is consumed)
+#pragma unroll
+    for (int tl = 0; tl < TB; ++tl) {
+      const int t = t0 + tl;
+      if (t < NTA * NTB) red[(wave * TB + tl) * 64 + lane] = acc[t / NTB][t % NTB];
+      else if (t < NT) red[(wave * TB + tl) * 64 + lane] = accd[t - NTA * NTB];
+    }
+    __syncthreads();
+    for (int tl = wave; tl < TB && t0 + tl < NT; tl += 4) {
+      const int t = t0 + tl;
+      const f32x4 v = (red[(0 * TB + tl) * 64 + lane] + red[(1 * TB + tl) * 64 + lane]) + (red[(2 * TB + tl) * 64 + lane] + red[(3 * TB + tl) * 64 + lane]);
+      if (t < NTA * NTB) {
+        const int a = t / NTB, b = t - a * NTB, c = 16 * b + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = 16 * a + 4 * lk + r; if (n < Cout && c < Cin) slab[(long long)n * Cin + c] = v[r]; }
+      } else if (want_ds && li == 0) {
+        const int a = t - NTA * NTB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = 16 * a + 4 * lk + r; if (n < Cout) p.dbp[(long long)split * Cout + n] = v[r]; }
+      }
+    }
+  }
+}
+
 // dw[i] += sum_s slab[s][i]      (16-byte vectorised, fully coalesced)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int splits) {
   const long long n4 = n >> 2;
@@ -1020,10 +1165,31 @@ static bool split_all_eligible(const effdet_wgrad_t* pv, const WgradK& k) {
   return true;
 }
 
+// (Cout / 16, Cin / 16) tile shapes conv_wgrad_thin_kernel is built for: EfficientNet-B0..B2's high-resolution 1x1 convs
+static int thin_combo(int nta, int ntb) {
+  static const int combos[][2] = {{1, 2}, {6, 1}, {2, 6}, {9, 2}, {2, 9}, {3, 9}, {1, 1}, {2, 1}, {1, 3}, {2, 2}};
+  for (int i = 0; i < (int)(sizeof(combos) / sizeof(combos[0])); ++i) if (combos[i][0] == nta && combos[i][1] == ntb) return i;
+  return -1;
+}
+// Does the (normalised) descriptor go to conv_wgrad_thin_kernel?  One contiguous pointwise level, few channels, many pixels.
+static bool thin_eligible(const effdet_wgrad_t* p, bool splitfmt) {
+  static const int on = getenv("EFFDET_WGRAD_THIN") ? atoi(getenv("EFFDET_WGRAD_THIN")) : 1;      // A/B switch
+  if (!on || splitfmt || !p || p->dtype != EFFDET_F32 || p->nseg != 1) return false;
+  if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad_t || p->pad_l) return false;
+  const effdet_seg_t& g = p->seg[0];
+  if (g.Ho != g.H || g.Wo != g.W || p->ldx != p->Cin || p->lddz != p->Cout || (p->Cin & 3) || (p->Cout & 3)) return false;
+  if (g.in_bstride != (long long)g.H * g.W * p->ldx || g.out_bstride != (long long)g.Ho * g.Wo * p->lddz) return false;
+  if ((g.in_off & 3) || (g.out_off & 3) || p->Cin + p->Cout > 192) return false;
+  if (thin_combo((p->Cout + 15) / 16, (p->Cin + 15) / 16) < 0) return false;
+  // the final reduction needs 4 x (tiles + bias tiles) x 1 KiB inside the three stage slots
+  return (long long)p->B * g.Ho * g.Wo >= 32768;
+}
+#define WGRAD_TILE(p, q) (q##_split ? 256 : (thin_eligible(p, q##_split) ? 256 : 128))
+
 extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  if (plan(p, k, splits, pn_split ? 256 : 128) != EFFDET_OK) return -1;
+  if (plan(p, k, splits, WGRAD_TILE(p, pn)) != EFFDET_OK) return -1;
   if (pn_split) {
     if (!split_all_eligible(p, k)) return -1;
     return (long long)splits * pn_cout * ((long long)(k.K / 2) + 1) * (long long)sizeof(float);
@@ -1034,7 +1200,7 @@ extern "C" long long effdet_conv2d_wgrad_workspace_bytes(const effdet_wgrad_t* p
 extern "C" int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p) {
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  if (plan(p, k, splits, pn_split ? 256 : 128) != EFFDET_OK) return -1;
+  if (plan(p, k, splits, WGRAD_TILE(p, pn)) != EFFDET_OK) return -1;
   if (pn_split && !split_all_eligible(p, k)) return -1;
   return splits;
 }
@@ -1098,11 +1264,18 @@ static int seg_slab_ranges(const effdet_wgrad_t* p, const WgradK& k, bool x3, bo
   return sf;
 }
 
+extern "C" int effdet_conv2d_wgrad_kernel(const effdet_wgrad_t* p) {
+  if (!p) return EFFDET_EINVAL;
+  WGRAD_NORMALISE_DTYPE(p, pn);
+  if (pn_split) return 2;
+  return thin_eligible(p, false) ? 1 : 0;
+}
+
 extern "C" int effdet_conv2d_wgrad_seg_slabs(const effdet_wgrad_t* p, int* first, int* count) {
   if (!p || !first || !count) return EFFDET_EINVAL;
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  const int rc = plan(p, k, splits, pn_split ? 256 : 128);
+  const int rc = plan(p, k, splits, WGRAD_TILE(p, pn));
   if (rc != EFFDET_OK) return rc;
   if (pn_split && !split_all_eligible(p, k)) return EFFDET_EUNSUPPORTED;
   bool fast[EFFDET_MAX_SEG];
@@ -1115,7 +1288,7 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   if (!p || !p->x || !p->dz || !workspace) return EFFDET_EINVAL;
   WGRAD_NORMALISE_DTYPE(p, pn);
   WgradK k; int splits = 0;
-  const int rc = plan(p, k, splits, pn_split ? 256 : 128);
+  const int rc = plan(p, k, splits, WGRAD_TILE(p, pn));
   if (rc != EFFDET_OK) return rc;
   if (pn_split) {
     // split-layout operands: one launch of the transpose-read kernel in its three-product form (k = the bf16 VIEW for staging;
@@ -1155,6 +1328,53 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   k.dbp = p->dbias ? (float*)workspace + (long long)splits * n : nullptr;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
+  if (thin_eligible(p, false)) {
+    // Stage size P (pixels) and ring depth NS, measured per channel budget (tools/wgrad_thin_bench.py, B = 32): the kernel is bound by
+    // its LDS-read + fp32-MFMA loop (knock-outs: DMA alone streams at 5.2-6.1 TB/s, the loop alone at 3.6-4.8), so what pays is TWO
+    // workgroups per CU taking turns -- slots small enough for that -- not a deeper ring in one workgroup:
+    //   <= 64 channels  P 128 x 3 slots   32 -> 16: 79 us (tiled kernel 264)
+    //   <= 128          P 64 x 2          16 -> 96: 229 (292), 96 -> 24: 69 (81)
+    //   wider           P 32 x 3          24 -> 144: 99 (138), 144 -> 24: 78 (134), 144 -> 40: 35 (41)
+    const int ch = p->Cin + p->Cout;
+    int P = ch <= 64 ? 128 : (ch <= 128 || (p->Cin & 7) || (p->Cout & 7)) ? 64 : 32;
+    int NS = (ch > 64 && ch <= 128) ? 2 : 3;
+    if (getenv("EFFDET_THIN_P")) P = atoi(getenv("EFFDET_THIN_P"));                         // tuning overrides (P % 64 == 0, or 32 with channels % 8 == 0)
+    if (getenv("EFFDET_THIN_NS")) NS = atoi(getenv("EFFDET_THIN_NS"));
+    if (P < 32 || (P & 31) || ((P * p->Cin) & 255) || ((P * p->Cout) & 255) || NS < 2 || NS > 6) return EFFDET_EINVAL;
+    const int np = P * ch * 4 / 1024, pps = (np + 3) / 4;                                   // 1-KiB DMA pieces per stage / per wave
+    const int nta = (p->Cout + 15) / 16, ntb = (p->Cin + 15) / 16;
+    const size_t slot = (size_t)P * ch * 4 + 1024;
+    while (NS > 2 && (NS - 2) * pps > 48) --NS;                                              // (the vmcnt immediates the kernel has)
+    size_t ldt = (size_t)NS * slot;
+    if (ldt < 32 * 1024) ldt = 32 * 1024;                                                   // the final cross-wave reduction (8 tiles x 4 waves)
+#define THIN_LAUNCH(A, B) do { EFFDET_SET_MAX_LDS((conv_wgrad_thin_kernel<A, B>), ldt); \
+      hipLaunchKernelGGL((conv_wgrad_thin_kernel<A, B>), dim3((unsigned)splits), dim3(256), ldt, st, k, P, pps, NS); } while (0)
+    switch (thin_combo(nta, ntb)) {
+      case 0: THIN_LAUNCH(1, 2); break;
+      case 1: THIN_LAUNCH(6, 1); break;
+      case 2: THIN_LAUNCH(2, 6); break;
+      case 3: THIN_LAUNCH(9, 2); break;
+      case 4: THIN_LAUNCH(2, 9); break;
+      case 5: THIN_LAUNCH(3, 9); break;
+      case 6: THIN_LAUNCH(1, 1); break;
+      case 7: THIN_LAUNCH(2, 1); break;
+      case 8: THIN_LAUNCH(1, 3); break;
+      default: THIN_LAUNCH(2, 2); break;
+    }
+#undef THIN_LAUNCH
+    EFFDET_CHECK_LAUNCH();
+    if (p->dw) {
+      long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
+      EFFDET_CHECK_LAUNCH();
+      if (p->dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((p->Cout + 255) / 256)), dim3(256), 0, st, (const float*)k.dbp, p->dbias,
+                           p->Cout, splits);
+        EFFDET_CHECK_LAUNCH();
+      }
+    }
+    return EFFDET_OK;
+  }
   // Partition the pyramid levels between the two kernels; each launch numbers its own splits from 0 and owns a
   // contiguous range of slabs (the slab order is irrelevant to the reduction).
   WgradK kf = k, ks = k;            // fast (DMA staging: bf16 LDS-transpose-read / fp32 direct-operand) / slow (register transpose)

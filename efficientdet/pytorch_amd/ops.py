@@ -372,15 +372,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
 
 
-def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False,
-                 image_splits=False, group=False):
-    """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
-    split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
-    runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ...
-    group=True (dw None, <= 5 maps): the maps are INDEPENDENT problems of the same conv geometry (different tensors, different
-    weights) sharing one launch -> a list of (slabs_i, parts_i), one per map (effdet_conv2d_wgrad_seg_slabs)."""
-    if isinstance(xs, Map):
-        xs, dzs = [xs], [dzs]
+def _wgrad_desc(xs, dzs, dw, dbias, Cin, Cout, KH, KW, stride, pad_t, pad_l, want_bias, split, image_splits):
     d = L.WgradDesc()
     x0, z0 = xs[0], dzs[0]
     isz = x0.t.element_size()
@@ -395,6 +387,26 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     d.ldx, d.lddz = x0.ld, z0.ld
     d.image_splits = int(image_splits)        # split-K boundaries on image boundaries: slabs [B*q], slab s = image s // q (one level only)
     _segs(d, xs, dzs, base_x, base_z, isz, z0.t.element_size())
+    return d
+
+
+def conv2d_wgrad_kernel_id(x, dz, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, split=False):
+    """Which kernel conv2d_wgrad would launch for one map pair (effdet_conv2d_wgrad_kernel): 0 tiled, 1 thin pointwise, 2 split."""
+    d = _wgrad_desc([x], [dz], None, None, Cin, Cout, KH, KW, stride, pad_t, pad_l, True, split, False)
+    return int(L.lib().effdet_conv2d_wgrad_kernel(C.byref(d)))
+
+
+def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, want_bias=True, split=False,
+                 image_splits=False, group=False):
+    """Weight gradient -> (slabs [splits][Cout][taps][Cin] fp32, bias partial rows [splits][Cout] fp32 or None): the UNREDUCED
+    split-K partials for unpack_wgrad / unpack_wgrad_bn to sum, in slab order, while unpacking (no float atomics anywhere: two
+    runs are bitwise equal).  With dw given (packed [Cout][taps][Cin] fp32) the library reduces itself: dw += ..., dbias += ...
+    group=True (dw None, <= 5 maps): the maps are INDEPENDENT problems of the same conv geometry (different tensors, different
+    weights) sharing one launch -> a list of (slabs_i, parts_i), one per map (effdet_conv2d_wgrad_seg_slabs)."""
+    if isinstance(xs, Map):
+        xs, dzs = [xs], [dzs]
+    x0 = xs[0]
+    d = _wgrad_desc(xs, dzs, dw, dbias, Cin, Cout, KH, KW, stride, pad_t, pad_l, want_bias, split, image_splits)
     flops = 2.0 * KH * KW * Cin * Cout * sum(z.B * z.H * z.W for z in dzs)
     splits = int(L.lib().effdet_conv2d_wgrad_splits(C.byref(d)))
     if splits < 1:
@@ -405,7 +417,8 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
     # (bf16: DMA + LDS-transpose-read kernel, fp32: DMA + direct-operand kernel; levels neither can take use the register-transpose kernel)
     _timed('conv_wgrad_tr_kernel<8>' if x0.dtype == torch.bfloat16 else
            ('conv_wgrad_split_kernel' if split else
-            ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>')), flops,
+            ('conv_wgrad_thin_kernel' if int(L.lib().effdet_conv2d_wgrad_kernel(C.byref(d))) == 1 else
+             ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>'))), flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
            'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))

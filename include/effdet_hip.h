@@ -133,6 +133,10 @@ int effdet_conv2d_wgrad_splits(const effdet_wgrad_t* p);
  * its own slab range.  The 8 nodes of a BiFPN module (64 -> 64 3x3 convs on one level each, 19-89 us apiece as single
  * launches because the small levels are one long dependent chain on 5..30 workgroups) leave as two such launches. */
 int effdet_conv2d_wgrad_seg_slabs(const effdet_wgrad_t* p, int* first, int* count);
+/* Which kernel serves the descriptor: 0 = the 128 x 128-tile kernels (DMA-staged / register-transpose, per level), 1 = the thin
+ * pointwise kernel (one contiguous 1x1 level, Cin + Cout <= 192, >= 32768 pixels: exact fp32 MFMA on linearly staged pixel
+ * rows -- also in the EFFDET_F32_BF16X3 mode), 2 = the split-layout kernel. */
+int effdet_conv2d_wgrad_kernel(const effdet_wgrad_t* p);
 int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, long long workspace_bytes, effdet_stream_t stream);
 
 /* OIHW fp32 master weight -> packed [Cout][KH*KW][Kpad] (mode 0, forward; channels >= Cin are

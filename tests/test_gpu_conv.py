@@ -296,6 +296,41 @@ def test_wgrad_shapes(dtype):
     _run_wgrad(dtype, 4, 64, 64, 144, 24, 1, pad=(0, 0, 0, 0))
 
 
+def test_thin_pointwise_wgrad_kernel():
+    """conv_wgrad_thin_kernel (fp32 storage, exact fp32 MFMA in both arithmetic modes): the backbone's high-resolution 1x1 shapes,
+    partial 16-channel tiles, a pixel count that is not a whole stage, per-image slabs -- against torch and bitwise run to run."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    dev = 'cuda'
+    g = torch.Generator().manual_seed(21)
+    for (B, H, W, Cin, Cout) in [(8, 64, 64, 16, 96), (8, 64, 64, 32, 16), (8, 64, 64, 24, 144), (8, 64, 64, 144, 24), (9, 60, 64, 144, 40),
+                                 (8, 64, 64, 96, 24), (3, 128, 128, 16, 16)]:
+        x = torch.randn(B, H, W, Cin, generator=g).to(dev); dz = torch.randn(B, H, W, Cout, generator=g).to(dev)
+        xm, zm = Map.of(x), Map.of(dz)
+        assert ops.conv2d_wgrad_kernel_id(xm, zm, Cin=Cin, Cout=Cout, KH=1, KW=1) == 1
+        ref = torch.einsum('bhwn,bhwc->nc', dz.double(), x.double())
+        G, dbp = ops.conv2d_wgrad(xm, zm, Cin=Cin, Cout=Cout, KH=1, KW=1)
+        G2, dbp2 = ops.conv2d_wgrad(xm, zm, Cin=Cin, Cout=Cout, KH=1, KW=1)
+        assert torch.equal(G, G2) and torch.equal(dbp, dbp2)
+        got = G.double().sum(0).view(Cout, Cin)
+        scale = float(ref.abs().max())
+        assert float((got - ref).abs().max()) <= 2e-5 * scale, (B, H, W, Cin, Cout)
+        assert float((dbp.double().sum(0) - dz.double().sum(dim=(0, 1, 2))).abs().max()) <= 2e-5 * float(dz.double().sum(dim=(0, 1, 2)).abs().max() + 1)
+        if (H * W) % 32 == 0:
+            Gi, _ = ops.conv2d_wgrad(xm, zm, Cin=Cin, Cout=Cout, KH=1, KW=1, image_splits=True)       # slab s = image s // q
+            q = Gi.shape[0] // B
+            per = Gi.double().view(B, q, Cout, Cin).sum(1)
+            refi = torch.einsum('bhwn,bhwc->bnc', dz.double(), x.double())
+            assert float((per - refi).abs().max()) <= 2e-5 * float(refi.abs().max())
+    # not this kernel: few pixels, wide rows, 3x3
+    xs, zs = Map.of(torch.zeros(2, 16, 16, 16, device=dev)), Map.of(torch.zeros(2, 16, 16, 96, device=dev))
+    assert ops.conv2d_wgrad_kernel_id(xs, zs, Cin=16, Cout=96, KH=1, KW=1) == 0
+    xw, zw = Map.of(torch.zeros(8, 64, 64, 240, device=dev)), Map.of(torch.zeros(8, 64, 64, 40, device=dev))
+    assert ops.conv2d_wgrad_kernel_id(xw, zw, Cin=240, Cout=40, KH=1, KW=1) == 0
+    x3_, z3_ = Map.of(torch.zeros(8, 64, 64, 64, device=dev)), Map.of(torch.zeros(8, 64, 64, 64, device=dev))
+    assert ops.conv2d_wgrad_kernel_id(x3_, z3_, Cin=64, Cout=64, KH=3, KW=3, pad_t=1, pad_l=1) == 0
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_wgrad_grouped_pyramid(dtype):
     """One wgrad launch over 5 pyramid levels that share a weight (levels split between the two bf16 kernels)."""
