@@ -149,25 +149,33 @@ def _t(m):
 
 class _StemFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train):
+    def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train, link=None):
         ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
         if isinstance(img, PackedImages) and (img.map.dtype != dtype or img.map.C != Fn.chunk_elems(dtype)):
             raise RuntimeError('PackedImages were packed for %s / %d channels, the model computes in %s'
                                % (img.map.dtype, img.map.C, dtype))
         y, saved = Fn.stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train)
         ctx.saved = saved if train else None
+        # link to the one consumer (block 0): if its backward applied this Swish' itself (see _MBConvFn) it says so here
+        ctx.link = link if train else None
+        if link is not None:
+            link['z'] = saved[1] if train else None
         return _t(y)
 
     @staticmethod
     def backward(ctx, dy):
         ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
-        dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()))
+        fused = bool(ctx.link and ctx.link.pop('dz_done', False))
+        dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()), dy_is_dz=fused)
         ctx.saved = None
-        return None, dw, dg, db, None, None, None, None, None
+        return None, dw, dg, db, None, None, None, None, None, None
 
 
 _MB_KEYS = ('expand.weight', 'bn0.weight', 'bn0.bias', 'dw.weight', 'bn1.weight', 'bn1.bias', 'se_reduce.weight',
             'se_reduce.bias', 'se_expand.weight', 'se_expand.bias', 'project.weight', 'bn2.weight', 'bn2.bias')
+
+
+STEM_LINK = os.environ.get('EFFDET_STEM_LINK', '1') == '1'        # A/B switch: the stem's Swish' inside block 0's depthwise data gradient
 
 
 class _MBConvFn(torch.autograd.Function):
@@ -177,7 +185,11 @@ class _MBConvFn(torch.autograd.Function):
         P = dict(buffers)
         keys = [k for k in _MB_KEYS if not (blk.expand == 1 and k in ('expand.weight', 'bn0.weight', 'bn0.bias'))]
         P.update(dict(zip(keys, params)))
-        y, saved = Fn.mbconv_fwd(Map.of(x), blk, P, dtype, train, rowscale)
+        # 'stem_link' (block 0 only, expand == 1, no skip): the stem's pre-activation -- this block's depthwise data gradient then
+        # returns d(loss)/d(z_stem) and tells the stem node so (one full pass over the 256 x 256 x 32 map less per step)
+        link = buffers.get('stem_link') if (train and blk.expand == 1 and not blk.skip and STEM_LINK) else None
+        ctx.link = link
+        y, saved = Fn.mbconv_fwd(Map.of(x), blk, P, dtype, train, rowscale, xpre=link['z'] if link else None)
         ctx.saved, ctx.keys = (saved if train else None), keys
         return _t(y)
 
@@ -189,6 +201,8 @@ class _MBConvFn(torch.autograd.Function):
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
             ops.add_inplace(dx, Map.of(dy.contiguous()))
         keys = ctx.keys
+        if ctx.link is not None:
+            ctx.link['dz_done'] = True; ctx.link.pop('z', None)
         ctx.saved = None
         return (_t(dx), None, None, None, None, None) + tuple(g[k] for k in keys)
 
@@ -424,7 +438,8 @@ class EfficientDet(nn.Module):
             self._prep[key].begin_step(img.device)
         bn = bb._bn0
         train = torch.is_grad_enabled()
-        x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train)
+        link = {} if (train and STEM_LINK) else None
+        x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train, link)
         feats = []
         rowscales = self._drop_connect_rowscales(int(img.shape[0]), img.device) if (self.training and bb.drop_connect_rate) else {}
         for i, (blk, m) in enumerate(zip(bb.plan, bb._blocks)):
@@ -436,6 +451,8 @@ class EfficientDet(nn.Module):
                 params += [m._expand_conv.weight, m._bn0.weight, m._bn0.bias]
             params += [m._depthwise_conv.weight, m._bn1.weight, m._bn1.bias, m._se_reduce.weight, m._se_reduce.bias,
                        m._se_expand.weight, m._se_expand.bias, m._project_conv.weight, m._bn2.weight, m._bn2.bias]
+            if i == 0 and link is not None:
+                buffers['stem_link'] = link
             rowscale = rowscales.get(i)                         # models/efficientnet.py:199-203, models/utils.py:79-90
             x = _MBConvFn.apply(x, blk, dt, rowscale, buffers, train, *params)
             if blk.stage_end:

@@ -72,22 +72,23 @@ def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train):
     return y, (x, z, s, inv, mean, w, pad)
 
 
-def stem_bwd(saved, dy):
+def stem_bwd(saved, dy, dy_is_dz=False):
+    """dy_is_dz: the incoming gradient already went through the stem's Swish' (fused into block 0's depthwise data gradient)."""
     x, z, s, inv, mean, w, pad = saved
     Cout, ce = w.shape[0], x.C
-    dz = ops.act_bwd(dy, z, ACT_SWISH)
+    dz = dy if dy_is_dz else ops.act_bwd(dy, z, ACT_SWISH)
     G, dsum = ops.conv2d_wgrad(x, dz, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0])
     dw, dg, db = ops.unpack_wgrad_bn(G, w, s, dsum, mean, inv, cin_pad=ce)     # + frozen-BN gamma/beta grads, one launch
     return dw, dg, db
 
 
 # ------------------------------------------------------------------------------------------ MBConv
-def mbconv_fwd(x, blk, P, dtype, train, rowscale=None):
+def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None):
     """models/efficientnet.py:75-105.  P: dict of parameter / buffer tensors of the block.
     rowscale: optional [B] fp32 = drop_connect keep-mask / keep_prob (models/utils.py:79-90)."""
     dev = x.t.device
     B, H, W = x.B, x.H, x.W
-    sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale}
+    sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale, 'xpre': xpre}      # xpre: see mbconv_bwd (expand == 1 blocks)
     dw_in_act = ACT_NONE
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
     if blk.expand != 1:
@@ -172,7 +173,9 @@ def mbconv_bwd(sv, dy):
     gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0], in_act=sv['dw_in_act'])
     g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,
                                                                              P['bn1.running_mean'], sv['i1'])
-    dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else None, H, W, blk.k, blk.stride,
+    # (expand == 1, i.e. block 0: the depthwise conv reads the block input itself; given the pre-activation `xpre` of the producer --
+    #  the stem's z -- its Swish' is applied here, in the data gradient's epilogue, instead of a separate pass in the stem's backward)
+    dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else sv.get('xpre'), H, W, blk.k, blk.stride,
                            blk.pad[0], blk.pad[0])
     if blk.expand == 1:
         return dze, g           # block 0: depthwise acts on the block input directly, no skip
