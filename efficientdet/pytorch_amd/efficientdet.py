@@ -236,8 +236,8 @@ class _NeckFn(torch.autograd.Function):
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
         with ops.unpack_batch():                                   # 8 unpacks per module + 5 laterals: two launches for the node
-            for sv in reversed(saved_mods):
-                d, dw1, dw2, dcw, dcb = Fn.bifpn_module_bwd(sv, d, dtype)
+            for k, sv in enumerate(reversed(saved_mods)):
+                d, dw1, dw2, dcw, dcb = Fn.bifpn_module_bwd(sv, d, dtype, own=k > 0)
                 mod_grads.append((dw1, dw2) + tuple(dcw) + tuple(dcb))
             dfs, dlw, dlb = Fn.lateral_bwd(feats, lw, d, dtype)
         ctx.saved = None

@@ -250,14 +250,15 @@ def bifpn_module_fwd(p, w1, w2, cw, cb, dtype, train):
     return cur, saved
 
 
-def bifpn_module_bwd(saved, douts, dtype):
-    """-> (d_inputs [5 Maps], dw1, dw2, dcw [8], dcb [8])."""
+def bifpn_module_bwd(saved, douts, dtype, own=False):
+    """-> (d_inputs [5 Maps], dw1, dw2, dcw [8], dcb [8]).  own: `douts` are private buffers of the caller (the d_inputs of the next
+    module's backward) and may be accumulated into; gradients handed over by autograd are copied first."""
     nodes, names, out_names, w1, w2, cw = saved
     dev = w1.device
     Wc = cw[0].shape[0]
     grads = {}                                   # tensor name -> Map (private, safe to accumulate into)
     for n, d in zip(out_names, douts):
-        grads[n] = Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
+        grads[n] = d if own else Map.of(d.tensor().clone())    # never write into autograd's grad_outputs
     n1, n2 = ops.fuse_dn_floats(w1.shape[1]), ops.fuse_dn_floats(w2.shape[1])
     ar = ZeroArena(ZeroArena.need(n1, n2), dev)
     dn1, dn2 = ar.take(n1), ar.take(n2)     # per-workgroup partial rows of d loss / d n_r (zeroed: a column without a launch adds nothing)
