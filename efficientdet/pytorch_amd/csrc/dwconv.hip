@@ -100,6 +100,22 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
                   ok ? img_off + (unsigned)((hi * p.W + wi) * p.C + (chunk0 + st_cq) * CE) * ES : EFFDET_OOB);
     }
   };
+  // z-only storage of the expand conv (training): the staged tile holds pre-activations -- Swish them ONCE, in place (the zero padding
+  // stays zero: swish(0) = 0), instead of the conv writing a second, activated copy.  Every lane Swishes exactly the 16 bytes it
+  // DMA'd itself, right behind its own wave's wait: no workgroup barrier of its own (the barrier at the top of the tile loop
+  // publishes the result), and the pass of one wave runs under the stores / taps of the others.  (As a workgroup-wide pass with its
+  // own barrier it cost 15 % of the k5 launches.)
+  auto swish_own = [&](int buf) {
+    if (!p.in_act) return;
+    for (int piece = wave; piece < NPIECE; piece += 4) {
+      uint4* q = xt + buf * TILE + piece * 64 + lane;
+      float v[CE];
+      Chunk<T>::unpack(*q, v);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = swishf_(v[e]);
+      *q = Chunk<T>::pack(v);
+    }
+  };
   stage(t0, 0);
   for (int i = tid; i < K * K * CQ * CE; i += 256) {
     const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
@@ -118,31 +134,22 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     for (int e = 0; e < CE; ++e) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
   }
   const int HoWo = p.Ho * p.Wo;
+  // (A vertical sliding window over the tap columns -- NOUT adjacent rows per thread, 65 instead of 125 LDS reads for k5 -- was measured:
+  //  k5 / stride-1 launches -10 %, everything else +-0, and it changes the fp32 summation order of every depthwise output.  Not kept.)
+  auto OP = [&](int o) { return ps + NPS * o; };
   dma_wait_all();
+  swish_own(0);
   for (int tile = t0; tile < t1; ++tile) {
     const int cur = (p.nbuf == 2) ? ((tile - t0) & 1) : 0;
-    __syncthreads();                                    // tile `tile` is in LDS for every wave; the other buffer is free
+    __syncthreads();                                    // tile `tile` is in LDS (Swished) for every wave; the other buffer is free
     if (p.nbuf == 2 && tile + 1 < t1) stage(tile + 1, cur ^ 1);
-    if (p.in_act) {
-      // z-only storage of the expand conv (training): the staged tile holds pre-activations -- Swish them ONCE, in place (the
-      // zero padding stays zero: swish(0) = 0), instead of the conv writing a second, activated copy (-1 of its 2 output streams;
-      // these kernels are HBM-bound with ~100 VALU slots per output to spare)
-      uint4* xw = xt + cur * TILE;
-      for (int i = tid; i < TILE; i += 256) {
-        float v[CE];
-        Chunk<T>::unpack(xw[i], v);
-#pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] = swishf_(v[e]);
-        xw[i] = Chunk<T>::pack(v);
-      }
-      __syncthreads();
-    }
     const uint4* xb = xt + cur * TILE;
     float acc[NOUT][CE];
 #pragma unroll
     for (int o = 0; o < NOUT; ++o)
 #pragma unroll
       for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+    {
 #pragma unroll 1
     for (int kh = 0; kh < K; ++kh) {           // NOT unrolled: the full K*K*NOUT unroll spilled to scratch (occupancy 1)
 #pragma unroll
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
         }
       }
     }
+    }
     const int oh0 = (tile / tiles_x) * TL::TH, ow0 = (tile % tiles_x) * TL::TW;
     uint4 zq[NOUT], yq[NOUT];
 #pragma unroll
@@ -178,9 +186,10 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
     // this wave's pieces of the NEXT tile have landed (they had the whole tap loop); waiting here, ahead of the stores,
     // keeps the stores of this tile in flight across the barrier and the next tile's taps
     dma_wait_all();
+    if (p.nbuf == 2 && tile + 1 < t1) swish_own(cur ^ 1);
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) {
-      const int op = ps + NPS * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
+      const int op = OP(o), oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
       if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
       const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
       if (p.z) *(uint4*)((T*)p.z + off) = zq[o];
@@ -194,6 +203,7 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
       __syncthreads();
       stage(tile + 1, 0);
       dma_wait_all();
+      swish_own(0);
     }
   }
   if (p.pool) {
@@ -434,7 +444,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
   typedef DwTile<K, S> TL;
   constexpr int CE = Elem<T>::CE;
   constexpr unsigned ES = sizeof(T);
-  constexpr int CPT = (K == 5 && CE == 8) ? 4 : CE;       // channels per thread: K*K*CPT accumulators must fit in registers
+  // channels per thread: K*K*CPT accumulators must fit in registers.  k = 5 in fp32 with 4 channels: 100 accumulators, 172-192 VGPRs,
+  // 2 waves / SIMD and nothing to overlap the synchronous staging of a tile with (1.3-2.5 TB/s); with 2 channels a thread owns a whole
+  // 8-pixel tile row (12 LDS values feed 8 x 5 taps), ~110 VGPRs, 4 waves / SIMD.
+  constexpr int CPT = (K == 5) ? (CE == 8 ? 4 : 2) : CE;
   constexpr int NCG = CQ * CE / CPT, NPS = 256 / NCG;     // channel groups per CQ-chunk slab, pixel slots
   constexpr int NPIX = TL::TH * TL::TW, NOUT = NPIX / NPS;
   constexpr int ROWS = K * K + 1;
@@ -471,6 +484,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
     const char* q = (const char*)xt + (unsigned)slot * (CQ * 16u) + lds_c;
     if constexpr (CPT * ES == 16) {
       Chunk<T>::unpack(*(const uint4*)q, v);
+    } else if constexpr (ES == 4) {                       // fp32, 2 channels = 8 bytes
+      const uint2 u = *(const uint2*)q;
+      v[0] = __uint_as_float(u.x); v[1] = __uint_as_float(u.y);
     } else {                                              // bf16, 4 channels = 8 bytes
       const uint2 u = *(const uint2*)q;
       v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
@@ -501,7 +517,10 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
       else { const int op = ps + NPS * o; oh = oh0 + op / TL::TW; ow = ow0 + op % TL::TW; }
       const bool ok = cok && oh < p.Ho && ow < p.Wo;
       const unsigned off = ok ? dz_img + (unsigned)((oh * p.Wo + ow) * p.C + c0) * ES : EFFDET_OOB;
-      if constexpr (CPT == 4) {
+      if constexpr (CPT == 2) {                           // (fp32 only)
+        const u32x2_t u = __builtin_amdgcn_raw_buffer_load_b64(rz, (int)off, 0, 0);
+        d[o][0] = __uint_as_float(u[0]); d[o][1] = __uint_as_float(u[1]);
+      } else if constexpr (CPT == 4) {
         const f32x4 v = srd_load4<T>(rz, off);
         d[o][0] = v[0]; d[o][1] = v[1]; d[o][2] = v[2]; d[o][3] = v[3];
       } else {
@@ -521,6 +540,9 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
       }
       __syncthreads();
     }
+    int base2[NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) { const int op = ps + NPS * o; base2[o] = 2 * (op / TL::TW) * TL::IWP + op % TL::TW; }
     if (S == 1) {
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
@@ -539,15 +561,19 @@ __global__ __launch_bounds__(256) void dw_wgrad_lds_kernel(const DwK p) {
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) {
 #pragma unroll
-        for (int kw = 0; kw < K; ++kw)
+        for (int kw = 0; kw < K; ++kw) {
 #pragma unroll
           for (int o = 0; o < NOUT; ++o) {
-            const int op = ps + NPS * o, oh = op / TL::TW, ow = op % TL::TW;
+            // slot(2 oh + kh, 2 ow + kw) = [2 oh IWP + ow] + [kh IWP + (kw & 1) IWH + (kw >> 1)]: a per-output base (NOUT registers,
+            // hoisted) + a compile-time tap constant that folds into the ds_read offset.  Written as slot(...) hipcc kept all
+            // NOUT x K x K addresses in VGPRs across the tile loop (k5: 100 of 184).
             float xv[CPT];
-            ldx(TL::slot(oh * S + kh, ow * S + kw), xv);
+            ldx(base2[o] + (kh * TL::IWP + (kw & 1) * TL::IWH + (kw >> 1)), xv);
 #pragma unroll
             for (int e = 0; e < CPT; ++e) g[kh * K + kw][e] = fmaf(d[o][e], xv[e], g[kh * K + kw][e]);
           }
+          if constexpr (K == 5 && CE == 4) __builtin_amdgcn_sched_barrier(0);    // (k5 fp32: one tap at a time -- 184 -> VGPRs that allow 4 waves / SIMD)
+        }
         __builtin_amdgcn_sched_barrier(0);                // one tap row of LDS reads in flight (the full hoist spilled)
       }
     }
