@@ -1143,6 +1143,14 @@ int dispatch(ConvK& k, hipStream_t st) {
     // coarse BiFPN levels are 16..144 workgroups walking 18..36 K-steps at one DMA round trip each)
     static const int deep_env = getenv("EFFDET_IGEMM_DEEP") ? atoi(getenv("EFFDET_IGEMM_DEEP")) : 2;      // A/B switch
     if ((SPLIT ? deep_env >= 2 : deep_env >= 1) && (long long)k.mtiles * k.ntiles <= 256 && k.Kc >= 6 * 8) {
+      // a handful of 128-wide tiles with a long K loop (the project convs of the 8x8 / 4x4 stages: 16 x 2 tiles, 36 K-steps) are bound
+      // by the MFMA work of their few CUs (0.66 us per K-step on 32 of 256 CUs): narrower tiles spread the same work over 4x the CUs
+      static const int narrow = getenv("EFFDET_IGEMM_NARROW") ? atoi(getenv("EFFDET_IGEMM_NARROW")) : 64;     // A/B switch: max 128/64-wide tiles (0 = off); 27.91 -> 27.61 ms on the D0 step, 128 / 256 and shorter K loops measured the same
+      static const int narrow_k = getenv("EFFDET_IGEMM_NARROW_K") ? atoi(getenv("EFFDET_IGEMM_NARROW_K")) : 16;
+      if (narrow && bn >= 64 && (long long)k.mtiles * k.ntiles <= narrow && k.Kc >= narrow_k * 8) {
+        k.ntiles = (k.Cout + 31) / 32;
+        return launch<T, 32, 1, 4, SPLIT, 4>(k, st);
+      }
       if (bn == 128) return launch<T, 128, 2, 8, SPLIT, 4>(k, st);
       if (bn == 64) return launch<T, 64, 1, 4, SPLIT, 4>(k, st);
     }
