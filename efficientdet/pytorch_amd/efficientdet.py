@@ -154,7 +154,7 @@ class _StemFn(torch.autograd.Function):
         if isinstance(img, PackedImages) and (img.map.dtype != dtype or img.map.C != Fn.chunk_elems(dtype)):
             raise RuntimeError('PackedImages were packed for %s / %d channels, the model computes in %s'
                                % (img.map.dtype, img.map.C, dtype))
-        y, saved = Fn.stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train)
+        y, saved = Fn.stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train, z_only=link is not None)
         ctx.saved = saved if train else None
         # link to the one consumer (block 0): if its backward applied this Swish' itself (see _MBConvFn) it says so here
         ctx.link = link if train else None
@@ -189,7 +189,10 @@ class _MBConvFn(torch.autograd.Function):
         # returns d(loss)/d(z_stem) and tells the stem node so (one full pass over the 256 x 256 x 32 map less per step)
         link = buffers.get('stem_link') if (train and blk.expand == 1 and not blk.skip and STEM_LINK) else None
         ctx.link = link
-        y, saved = Fn.mbconv_fwd(Map.of(x), blk, P, dtype, train, rowscale, xpre=link['z'] if link else None)
+        xm = Map.of(x)
+        if link is not None:         # the stem stored its pre-activation only and `x` IS that tensor: same Map object for mbconv_fwd's test
+            xm = link['z'] if link['z'].t.data_ptr() == x.data_ptr() else xm
+        y, saved = Fn.mbconv_fwd(xm, blk, P, dtype, train, rowscale, xpre=link['z'] if link else None)
         ctx.saved, ctx.keys = (saved if train else None), keys
         return _t(y)
 
@@ -438,7 +441,7 @@ class EfficientDet(nn.Module):
             self._prep[key].begin_step(img.device)
         bn = bb._bn0
         train = torch.is_grad_enabled()
-        link = {} if (train and STEM_LINK) else None
+        link = {} if (train and STEM_LINK and bb.plan[0].expand == 1 and not bb.plan[0].skip) else None
         x = _StemFn.apply(img, bb._conv_stem.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, bb.stem_pad, dt, train, link)
         feats = []
         rowscales = self._drop_connect_rowscales(int(img.shape[0]), img.device) if (self.training and bb.drop_connect_rate) else {}

@@ -53,8 +53,10 @@ def as_map(t):
 
 
 # ------------------------------------------------------------------------------------------ stem
-def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train):
-    """models/efficientnet.py:193  swish(bn0(conv_stem(img)))  (3x3 s2, static same pad)."""
+def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train, z_only=False):
+    """models/efficientnet.py:193  swish(bn0(conv_stem(img)))  (3x3 s2, static same pad).
+    z_only (training, consumer = an expand-1 MBConv block handed `xpre`): only the PRE-activation is stored and returned -- the
+    block's depthwise kernels Swish their staged tiles (one 256 x 256 x 32 write stream less)."""
     ce = chunk_elems(dtype)
     B, _, H, W = img.shape
     if hasattr(img, 'map'):       # efficientdet.PackedImages: already NHWC / compute dtype / one chunk of channels
@@ -65,6 +67,10 @@ def stem_fwd(img, w, gamma, beta, mean, var, pad, dtype, train):
     wp = ops.pack_weight(w, dtype, cin_pad=ce)
     Cout = w.shape[0]
     Ho, Wo = conv_out(H, 3, 2, pad), conv_out(W, 3, 2, pad)
+    if z_only and train:
+        z = Map.new(B, Ho, Wo, Cout, dtype, img.device)
+        ops.conv2d(x, wp, z, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0], scale=s, shift=t, act=ACT_NONE)
+        return z, (x, z, s, inv, mean, w, pad)
     y = Map.new(B, Ho, Wo, Cout, dtype, img.device)
     z = Map.new(B, Ho, Wo, Cout, dtype, img.device) if train else None
     ops.conv2d(x, wp, y, Cin=ce, Cout=Cout, KH=3, KW=3, stride=2, pad_t=pad[0], pad_l=pad[0], scale=s, shift=t,
@@ -108,6 +114,8 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None):
         sv.update(s0=s0, i0=i0, ze=ze)
     else:
         xe = x
+        if sv.get('xpre') is not None and sv['xpre'] is x:      # the producer (the stem) handed its pre-activation ONLY (stem_fwd z_only)
+            dw_in_act = ACT_SWISH
     s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
     wk = ops.dw_pack_weight(P['dw.weight'])
     # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):
