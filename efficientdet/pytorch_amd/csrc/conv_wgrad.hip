@@ -890,7 +890,11 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_f32dma_kernel(const WgradK
 // are straight-line code: every wave takes every 4th group of four pixels for ALL tiles (the first version gave each wave its own
 // tiles behind per-tile branches: one ds_read -> wait -> MFMA chain per basic block, 1.1 TB/s) and the four partial sums of a
 // tile meet in LDS at the end, added in wave order (bitwise reproducible).
-template <int NTA, int NTB>
+// STEM = the one conv with an image as input (3x3, stride 2, 4 padded channels -> 32): the x "row" of an output pixel is its 9 taps x
+// 16 bytes gathered by the DMA lanes (lane = (pixel, tap): computed source address, halo taps out of range = zeros), i.e. an im2col row
+// of 36 floats = the packed [tap][channel] gradient row; everything behind the staging is the pointwise kernel with Cin = 36.
+// (On the 128 x 128-tile kernel this launch was 250 us for 402 MB: 97 % of its tile is padding.)
+template <int NTA, int NTB, bool STEM = false>
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p, int P, int pps, int NS) {
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -898,9 +902,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p, in
   const int split = blockIdx.x;
   const WSeg sg = p.seg[0];
   const int m_begin = split * p.mchunk, m_end = min(sg.M, m_begin + p.mchunk);
-  const int Cin = p.Cin, Cout = p.Cout;
+  const int Cin = STEM ? p.K : p.Cin, Cout = p.Cout;                              // (STEM: the 36 columns of the im2col row)
   const unsigned xrow = (unsigned)Cin * 4u, zrow = (unsigned)Cout * 4u;
   const unsigned xstage = (unsigned)P * xrow, zstage = (unsigned)P * zrow;       // multiples of 1 KiB (P % 64 == 0, channels % 4 == 0)
+  const int HoWo = sg.Ho * sg.Wo;
   const unsigned slot = xstage + zstage + 1024u;                                 // + a dump piece for the padded DMA slots
   const int xp = (int)(xstage >> 10), np = xp + (int)(zstage >> 10);             // pieces: x first, then dz
   const u32x4_t srd_x = make_srd_raw((const float*)p.x + sg.in_off, sg.x_bytes);
@@ -915,8 +920,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradK p, in
     for (int q = 0; q < pps; ++q) {
       const int piece = wave + 4 * q;
       if (piece < xp) {
-        const unsigned src = m0 * xrow + (unsigned)piece * 1024u + (unsigned)lane * 16u;
-        dma16_async(srd_x, base + (unsigned)piece * 1024u, src < x_end ? src : EFFDET_OOB);
+        unsigned src;
+        if constexpr (STEM) {
+          const int j = piece * 64 + lane, pl = j / 9, t = j - pl * 9;                   // chunk j of the stage = (pixel, tap)
+          const int m = (int)m0 + pl;
+          const int b = m / HoWo, rem = m - b * HoWo, ho = rem / sg.Wo, wo = rem - ho * sg.Wo;
+          const int hi = ho * 2 + t / 3 - p.pad_t, wi = wo * 2 + t % 3 - p.pad_l;
+          const bool ok = m < m_end && hi >= 0 && hi < sg.H && wi >= 0 && wi < sg.W;
+          src = ok ? (unsigned)((long long)b * sg.in_bs * 4 + ((long long)hi * sg.W + wi) * 16) : EFFDET_OOB;
+        } else {
+          src = m0 * xrow + (unsigned)piece * 1024u + (unsigned)lane * 16u;
+          src = src < x_end ? src : EFFDET_OOB;
+        }
+        dma16_async(srd_x, base + (unsigned)piece * 1024u, src);
       } else if (piece < np) {
         const unsigned src = m0 * zrow + (unsigned)(piece - xp) * 1024u + (unsigned)lane * 16u;
         dma16_async(srd_z, base + (unsigned)piece * 1024u, src < z_end ? src : EFFDET_OOB);
@@ -1171,18 +1187,25 @@ static int thin_combo(int nta, int ntb) {
   for (int i = 0; i < (int)(sizeof(combos) / sizeof(combos[0])); ++i) if (combos[i][0] == nta && combos[i][1] == ntb) return i;
   return -1;
 }
-// Does the (normalised) descriptor go to conv_wgrad_thin_kernel?  One contiguous pointwise level, few channels, many pixels.
-static bool thin_eligible(const effdet_wgrad_t* p, bool splitfmt) {
-  static const int on = getenv("EFFDET_WGRAD_THIN") ? atoi(getenv("EFFDET_WGRAD_THIN")) : 1;      // A/B switch
-  if (!on || splitfmt || !p || p->dtype != EFFDET_F32 || p->nseg != 1) return false;
-  if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad_t || p->pad_l) return false;
+// Does the (normalised) descriptor go to conv_wgrad_thin_kernel?  1 = one contiguous pointwise level, few channels, many pixels;
+// 2 = the stem's geometry (3x3 stride 2 on a 4-channel NHWC image, <= 32 output channels, pad 0 / 1); 0 = no.
+static int thin_eligible(const effdet_wgrad_t* p, bool splitfmt) {
+  static const int on = getenv("EFFDET_WGRAD_THIN") ? atoi(getenv("EFFDET_WGRAD_THIN")) : 1;      // A/B switch (2: pointwise form only)
+  if (!on || splitfmt || !p || p->dtype != EFFDET_F32 || p->nseg != 1) return 0;
   const effdet_seg_t& g = p->seg[0];
-  if (g.Ho != g.H || g.Wo != g.W || p->ldx != p->Cin || p->lddz != p->Cout || (p->Cin & 3) || (p->Cout & 3)) return false;
-  if (g.in_bstride != (long long)g.H * g.W * p->ldx || g.out_bstride != (long long)g.Ho * g.Wo * p->lddz) return false;
-  if ((g.in_off & 3) || (g.out_off & 3) || p->Cin + p->Cout > 192) return false;
-  if (thin_combo((p->Cout + 15) / 16, (p->Cin + 15) / 16) < 0) return false;
-  // the final reduction needs 4 x (tiles + bias tiles) x 1 KiB inside the three stage slots
-  return (long long)p->B * g.Ho * g.Wo >= 32768;
+  if (p->lddz != p->Cout || (p->Cout & 3) || (g.out_off & 3) || g.out_bstride != (long long)g.Ho * g.Wo * p->lddz) return 0;
+  if ((long long)p->B * g.Ho * g.Wo < 32768) return 0;
+  if (p->KH == 3 && p->KW == 3 && p->stride == 2) {
+    if (on == 2 || p->Cin != 4 || p->ldx != 4 || p->Cout <= 16 || p->Cout > 32 || (g.in_off & 3) || g.in_bstride != (long long)g.H * g.W * 4) return 0;
+    if (p->pad_t < 0 || p->pad_t > 1 || p->pad_l < 0 || p->pad_l > 1) return 0;
+    if (2 * (g.Ho - 1) - p->pad_t >= g.H || 2 * (g.Wo - 1) - p->pad_l >= g.W) return 0;       // every output pixel has its centre tap row/column start inside
+    return 2;
+  }
+  if (p->KH != 1 || p->KW != 1 || p->stride != 1 || p->pad_t || p->pad_l) return 0;
+  if (g.Ho != g.H || g.Wo != g.W || p->ldx != p->Cin || (p->Cin & 3)) return 0;
+  if (g.in_bstride != (long long)g.H * g.W * p->ldx) return 0;
+  if ((g.in_off & 3) || p->Cin + p->Cout > 192) return 0;
+  return thin_combo((p->Cout + 15) / 16, (p->Cin + 15) / 16) < 0 ? 0 : 1;
 }
 #define WGRAD_TILE(p, q) (q##_split ? 256 : (thin_eligible(p, q##_split) ? 256 : 128))
 
@@ -1268,7 +1291,7 @@ extern "C" int effdet_conv2d_wgrad_kernel(const effdet_wgrad_t* p) {
   if (!p) return EFFDET_EINVAL;
   WGRAD_NORMALISE_DTYPE(p, pn);
   if (pn_split) return 2;
-  return thin_eligible(p, false) ? 1 : 0;
+  return thin_eligible(p, false) ? 1 : 0;      // (the stem's form of the thin kernel reports 1 too)
 }
 
 extern "C" int effdet_conv2d_wgrad_seg_slabs(const effdet_wgrad_t* p, int* first, int* count) {
@@ -1328,7 +1351,28 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
   k.dbp = p->dbias ? (float*)workspace + (long long)splits * n : nullptr;
   const size_t lds = (size_t)4 * 128 * 8 * sizeof(uint4);
   hipStream_t st = (hipStream_t)stream;
-  if (thin_eligible(p, false)) {
+  const int thin = thin_eligible(p, false);
+  if (thin == 2) {
+    // the stem: 64 output pixels per stage = 9 KiB of gathered taps + 8 KiB of dz rows, 3 slots (two workgroups per CU)
+    const int P = 64, np = P * (36 + p->Cout) * 4 / 1024, pps = (np + 3) / 4, NS = 3;
+    const size_t ldt = (size_t)NS * ((size_t)P * (36 + p->Cout) * 4 + 1024);
+    if ((P * p->Cout * 4) & 1023) return EFFDET_EUNSUPPORTED;
+    EFFDET_SET_MAX_LDS((conv_wgrad_thin_kernel<2, 3, true>), ldt);
+    hipLaunchKernelGGL((conv_wgrad_thin_kernel<2, 3, true>), dim3((unsigned)splits), dim3(256), ldt, st, k, P, pps, NS);
+    EFFDET_CHECK_LAUNCH();
+    if (p->dw) {
+      long long g = (n / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, (const float*)workspace, p->dw, n, splits);
+      EFFDET_CHECK_LAUNCH();
+      if (p->dbias) {
+        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((p->Cout + 255) / 256)), dim3(256), 0, st, (const float*)k.dbp, p->dbias,
+                           p->Cout, splits);
+        EFFDET_CHECK_LAUNCH();
+      }
+    }
+    return EFFDET_OK;
+  }
+  if (thin == 1) {
     // Stage size P (pixels) and ring depth NS, measured per channel budget (tools/wgrad_thin_bench.py, B = 32): the kernel is bound by
     // its LDS-read + fp32-MFMA loop (knock-outs: DMA alone streams at 5.2-6.1 TB/s, the loop alone at 3.6-4.8), so what pays is TWO
     // workgroups per CU taking turns -- slots small enough for that -- not a deeper ring in one workgroup:

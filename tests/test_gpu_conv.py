@@ -322,6 +322,23 @@ def test_thin_pointwise_wgrad_kernel():
             per = Gi.double().view(B, q, Cout, Cin).sum(1)
             refi = torch.einsum('bhwn,bhwc->bnc', dz.double(), x.double())
             assert float((per - refi).abs().max()) <= 2e-5 * float(refi.abs().max())
+    # the stem's form: 3x3 stride 2 on a 4-channel NHWC image (3 real channels), bottom / right padding, gathered im2col rows
+    for (B, H, Cout) in [(8, 128, 32), (3, 224, 24)]:
+        img = torch.randn(B, 3, H, H, generator=g)
+        x4 = torch.zeros(B, H, H, 4); x4[..., :3] = img.permute(0, 2, 3, 1)
+        Ho = H // 2
+        dz = torch.randn(B, Cout, Ho, Ho, generator=g)
+        wt = torch.zeros(Cout, 3, 3, 3, requires_grad=True)
+        (F.conv2d(F.pad(img, [0, 1, 0, 1]), wt, None, 2) * dz).sum().backward()
+        xm, zm = Map.of(x4.to(dev)), Map.of(dz.permute(0, 2, 3, 1).contiguous().to(dev))
+        assert ops.conv2d_wgrad_kernel_id(xm, zm, Cin=4, Cout=Cout, KH=3, KW=3, stride=2) == 1
+        G, dbp = ops.conv2d_wgrad(xm, zm, Cin=4, Cout=Cout, KH=3, KW=3, stride=2)
+        G2, _ = ops.conv2d_wgrad(xm, zm, Cin=4, Cout=Cout, KH=3, KW=3, stride=2)
+        assert torch.equal(G, G2)
+        got = G.double().sum(0)[:, :, :3].permute(0, 2, 1).reshape(Cout, 3, 3, 3).cpu()       # [Cout][tap][c] -> OIHW
+        assert float((got - wt.grad.double()).abs().max()) <= 2e-5 * float(wt.grad.abs().max()), (B, H, Cout)
+        assert float((G.double().sum(0)[:, :, 3]).abs().max()) == 0.0                              # the padding channel
+        assert float((dbp.double().sum(0).cpu() - dz.double().sum(dim=(0, 2, 3))).abs().max()) <= 2e-5 * float(dz.double().sum(dim=(0, 2, 3)).abs().max() + 1)
     # not this kernel: few pixels, wide rows, 3x3
     xs, zs = Map.of(torch.zeros(2, 16, 16, 16, device=dev)), Map.of(torch.zeros(2, 16, 16, 96, device=dev))
     assert ops.conv2d_wgrad_kernel_id(xs, zs, Cin=16, Cout=96, KH=1, KW=1) == 0
