@@ -792,8 +792,12 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
 }
 
 namespace {
-// tiny maps (<= 8x8 outputs): a 16x8 tile is mostly halo and padding -- the direct kernel is faster there
-inline bool wgrad_direct(int Ho, int Wo) { return Ho * Wo <= 64; }
+// tiny maps (<= 4x4 outputs): a 16x8 tile is mostly halo and padding -- the direct kernel is faster there.  (8x8 maps were on the direct
+// kernel too until the k5 LDS form got its registers down: C1152 8x8 k5 28-30 us direct, 24 us on the LDS kernel incl. its Swish pass.)
+inline bool wgrad_direct(int Ho, int Wo) {
+  static const int lim = getenv("EFFDET_DW_WGRAD_DIRECT") ? atoi(getenv("EFFDET_DW_WGRAD_DIRECT")) : 16;      // A/B switch: largest map on the direct kernel
+  return Ho * Wo <= lim;
+}
 
 int wgrad_plan(DwK& a, dim3& grid, int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l, int Ho, int Wo) {
   if (wgrad_direct(Ho, Wo)) {

@@ -1,3 +1,1 @@
-timeout 300 python -m pytest tests/test_gpu_conv.py -q -x 2>&1 | tail -3
-timeout 600 python -m pytest tests/test_gpu_model.py tests/test_gpu_determinism.py -q -x 2>&1 | tail -2
-bash tools/ab_env.sh EFFDET_WGRAD_THIN 2 1 2 1
+for d in 64 16 0; do echo DIRECT=$d; EFFDET_DW_WGRAD_DIRECT=$d DW_ONLY=wgrad timeout 300 python tools/dw_bench2.py 2>&1 | grep -v amdgpu | tail -4; done

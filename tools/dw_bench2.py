@@ -13,7 +13,8 @@ from efficientdet.pytorch_amd.ops import Map  # noqa: E402
 dev, dt, B = 'cuda', torch.float32, int(os.environ.get('DW_B', 32))
 only = os.environ.get('DW_ONLY', 'fwd,dgrad,wgrad').split(',')
 BLOCKS = [(32, 256, 3, 1, 1), (96, 256, 3, 2, 6), (144, 128, 3, 1, 6), (144, 128, 5, 2, 6), (240, 64, 5, 1, 6), (240, 64, 3, 2, 6),
-          (480, 32, 3, 1, 6), (480, 32, 5, 1, 6), (672, 32, 5, 1, 6), (672, 32, 5, 2, 6), (1152, 16, 5, 1, 6), (1152, 16, 3, 1, 6)]
+          (480, 32, 3, 1, 6), (480, 32, 5, 1, 6), (672, 32, 5, 1, 6), (672, 32, 5, 2, 6), (1152, 16, 5, 1, 6), (1152, 16, 3, 1, 6),
+          (672, 16, 5, 2, 6), (1152, 8, 5, 1, 6), (1152, 8, 3, 2, 6)]          # (the last three: this reference's B0 strides -- 8x8 / 4x4 maps)
 
 
 def timeit(fn, reps=20):
@@ -51,4 +52,4 @@ for (C, H, k, s, e) in BLOCKS:
         tot['wgrad'] += us
         line += ' wgrad %6.1f us %4.2f TB/s' % (us, 4 * B * C * (H * H + Ho * Ho) / us / 1e6)
     print(line, flush=True)
-print('sum (12 distinct shapes) ', {k_: round(v, 1) for k_, v in tot.items()})
+print('sum (15 shapes) ', {k_: round(v, 1) for k_, v in tot.items()})
