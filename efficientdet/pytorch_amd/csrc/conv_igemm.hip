@@ -1267,8 +1267,10 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
   if (p->dtype == EFFDET_F32_SPLIT) {
-    // persistent 256 x 256 / 32x32x16 form for the long-K head convs (tuning knob EFFDET_TUNE_SPLIT_PERS / env EFFDET_SPLIT_PERS)
-    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] < 0) g_tuning[EFFDET_TUNE_SPLIT_PERS] = getenv("EFFDET_SPLIT_PERS") ? atoi(getenv("EFFDET_SPLIT_PERS")) : 0;
+    // persistent 256 x 256 / 32x32x16 form for the long-K head convs (tuning knob EFFDET_TUNE_SPLIT_PERS / env EFFDET_SPLIT_PERS).
+    // In-step A/B on the D0 train step (same box, ms/step): off 27.83 | all eligible 27.57 | forward convs only (default) 27.33 |
+    // residual-epilogue convs only 27.94 -- the exposed epilogue of the persistent form costs more where it also reads the ReLU mask.
+    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] < 0) g_tuning[EFFDET_TUNE_SPLIT_PERS] = getenv("EFFDET_SPLIT_PERS") ? atoi(getenv("EFFDET_SPLIT_PERS")) : 2;
     if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && !p->bc_scale && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
       long long mtot = 0;
       bool fits = true;
@@ -1276,7 +1278,10 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
         mtot += k.seg[s].M;
         if ((long long)k.seg[s].x_bytes + 2LL * ((long long)p->KH * p->seg[s].W + p->KW) * p->ldx * 4 >= 0x70000000LL) fits = false;
       }
-      if (fits && mtot >= g_tuning[EFFDET_TUNE_IGEMM_BIG_MIN_M] && (long long)k.Kc * 4 >= 1152) return 10000 + 442;
+      // knob values: 1 = every eligible conv, 2 = only those without a residual epilogue (forward convs), 3 = only those WITH one
+      const int pv = g_tuning[EFFDET_TUNE_SPLIT_PERS];
+      const bool pick = pv == 1 || (pv == 2 && p->res_mode == EFFDET_RES_NONE) || (pv == 3 && p->res_mode != EFFDET_RES_NONE);
+      if (pick && fits && mtot >= g_tuning[EFFDET_TUNE_IGEMM_BIG_MIN_M] && (long long)k.Kc * 4 >= 1152) return 10000 + 442;
     }
     return 8 + (bt > 1 ? 1 : bt);                        // (block tiles of 128 / 64 output channels)
   }

@@ -95,7 +95,7 @@ int effdet_conv2d_kernel(const effdet_conv_t* p);
  *                                 (waves along pixels, waves along channels, LDS stages)
  *   EFFDET_TUNE_IGEMM_BIG_MIN_M : minimum output pixels per launch for that variant */
 enum { EFFDET_TUNE_IGEMM_BIG = 0, EFFDET_TUNE_IGEMM_BIG_MIN_M = 1,
-       EFFDET_TUNE_SPLIT_PERS = 2 /* EFFDET_F32_SPLIT convs: 1 = persistent 256x256 32x32x16 form for Cout >= 192, long K */,
+       EFFDET_TUNE_SPLIT_PERS = 2 /* EFFDET_F32_SPLIT convs, persistent 256x256 32x32x16 form for Cout >= 192, long K: 0 off, 1 all, 2 (default) only without a residual epilogue, 3 only with one */,
        EFFDET_TUNE_IGEMM_KORD = 3 /* K walk of the persistent variants: 0 tap-major, 1 channel-group-major */,
        EFFDET_TUNE_SPLIT_KORD = 4 /* K walk of the EFFDET_F32_SPLIT convs: 0 tap-major, 1 channel-group-major */, EFFDET_TUNE_COUNT = 5 };
 int effdet_tuning_set(int key, int value);
