@@ -142,3 +142,88 @@ def test_bf16x3_rule_and_enum_values_match_header():
     import pytest
     with pytest.raises(ValueError):
         ops.set_f32_arith('fp8')
+
+
+def _wgrad_desc(dtype, B, cin, cout, sizes, k=1, stride=1, pad=0, ldx=None, lddz=None, image_splits=0, want_bias=True, separate=False):
+    """effdet_wgrad_t over fake device pointers (planning entry points do no device work).  separate: every level in its own
+    'allocation' (offsets from a common base, 4 KiB apart beyond the tensor), as the grouped BiFPN launch passes them."""
+    from efficientdet.pytorch_amd import _lib as L
+    d = L.WgradDesc()
+    d.x, d.dz, d.dw = 0x10000000, 0x50000000, None
+    d.dbias = 1 if want_bias else None
+    d.dtype, d.B, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = dtype, B, cin, cout, k, k, stride, pad, pad
+    d.ldx, d.lddz, d.nseg, d.image_splits = ldx or cin, lddz or cout, len(sizes), image_splits
+    ox = oz = 0
+    for i, (h, w) in enumerate(sizes):
+        s = d.seg[i]
+        ho, wo = (h + stride - 1) // stride, (w + stride - 1) // stride
+        s.H, s.W, s.Ho, s.Wo = h, w, ho, wo
+        s.in_off, s.in_bstride, s.out_off, s.out_bstride = ox, h * w * d.ldx, oz, ho * wo * d.lddz
+        ox += B * h * w * d.ldx + (1024 * (i + 1) if separate else 0)
+        oz += B * ho * wo * d.lddz + (1024 * (i + 1) if separate else 0)
+    return d
+
+
+def test_weight_gradient_planning_entry_points():
+    """effdet_conv2d_wgrad_kernel / _splits / _seg_slabs / _workspace_bytes (host planning only): which launches take the thin
+    pointwise kernel (and the stem's form of it), that the per-segment slab ranges tile [0, splits) without overlap -- the contract
+    the grouped BiFPN weight gradients unpack by -- and that per-image splits land on image boundaries."""
+    import ctypes as C
+    from efficientdet.pytorch_amd import _lib as L
+    lib = L.lib()
+    kid = lambda d: int(lib.effdet_conv2d_wgrad_kernel(C.byref(d)))
+    # the six high-resolution 1x1 weight gradients of a D0 step (B = 32 @ 512) + the stem: thin kernel, in both fp32-storage modes
+    for dt in (L.F32, L.F32_BF16X3):
+        for (hw, cin, cout) in [(256, 32, 16), (256, 16, 96), (128, 96, 24), (128, 24, 144), (128, 144, 24), (64, 144, 40)]:
+            assert kid(_wgrad_desc(dt, 32, cin, cout, [(hw, hw)])) == 1, (dt, hw, cin, cout)
+        assert kid(_wgrad_desc(dt, 32, 4, 32, [(512, 512)], k=3, stride=2)) == 1            # the stem
+    assert kid(_wgrad_desc(L.F32, 32, 40, 240, [(64, 64)])) == 0          # 280 channels: tile kernels
+    assert kid(_wgrad_desc(L.F32, 32, 40, 144, [(64, 64)])) == 0          # 9 x 3 tiles: no such instantiation
+    assert kid(_wgrad_desc(L.F32, 2, 16, 96, [(64, 64)])) == 0            # 8192 pixels: too few
+    assert kid(_wgrad_desc(L.F32, 32, 16, 96, [(128, 128)], ldx=32)) == 0  # strided rows
+    assert kid(_wgrad_desc(L.F32, 32, 16, 96, [(64, 64), (32, 32)])) == 0  # two levels
+    assert kid(_wgrad_desc(L.BF16, 32, 16, 96, [(256, 256)])) == 0        # bf16 storage
+    assert kid(_wgrad_desc(L.F32, 32, 8, 32, [(512, 512)], k=3, stride=2)) == 0     # not the stem's 4-channel image
+    assert kid(_wgrad_desc(L.F32_SPLIT, 32, 256, 256, [(64, 64), (32, 32)], k=3, pad=1)) == 2
+    # per-image splits on the thin kernel: B * q slabs, q | image pixels
+    d = _wgrad_desc(L.F32_BF16X3, 32, 96, 24, [(128, 128)], image_splits=1)
+    splits = int(lib.effdet_conv2d_wgrad_splits(C.byref(d)))
+    assert splits >= 32 and splits % 32 == 0 and (128 * 128) % (splits // 32) == 0
+    assert int(lib.effdet_conv2d_wgrad_workspace_bytes(C.byref(d))) == splits * 24 * (96 + 1) * 4
+    # grouped independent problems (the BiFPN nodes): 5 levels in separate allocations, slab ranges partition [0, splits)
+    for dt, sizes in ((L.F32_BF16X3, [(64, 64), (16, 16), (8, 8), (8, 8), (4, 4)]), (L.F32, [(32, 32), (32, 32), (16, 16)]),
+                      (L.BF16, [(64, 64), (5, 7), (8, 8), (3, 3), (4, 4)])):            # (bf16: levels split between two kernels)
+        d = _wgrad_desc(dt, 32, 64, 64, sizes, k=3, pad=1, separate=True)
+        n = len(sizes)
+        first, count = (C.c_int * n)(), (C.c_int * n)()
+        tot = int(lib.effdet_conv2d_wgrad_seg_slabs(C.byref(d), first, count))
+        assert tot == int(lib.effdet_conv2d_wgrad_splits(C.byref(d))) and tot >= n
+        covered = sorted((first[i], first[i] + count[i]) for i in range(n))
+        assert covered[0][0] == 0 and covered[-1][1] == tot and all(count[i] >= 1 for i in range(n))
+        assert all(covered[i][1] == covered[i + 1][0] for i in range(n - 1)), covered
+    assert int(lib.effdet_conv2d_wgrad_seg_slabs(None, None, None)) == -1
+
+
+def test_tail_batch_context_records_and_joins(monkeypatch):
+    """ops.unpack_batch (host logic of effdet_backward_tail): jobs issued inside are recorded, an inner block joins the outer one,
+    the launch happens once at the outermost exit, and an exception inside drops the batch instead of launching half a node."""
+    from efficientdet.pytorch_amd import ops, _lib as L
+    launched = []
+    monkeypatch.setattr(ops._TailBatch, 'flush', lambda self: launched.append([j.kind for j in self.jobs]))
+    job = L.UnpackJob()
+    with ops.unpack_batch():
+        assert ops._UNPACK_BATCH is not None
+        ops._UNPACK_BATCH.add(L.TAIL_UNPACK, job, 'keep')
+        with ops.unpack_batch():                                  # e.g. bifpn_module_bwd inside _NeckFn.backward
+            ops._UNPACK_BATCH.add(L.TAIL_SE_PARAMS, L.SeParamJob())
+        assert launched == []                                      # the inner exit does not launch
+        ops._UNPACK_BATCH.add(L.TAIL_DW_UNPACK, L.DwUnpackJob())
+    assert launched == [[L.TAIL_UNPACK, L.TAIL_SE_PARAMS, L.TAIL_DW_UNPACK]] and ops._UNPACK_BATCH is None
+    with pytest.raises(RuntimeError):
+        with ops.unpack_batch():
+            ops._UNPACK_BATCH.add(L.TAIL_UNPACK, job)
+            raise RuntimeError('backward failed')
+    assert len(launched) == 1 and ops._UNPACK_BATCH is None
+    monkeypatch.setattr(ops, 'UNPACK_BATCHED', False)              # EFFDET_UNPACK_BATCH=0: the context is a no-op, jobs launch one by one
+    with ops.unpack_batch():
+        assert ops._UNPACK_BATCH is None
