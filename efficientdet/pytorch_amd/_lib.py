@@ -11,6 +11,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
+ABI_VERSION = 4                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
@@ -89,7 +90,7 @@ SYMBOLS = [
     'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',
     'effdet_clip_adamw_step', 'effdet_opt_chunk',
     'effdet_drop_connect_scales', 'effdet_philox4x32_10', 'effdet_preprocess_batch', 'effdet_finalize_dets', 'effdet_head_out_bwd',
-    'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_to_split', 'effdet_version',
+    'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_to_split', 'effdet_version', 'effdet_abi_version',
 ]
 
 
@@ -101,7 +102,13 @@ def lib():
             raise RuntimeError(
                 'libeffdet_hip.so is missing (%s). Build it with `python -m efficientdet.pytorch_amd.build` '
                 '(or __graft_entry__.build()). There is no CPU fallback for this path.' % LIB_PATH)
-        _lib = C.CDLL(LIB_PATH)
+        cand = C.CDLL(LIB_PATH)
+        # a stale build (or a foreign EFFDET_HIP_LIB) with other signatures would be called with shifted arguments: refuse it
+        got = int(cand.effdet_abi_version()) if hasattr(cand, 'effdet_abi_version') else 0
+        if got != ABI_VERSION:
+            raise RuntimeError('%s has ABI generation %d, this binding needs %d: rebuild it (`python -m efficientdet.pytorch_amd.build`)'
+                               % (LIB_PATH, got, ABI_VERSION))
+        _lib = cand
         _lib.effdet_version.restype = C.c_char_p
         for name in ('effdet_num_anchors', 'effdet_nms_workspace_bytes', 'effdet_loss_workspace_bytes',
                      'effdet_conv2d_wgrad_workspace_bytes', 'effdet_dwconv_wgrad_workspace_bytes',

@@ -312,4 +312,5 @@ extern "C" int effdet_to_split(const float* src, void* dst, long long n, effdet_
   return EFFDET_OK;
 }
 
-extern "C" const char* effdet_version(void) { return "effdet-hip gfx950 0.1"; }
+extern "C" const char* effdet_version(void) { return "effdet-hip gfx950 0.4"; }
+extern "C" int effdet_abi_version(void) { return EFFDET_ABI_VERSION; }

@@ -190,9 +190,16 @@ class _MBConvFn(torch.autograd.Function):
         link = buffers.get('stem_link') if (train and blk.expand == 1 and not blk.skip and STEM_LINK) else None
         ctx.link = link
         xm = Map.of(x)
-        if link is not None:         # the stem stored its pre-activation only and `x` IS that tensor: same Map object for mbconv_fwd's test
-            xm = link['z'] if link['z'].t.data_ptr() == x.data_ptr() else xm
-        y, saved = Fn.mbconv_fwd(xm, blk, P, dtype, train, rowscale, xpre=link['z'] if link else None)
+        if link is not None:
+            # the stem stored its PRE-activation only (stem_fwd z_only) and `x` must BE that tensor: the depthwise kernels Swish
+            # it on the fly (in_act) and the backward hands d(z_stem) back.  Anything else between the stem and block 0 (a copy, a
+            # cast) would make this block consume un-Swished activations silently -- refuse instead.
+            if link.get('z') is None or link['z'].t.data_ptr() != x.data_ptr():
+                raise RuntimeError('stem link broken: block 0 was not handed the stem\'s pre-activation tensor itself '
+                                   '(EFFDET_STEM_LINK=0 disables the fused stem Swish)')
+            xm = link['z']
+        y, saved = Fn.mbconv_fwd(xm, blk, P, dtype, train, rowscale, xpre=link['z'] if link else None,
+                                 in_act=ops.ACT_SWISH if link is not None else ops.ACT_NONE)
         ctx.saved, ctx.keys = (saved if train else None), keys
         return _t(y)
 

@@ -21,16 +21,15 @@ def postprocess(model, cls, reg, anc, H, W):
 
 def default_max_detections(xywh, A, num_classes=None):
     """eval.py:104-117 (_get_detections, the VOC path) keeps the 100 best detections per image; eval.py:279-306 (evaluate_coco)
-    emits EVERY detection scoring >= the threshold and leaves the capping to COCOeval (maxDets per image AND category).  The
-    xywh / COCO path therefore defaults to 100 per category (bounded by the NMS output size), not 100 per image."""
-    if not xywh:
-        return 100
-    return int(min(A, 100 * num_classes)) if num_classes else int(A)
+    emits EVERY detection scoring >= the threshold and leaves the capping to COCOeval.  finalize_dets' cap is a per-image top-K by
+    score, so any cap below the NMS output size A could truncate whole low-scoring categories the reference would have emitted:
+    the xywh / COCO path is therefore UNCAPPED by default (A rows), whatever num_classes is."""
+    return int(A) if xywh else 100
 
 
 def finalize(s, l, b, count, scales, score_threshold=0.05, max_detections=None, xywh=False, num_classes=None):
     """eval.py:104-117 / :279-292 for the batch on the device -> (dets [B,max_detections,6], counts [B]) on the HOST.
-    max_detections=None: default_max_detections (100 per image for the VOC rows, 100 per category for the COCO rows)."""
+    max_detections=None: default_max_detections (100 per image for the VOC rows, every detection for the COCO rows)."""
     if max_detections is None:
         max_detections = default_max_detections(xywh, s.shape[1], num_classes)
     sc = torch.as_tensor(np.asarray(scales, dtype=np.float32) if not torch.is_tensor(scales) else scales,

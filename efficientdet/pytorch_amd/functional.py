@@ -89,9 +89,12 @@ def stem_bwd(saved, dy, dy_is_dz=False):
 
 
 # ------------------------------------------------------------------------------------------ MBConv
-def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None):
+def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NONE):
     """models/efficientnet.py:75-105.  P: dict of parameter / buffer tensors of the block.
-    rowscale: optional [B] fp32 = drop_connect keep-mask / keep_prob (models/utils.py:79-90)."""
+    rowscale: optional [B] fp32 = drop_connect keep-mask / keep_prob (models/utils.py:79-90).
+    in_act=ACT_SWISH (expand == 1 blocks only, with xpre = x): x is the producer's PRE-activation (stem_fwd z_only) -- stated by the
+    caller, never inferred."""
+    assert in_act == ACT_NONE or (blk.expand == 1 and xpre is x)
     dev = x.t.device
     B, H, W = x.B, x.H, x.W
     sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale, 'xpre': xpre}      # xpre: see mbconv_bwd (expand == 1 blocks)
@@ -114,8 +117,7 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None):
         sv.update(s0=s0, i0=i0, ze=ze)
     else:
         xe = x
-        if sv.get('xpre') is not None and sv['xpre'] is x:      # the producer (the stem) handed its pre-activation ONLY (stem_fwd z_only)
-            dw_in_act = ACT_SWISH
+        dw_in_act = in_act          # ACT_SWISH: the producer (the stem) handed its pre-activation ONLY (stem_fwd z_only)
     s1, t1, i1 = ops.bn_fold(P['bn1.weight'], P['bn1.bias'], P['bn1.running_mean'], P['bn1.running_var'], BN_EPS)
     wk = ops.dw_pack_weight(P['dw.weight'])
     # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):

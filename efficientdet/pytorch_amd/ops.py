@@ -441,7 +441,7 @@ class _TailBatch:
     Nothing inside the block may READ these outputs."""
 
     def __init__(self):
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.bytes = [], [], 0
 
     def add(self, kind, job, *tensors):
         t = L.TailJob()
@@ -453,16 +453,27 @@ class _TailBatch:
         else:
             t.u.dw = job
         self.jobs.append(t); self.keep.append(tensors)
+        # the deferred jobs pin their split-K slab workspaces (tens of MB per head conv): bound the lifetime, not only the launch
+        # size -- past the byte budget the jobs recorded so far leave now and their inputs go back to the allocator
+        self.bytes += sum(x.numel() * x.element_size() for x in tensors if isinstance(x, torch.Tensor))
+        if self.bytes > TAIL_KEEP_BYTES:
+            self.flush()
 
     def flush(self):
         if self.jobs:
             arr = (L.TailJob * len(self.jobs))(*self.jobs)
             L.check(L.lib().effdet_backward_tail(arr, len(self.jobs), L.stream_ptr()), 'effdet_backward_tail')
-        self.jobs, self.keep = [], []
+        self.jobs, self.keep, self.bytes = [], [], 0
 
 
-_UNPACK_BATCH = None
 UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'      # A/B switch: 0 = every tail job is its own launch
+TAIL_KEEP_BYTES = int(os.environ.get('EFFDET_TAIL_KEEP_MB', '256')) << 20  # flush early once the deferred jobs pin this much workspace
+
+
+def _cur_batch():
+    """The open tail batch of THIS thread (thread-local like the ParamPrep pointer: replica backwards of a multi-device
+    nn.DataParallel run concurrently on per-device autograd threads and must never see each other's batch)."""
+    return getattr(_tls, 'unpack_batch', None)
 
 
 class unpack_batch:
@@ -470,16 +481,14 @@ class unpack_batch:
     joins the outer one)."""
 
     def __enter__(self):
-        global _UNPACK_BATCH
-        self.owner = _UNPACK_BATCH is None and UNPACK_BATCHED
+        self.owner = _cur_batch() is None and UNPACK_BATCHED
         if self.owner:
-            _UNPACK_BATCH = _TailBatch()
+            _tls.unpack_batch = _TailBatch()
         return self
 
     def __exit__(self, et, ev, tb):
-        global _UNPACK_BATCH
         if self.owner:
-            b, _UNPACK_BATCH = _UNPACK_BATCH, None
+            b, _tls.unpack_batch = _tls.unpack_batch, None
             if et is None:
                 b.flush()
         return False
@@ -496,8 +505,9 @@ def _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, **ptrs):
 
 
 def _unpack_submit(job, *tensors):
-    if _UNPACK_BATCH is not None:
-        _UNPACK_BATCH.add(L.TAIL_UNPACK, job, *tensors)
+    batch = _cur_batch()
+    if batch is not None:
+        batch.add(L.TAIL_UNPACK, job, *tensors)
     else:
         L.check(L.lib().effdet_unpack_conv_wgrad_batch(C.byref(job), 1, L.stream_ptr()), 'effdet_unpack_conv_wgrad_batch')
 
@@ -633,11 +643,12 @@ def dw_unpack_wgrad_bn(g_kkc, scale, w_c1kk, dsum, mean, invstd):
     dw = torch.empty_like(w_c1kk)
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=dw.device)
     wd = w_c1kk.detach()
-    if _UNPACK_BATCH is not None:
+    batch = _cur_batch()
+    if batch is not None:
         j = L.DwUnpackJob()
         j.g_kkc, j.scale, j.w_c1kk, j.dw_c1kk, j.dsum, j.mean, j.invstd = (t.data_ptr() for t in (g_kkc, scale, wd, dw, dsum, mean, invstd))
         j.dgamma, j.dbeta, j.C, j.kk = dgb[0].data_ptr(), dgb[1].data_ptr(), Cc, k * k
-        _UNPACK_BATCH.add(L.TAIL_DW_UNPACK, j, g_kkc, scale, wd, dw, dsum, mean, invstd, dgb)
+        batch.add(L.TAIL_DW_UNPACK, j, g_kkc, scale, wd, dw, dsum, mean, invstd, dgb)
     else:
         L.check(L.lib().effdet_dw_unpack_wgrad_bn(L.ptr(g_kkc), L.ptr(scale), L.ptr(wd), L.ptr(dw), L.ptr(dsum), L.ptr(mean),
                                                   L.ptr(invstd), L.ptr(dgb[0]), L.ptr(dgb[1]), Cc, k, L.stream_ptr()),
@@ -752,7 +763,8 @@ def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, times_gate=False):
     db2 = out[o:o + Cc]; o += Cc
     ws = out[o:]
     assert ws.numel() >= L.lib().effdet_se_gate_bwd_workspace_floats(B, Cc, Cse)
-    defer = _UNPACK_BATCH is not None          # the parameter gradients (phase B) join the node's tail launch
+    batch = _cur_batch()
+    defer = batch is not None                  # the parameter gradients (phase B) join the node's tail launch
     w1d, b1d, w2d = w1.detach(), b1.detach(), w2.detach()
     L.check(L.lib().effdet_se_gate_bwd(L.ptr(dgate), dgate.shape[1], int(times_gate), L.ptr(gate), L.ptr(mid), L.ptr(pool), L.ptr(w1d), L.ptr(b1d),
                                        L.ptr(w2d), L.ptr(dpool), L.ptr(None if defer else dw1), L.ptr(None if defer else db1),
@@ -763,7 +775,7 @@ def se_gate_bwd(dgate, gate, mid, pool, w1, b1, w2, inv_hw, times_gate=False):
         j.du, j.dmid, j.sw = ws.data_ptr(), ws.data_ptr() + 4 * B * Cc, ws.data_ptr() + 4 * B * (Cc + Cse)
         j.pool, j.dw1, j.db1, j.dw2, j.db2 = pool.data_ptr(), dw1.data_ptr(), db1.data_ptr(), dw2.data_ptr(), db2.data_ptr()
         j.B, j.C, j.Cse, j.inv_hw = B, Cc, Cse, inv_hw
-        _UNPACK_BATCH.add(L.TAIL_SE_PARAMS, j, out, pool)
+        batch.add(L.TAIL_SE_PARAMS, j, out, pool)
     return dpool, dw1, db1, dw2, db2
 
 

@@ -169,10 +169,16 @@ class ClipAdamW(torch.optim.Optimizer):
                 t['g_last'] = ptrs
         self._step += 1
         b1, b2 = g['betas']
+        if len(self.param_groups) != 1:
+            raise RuntimeError('ClipAdamW honours ONE parameter group (the reference builds one, train.py:266); got %d -- other '
+                               "groups' lr / weight_decay would be silently ignored" % len(self.param_groups))
         if torch.cuda.is_current_stream_capturing():
             self._captured = True
             if t['hyper_last'] is None:
                 raise RuntimeError('ClipAdamW: run one eager step (or sync_hyper()) before capturing the step as a hipGraph')
+            if self._hyper_values() != t['hyper_last']:
+                raise RuntimeError('ClipAdamW: param_groups changed since the last upload of the device hyper-parameter buffer and '
+                                   'the stream is capturing (no upload possible); call sync_hyper() before capturing')
         else:
             self.sync_hyper()
         ops_mod.bump_param_generation()      # parameters are rewritten through raw pointers: Tensor._version does not move

@@ -512,6 +512,12 @@ int effdet_head_out_bwd(const float* dprob, const float* prob, const float* dreg
 /* library identification: returns "effdet-hip gfx950 <version>" */
 const char* effdet_version(void);
 
+/* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
+ * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
+ * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
+#define EFFDET_ABI_VERSION 4
+int effdet_abi_version(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,7 +23,29 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(_lib.SYMBOLS) == declared, set(_lib.SYMBOLS) ^ set(declared)
     assert L.effdet_version().decode().startswith('effdet-hip gfx950')
+    # ABI generation: header define == what the library was compiled with == what the ctypes binding was written against
+    hdr = int(re.search(r'#define\s+EFFDET_ABI_VERSION\s+(\d+)', open(os.path.join(ROOT, 'include', 'effdet_hip.h')).read()).group(1))
+    assert hdr == int(L.effdet_abi_version()) == _lib.ABI_VERSION
     assert int(L.effdet_num_anchors(512, 512)) == 49104 and int(L.effdet_num_anchors(1024, 1024)) == 196416
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A library with another ABI generation (stale build, foreign EFFDET_HIP_LIB) must not be bound: ctypes would call it with
+    shifted arguments."""
+    import shutil
+    import subprocess
+    import pytest
+    from efficientdet.pytorch_amd import _lib
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'stale.c'
+    src.write_text('int effdet_abi_version(void) { return %d; }\nconst char* effdet_version(void) { return "effdet-hip gfx950 stale"; }\n'
+                   % (_lib.ABI_VERSION - 1))
+    so = tmp_path / 'libstale.so'
+    subprocess.run(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)], check=True)
+    monkeypatch.setattr(_lib, '_lib', None); monkeypatch.setattr(_lib, 'LIB_PATH', str(so))
+    with pytest.raises(RuntimeError, match='ABI generation'):
+        _lib.lib()
 
 
 def test_struct_layouts_match_header():

@@ -209,21 +209,63 @@ def test_tail_batch_context_records_and_joins(monkeypatch):
     the launch happens once at the outermost exit, and an exception inside drops the batch instead of launching half a node."""
     from efficientdet.pytorch_amd import ops, _lib as L
     launched = []
-    monkeypatch.setattr(ops._TailBatch, 'flush', lambda self: launched.append([j.kind for j in self.jobs]))
+
+    def fake_flush(self):
+        launched.append([j.kind for j in self.jobs]); self.jobs, self.keep, self.bytes = [], [], 0
+    monkeypatch.setattr(ops._TailBatch, 'flush', fake_flush)
     job = L.UnpackJob()
     with ops.unpack_batch():
-        assert ops._UNPACK_BATCH is not None
-        ops._UNPACK_BATCH.add(L.TAIL_UNPACK, job, 'keep')
+        assert ops._cur_batch() is not None
+        ops._cur_batch().add(L.TAIL_UNPACK, job, 'keep')
         with ops.unpack_batch():                                  # e.g. bifpn_module_bwd inside _NeckFn.backward
-            ops._UNPACK_BATCH.add(L.TAIL_SE_PARAMS, L.SeParamJob())
+            ops._cur_batch().add(L.TAIL_SE_PARAMS, L.SeParamJob())
         assert launched == []                                      # the inner exit does not launch
-        ops._UNPACK_BATCH.add(L.TAIL_DW_UNPACK, L.DwUnpackJob())
-    assert launched == [[L.TAIL_UNPACK, L.TAIL_SE_PARAMS, L.TAIL_DW_UNPACK]] and ops._UNPACK_BATCH is None
+        ops._cur_batch().add(L.TAIL_DW_UNPACK, L.DwUnpackJob())
+    assert launched == [[L.TAIL_UNPACK, L.TAIL_SE_PARAMS, L.TAIL_DW_UNPACK]] and ops._cur_batch() is None
     with pytest.raises(RuntimeError):
         with ops.unpack_batch():
-            ops._UNPACK_BATCH.add(L.TAIL_UNPACK, job)
+            ops._cur_batch().add(L.TAIL_UNPACK, job)
             raise RuntimeError('backward failed')
-    assert len(launched) == 1 and ops._UNPACK_BATCH is None
+    assert len(launched) == 1 and ops._cur_batch() is None
     monkeypatch.setattr(ops, 'UNPACK_BATCHED', False)              # EFFDET_UNPACK_BATCH=0: the context is a no-op, jobs launch one by one
     with ops.unpack_batch():
-        assert ops._UNPACK_BATCH is None
+        assert ops._cur_batch() is None
+
+
+def test_tail_batch_is_thread_local_and_bounds_pinned_bytes(monkeypatch):
+    """Replica backwards of a multi-device nn.DataParallel run concurrently on per-device autograd threads: a thread must never
+    see (or append to) another thread's open batch.  And the deferred jobs pin their workspaces only up to a byte budget."""
+    import threading
+    import torch
+    from efficientdet.pytorch_amd import ops, _lib as L
+    launched = []
+
+    def fake_flush(self):
+        launched.append((threading.get_ident(), len(self.jobs))); self.jobs, self.keep, self.bytes = [], [], 0
+    monkeypatch.setattr(ops._TailBatch, 'flush', fake_flush)
+    seen, gate_a, gate_b = {}, threading.Event(), threading.Event()
+
+    def other():
+        gate_a.wait(10)
+        seen['other_before'] = ops._cur_batch()                   # the main thread's block is open right now
+        with ops.unpack_batch():
+            seen['other_inside'] = ops._cur_batch()
+            ops._cur_batch().add(L.TAIL_UNPACK, L.UnpackJob())
+        gate_b.set()
+    th = threading.Thread(target=other); th.start()
+    with ops.unpack_batch():
+        mine = ops._cur_batch()
+        mine.add(L.TAIL_UNPACK, L.UnpackJob())
+        gate_a.set(); assert gate_b.wait(10)
+        assert len(mine.jobs) == 1                                 # the other thread's job did not land here
+    th.join()
+    assert seen['other_before'] is None and seen['other_inside'] is not None and seen['other_inside'] is not mine
+    assert sorted(n for _, n in launched) == [1, 1] and len({t for t, _ in launched}) == 2
+    launched.clear()
+    monkeypatch.setattr(ops, 'TAIL_KEEP_BYTES', 1000)
+    with ops.unpack_batch():
+        ops._cur_batch().add(L.TAIL_UNPACK, L.UnpackJob(), torch.empty(100))       # 400 B pinned
+        ops._cur_batch().add(L.TAIL_UNPACK, L.UnpackJob(), torch.empty(200))       # 1200 B > budget: both leave now
+        assert [n for _, n in launched] == [2] and ops._cur_batch().keep == []
+        ops._cur_batch().add(L.TAIL_UNPACK, L.UnpackJob(), torch.empty(10))
+    assert [n for _, n in launched] == [2, 1]
