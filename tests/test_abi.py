@@ -103,3 +103,37 @@ def test_no_float_atomics_in_the_kernels():
         floaty = [h for h in hits if not re.search(r'kcount|kover_n|nvalid|&cnt|\(int|counter', h)]
         assert not floaty, (os.path.basename(f), floaty)
     assert 'unsafe-fp-atomics' not in open(os.path.join(ROOT, 'efficientdet', 'pytorch_amd', 'build.py')).read()
+
+
+def integration_md_stub():
+    """The python code block of INTEGRATION.md section 2 (the ctypes stub a maintainer would paste), with the library path made absolute."""
+    md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    sec = md[md.index('## 2. Binding the C ABI'):]
+    code = re.search(r'```python\n(.*?)```', sec, flags=re.S).group(1)
+    assert 'class Conv(C.Structure)' in code and 'def conv3x3_bias_relu' in code
+    return code.replace("'efficientdet/pytorch_amd/libeffdet_hip.so'", repr(os.path.join(ROOT, 'efficientdet', 'pytorch_amd', 'libeffdet_hip.so')))
+
+
+def test_integration_md_stub_matches_the_header(tmp_path):
+    """The DOCUMENTED binding (not _lib.py): its Seg / Conv ctypes structs have the sizes and field offsets gcc gives effdet_seg_t /
+    effdet_conv_t, and its ABI generation is the header's."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    import pytest
+    from efficientdet.pytorch_amd import build
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    build.build(verbose=False)
+    ns = {}
+    exec(integration_md_stub(), ns)                         # defines lib, Seg, Conv, conv3x3_bias_relu (no compute call at import)
+    fields = [n for n, _ in ns['Conv']._fields_]
+    src = tmp_path / 'off.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "effdet_hip.h"\nint main(void){printf("%zu %zu\\n", sizeof(effdet_seg_t), sizeof(effdet_conv_t));'
+                   + ''.join('printf("%%zu\\n", offsetof(effdet_conv_t, %s));' % f for f in fields) + 'return 0;}\n')
+    exe = tmp_path / 'off'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert (C.sizeof(ns['Seg']), C.sizeof(ns['Conv'])) == (int(out[0]), int(out[1]))
+    for f, off in zip(fields, out[2:]):
+        assert getattr(ns['Conv'], f).offset == int(off), f

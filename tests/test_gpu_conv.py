@@ -515,3 +515,22 @@ def test_batched_unpack_is_bitwise_the_single_launches():
     kind, g, w, part, *_ = jobs[0]
     ref = g.sum(0)[:, :, :w.shape[1]].permute(0, 2, 1).reshape(w.shape[0], w.shape[1], 3, 3)
     assert torch.allclose(single[0][0], ref, atol=1e-5) and torch.allclose(single[0][1], part.sum(0), atol=1e-5)
+
+
+def test_integration_md_stub_runs():
+    """The ctypes stub PRINTED in INTEGRATION.md section 2 (what a reference maintainer would paste), extracted from the document
+    and executed as is: one RetinaHead tower conv (models/module.py:495-501, 3x3 + bias + ReLU) vs F.conv2d on the same
+    bf16-rounded operands."""
+    from tests.test_abi import integration_md_stub
+    ns = {}
+    exec(integration_md_stub(), ns)
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cin, Cout = 2, 16, 24, 64, 256
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.3
+    y = ns['conv3x3_bias_relu'](x.permute(0, 2, 3, 1).contiguous().to('cuda', torch.bfloat16), w.cuda(), b.cuda())
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1))
+    assert y.shape == (B, H, W, Cout) and y.dtype == torch.bfloat16
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL[torch.bfloat16], 'INTEGRATION.md stub')
