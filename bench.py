@@ -51,9 +51,15 @@ def parse():
     ap.add_argument('--no-d4', action='store_true', help='skip configs[4] (D4 batch 8 @ 1024 inference)')
     ap.add_argument('--extra-steps', type=int, default=20, help='timed steps of each extra-mode train leg')
     ap.add_argument('--extra-warmup', type=int, default=3)
-    ap.add_argument('--ddp-graph', action='store_true',
-                    help='N > 1, EXPERIMENTAL (never run on multi-GPU hardware): capture the DDP step, RCCL collectives included, as a '
-                         'hipGraph; a failed capture aborts the run.  Default: eager launches under DDP')
+    ap.add_argument('--no-ddp-graph', action='store_true',
+                    help='N > 1: eager launches under DDP.  Default: the DDP step, RCCL all-reduces included, is captured as ONE hipGraph '
+                         'when a pre-flight probe (throw-away child process per rank: world_size-1 RCCL group, all-reduce captured + '
+                         'replayed) says this torch / RCCL build can do it on this box; every rank must agree, else all run eager')
+    ap.add_argument('--ddp-graph', action='store_true', help='(kept for older command lines: the captured DDP step is the default now)')
+    ap.add_argument('--ddp-single', action='store_true',
+                    help='N = 1 through the N > 1 code path: world_size-1 RCCL process group, ddp.wrap, bucketed all-reduce, captured DDP step '
+                         '(what a box with one GPU can validate of the multi-GPU path)')
+    ap.add_argument('--infer-reps', type=int, default=20, help='timed repetitions of every inference leg')
     ap.add_argument('--torch-optim', action='store_true', help='stock clip_grad_norm_ + torch.optim.AdamW(fused) instead of the HIP ClipAdamW')
     return ap.parse_args()
 
@@ -160,7 +166,8 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     dtype = torch.bfloat16 if dtype_name == 'bf16' else torch.float32
     model = build_model(a.network, dtype, dev, True, 'bf16x3' if dtype_name == 'f32_bf16x3' else 'f32')
     ddp.freeze_dead_parameters(model)
-    net = ddp.wrap(model, device_ids=[local]) if world > 1 else model
+    use_ddp = world > 1 or a.ddp_single
+    net = ddp.wrap_for_capture(model, device_ids=[local]) if use_ddp else model
     params = [p for p in model.parameters() if p.requires_grad]
     if a.torch_optim:
         opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
@@ -181,7 +188,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
         return loss
 
     def sync_all():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -189,26 +196,25 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
         step()
     sync_all()
     graphed = None
-    if (world == 1 or a.ddp_graph) and not a.no_graph and not a.torch_optim:
+    if (not use_ddp or a.ddp_graph_ok) and not a.no_graph and not a.torch_optim:
         # the SAME step (zero_grad, forward, loss, backward, clip + AdamW) captured once as a hipGraph and replayed: one
-        # hipGraphLaunch per step instead of ~560 launches through Python; every replay does the full work on the resident
-        # batch (fresh drop_connect masks from the device-side step counter, parameters updated in place).  N > 1 (--ddp-graph,
-        # off by default: not validated on hardware): DDP's bucketed RCCL all-reduces are captured with the step.
+        # hipGraphLaunch per step instead of ~400 launches through Python; every replay does the full work on the resident
+        # batch (fresh drop_connect masks from the device-side step counter, parameters updated in place).  Under DDP the bucketed
+        # RCCL all-reduces are captured with the step (11 eager iterations first: DDP rebuilds its buckets after the first one);
+        # whether RCCL can be captured here was decided for ALL ranks by the pre-flight probe in main(), before any collective
+        # of this job existed -- a capture that fails now, with collectives in flight, is not recoverable and aborts the run.
         from efficientdet.pytorch_amd.graph import GraphedTrainStep
         try:
-            graphed = GraphedTrainStep(net, opt, img, ann, warmup=2 if world == 1 else 11)
+            graphed = GraphedTrainStep(net, opt, img, ann, warmup=11 if use_ddp else 2)
             for _ in range(2):
                 graphed()
             sync_all()
         except Exception as e:        # report and fall back to eager launches
-            if world > 1:             # a failed capture with collectives in flight cannot be recovered from (measured with gloo, which
-                raise                 # is not capturable at all: the process is left with an invalidated stream) -- fail loudly
+            if use_ddp:
+                sys.stderr.write('capturing the DDP step failed AFTER the RCCL capture probe passed (%s: %s); re-run with --no-ddp-graph\n'
+                                 % (type(e).__name__, e))
+                raise
             sys.stderr.write('hipGraph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
-            graphed = None
-    if world > 1:                     # all ranks must take the same path (a collective inside / outside a graph)
-        flag = torch.tensor([1 if graphed is not None else 0], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
             graphed = None
     sync_all()
     t0 = time.perf_counter()
@@ -223,7 +229,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     sync_all()
     dt = time.perf_counter() - t0
     host_ms = [round(host_dt / steps * 1e3, 3)]
-    if world > 1:
+    if use_ddp:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -246,7 +252,7 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
             roof['other_mfma_by_shape'] = {k: ops.PROFILE.by_shape(k, top=3) for k, v in summ.items()
                                            if k.startswith('conv_') and k != roof['kernel'] and v['ms'] >= 1.0}
             ops.PROFILE = None
-        if world > 1:
+        if use_ddp:
             dist.barrier()
     final = float(loss.item())
     del opt, net, model
@@ -254,9 +260,39 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     return a.batch * world * steps / dt, dt / steps * 1e3, final, roof, img, graphed is not None, host_ms
 
 
-def inference_leg(network, dtype, dev, img, reps=5, graph=True, f32_arith='f32'):
+INFER_GFLOP_PER_IMG = {('efficientdet-d0', 512): 64.089, ('efficientdet-d4', 1024): 455.596}     # SURVEY 8(d) forward conv FLOPs (2*MAC)
+
+
+def inference_roofline(model, img, dtype_name):
+    """The dominant MFMA kernel of ONE instrumented eager forward (per-launch HIP events on the launch stream) against the dense
+    peak of its arithmetic, like the train legs' roofline; traffic = null (no PMC pass of the inference command is attached)."""
+    from efficientdet.pytorch_amd import ops
+    peak = {'bf16': BF16_MFMA_PEAK_TFLOPS, 'f32': F32_MFMA_PEAK_TFLOPS, 'f32_bf16x3': round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)}[dtype_name]
+    ops.PROFILE = ops.LaunchProfile()
+    try:
+        with torch.no_grad():
+            model.forward_raw(img)
+        torch.cuda.synchronize()
+        summ = ops.PROFILE.summary()
+        mf = {k: v for k, v in summ.items() if k.startswith('conv_')}
+        name, d = max(mf.items(), key=lambda kv: kv[1]['ms'])
+        ach = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None, 'launches_per_forward': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
+                'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+                'dominant_by_shape': ops.PROFILE.by_shape(name, top=3),
+                'all_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'tflops': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
+                                for k, v in mf.items()},
+                'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)}
+                                for k, v in summ.items() if not k.startswith('conv_')}}
+    finally:
+        ops.PROFILE = None
+    return roof
+
+
+def inference_leg(network, dtype, dev, img, reps=20, graph=True, f32_arith='f32', dtype_name=None):
     """eval forward + decode + per-image NMS (thr 0.01, IoU 0.5) on RANDOM-INIT weights: every anchor passes the threshold = the
-    NMS worst case.  -> (ms/img end to end, ms/img forward only, kept boxes of image 0)."""
+    NMS worst case.  -> (ms/img end to end, ms/img forward only, kept boxes of image 0, roofline of the forward or None)."""
     model = build_model(network, dtype, dev, False, f32_arith)
     B = img.shape[0]
     with torch.no_grad():
@@ -282,9 +318,10 @@ def inference_leg(network, dtype, dev, img, reps=5, graph=True, f32_arith='f32')
             model.forward_raw(img)
         torch.cuda.synchronize(); tf = (time.perf_counter() - t1) / reps
     kept = int(dets[0][0].numel())
+    roof = inference_roofline(model, img, dtype_name) if dtype_name else None
     del model, detect, dets
     torch.cuda.empty_cache()
-    return round(ti * 1e3 / B, 4), round(tf * 1e3 / B, 4), kept
+    return round(ti * 1e3 / B, 4), round(tf * 1e3 / B, 4), kept, roof
 
 
 def main():
@@ -299,8 +336,20 @@ def main():
     dev = torch.device('cuda', local)
     from efficientdet.pytorch_amd import EFFICIENTDET, ddp
     import torch.distributed as dist
-    if world > 1:
-        ddp.init_process_group_from_env(os.environ.get('EFFDET_BENCH_BACKEND', 'nccl'))     # 'nccl' IS RCCL on ROCm
+    a.ddp_graph_ok, probe_note = False, None
+    if world > 1 or a.ddp_single:
+        backend = os.environ.get('EFFDET_BENCH_BACKEND', 'nccl')                             # 'nccl' IS RCCL on ROCm
+        if backend == 'nccl' and not a.no_ddp_graph and not a.no_graph and not a.torch_optim:
+            # pre-flight, BEFORE this job owns a communicator: can this box capture + replay an RCCL collective inside a hipGraph?
+            ok, probe_note = ddp.rccl_graph_probe(local)
+        else:
+            ok, probe_note = False, 'not probed (%s)' % ('backend %s' % backend if backend != 'nccl' else 'graph capture disabled by flag')
+        if a.ddp_single:
+            os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1'); os.environ.setdefault('LOCAL_RANK', '0')
+        ddp.init_process_group_from_env(backend)
+        flag = torch.tensor([1 if ok else 0], device=dev)                                   # every rank takes the same path
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        a.ddp_graph_ok = bool(int(flag.item()))
     cfg = EFFICIENTDET[a.network]
     d0_512 = a.network == 'efficientdet-d0' and a.size == 512
 
@@ -323,7 +372,9 @@ def main():
         'config': {'workload': 'EfficientDet-D0 train step (fwd + FocalLoss/SmoothL1 + bwd + clip_grad_norm + AdamW), batch %d/GPU @ %dx%d, '
                                'synthetic COCO-shape targets, 80 classes, random-init, W_bifpn=%d D_bifpn=%d, drop_connect 0.2 active'
                                % (a.batch, a.size, a.size, cfg['W_bifpn'], cfg['D_bifpn']),
-                   'network': a.network, 'global_batch': a.batch * world, 'image_size': a.size, 'parallelism': 'dp%d' % world,
+                   'network': a.network, 'global_batch': a.batch * world, 'image_size': a.size,
+                   'parallelism': 'dp%d' % world + (' (world_size-1 RCCL group: ddp.wrap + bucketed all-reduce on the one GPU)' if a.ddp_single else ''),
+                   'ddp_graph': ({'captured': bool(graphed), 'rccl_capture_probe': probe_note} if (world > 1 or a.ddp_single) else None),
                    'arithmetic': MODE_NOTE[a.dtype],
                    'final_loss': round(final_loss, 4), 'launch': 'hipGraph replay (one graph launch per step)' if graphed else 'eager launches'},
         'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / ms_step, 2) if d0_512 else None,
@@ -344,34 +395,41 @@ def main():
                                     'launch': 'hipGraph replay' if pgr else 'eager launches', 'note': MODE_NOTE[mode], 'roofline': proof}
 
     if rank == 0 and world == 1 and not a.no_inference:
-        ti, tf, kept = inference_leg(a.network, tdt[a.dtype], dev, img, graph=not a.no_graph, f32_arith=arith[a.dtype])
+        ti, tf, kept, iroof = inference_leg(a.network, tdt[a.dtype], dev, img, reps=a.infer_reps, graph=not a.no_graph, f32_arith=arith[a.dtype],
+                                            dtype_name=None if a.no_roofline else a.dtype)
+        gf = INFER_GFLOP_PER_IMG.get((a.network, a.size))
         out['inference'] = {'workload': 'configs[1]: D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
-                            'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
+                            'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept, 'reps': a.infer_reps,
+                            'forward_tflops': round(gf / tf, 2) if gf else None, 'roofline': iroof,
                             'launch': 'eager launches' if a.no_graph else 'forward + decode as one hipGraph replay, NMS eager (end-to-end number; forward_only is eager)'}
         if not a.no_extra_modes:
             for mode in others:
-                ti, tf, kept = inference_leg(a.network, tdt[mode], dev, img, reps=3, graph=not a.no_graph, f32_arith=arith[mode])
-                out['inference'][EXTRA_KEY[mode]] = {'dtype': mode, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+                ti, tf, kept, _ = inference_leg(a.network, tdt[mode], dev, img, reps=a.infer_reps, graph=not a.no_graph, f32_arith=arith[mode])
+                out['inference'][EXTRA_KEY[mode]] = {'dtype': mode, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
+                                                     'reps': a.infer_reps}
         del img
         torch.cuda.empty_cache()
         if not a.no_d4:
             from efficientdet.pytorch_amd.synthetic import synthetic_batch
             img4 = synthetic_batch(8, 1024, seed=1, num_classes=80)[0].to(dev)
-            ti, tf, kept = inference_leg('efficientdet-d4', tdt[a.dtype], dev, img4, reps=3, graph=not a.no_graph, f32_arith=arith[a.dtype])
+            ti, tf, kept, iroof = inference_leg('efficientdet-d4', tdt[a.dtype], dev, img4, reps=a.infer_reps, graph=not a.no_graph,
+                                                f32_arith=arith[a.dtype], dtype_name=None if a.no_roofline else a.dtype)
             out['inference_d4'] = {'workload': 'configs[4]: D4 eval batch 8 @ 1024: forward + decode + per-image NMS (thr 0.01, IoU 0.5)',
-                                   'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
-                                   'forward_tflops': round(455.596 * 8 / (tf * 8) , 2)}
+                                   'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept, 'reps': a.infer_reps,
+                                   'forward_tflops': round(455.596 / tf, 2), 'roofline': iroof}
             if not a.no_extra_modes:
                 for mode in others:
-                    ti, tf, kept = inference_leg('efficientdet-d4', tdt[mode], dev, img4, reps=2, graph=not a.no_graph, f32_arith=arith[mode])
-                    out['inference_d4'][EXTRA_KEY[mode]] = {'dtype': mode, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept}
+                    ti, tf, kept, _ = inference_leg('efficientdet-d4', tdt[mode], dev, img4, reps=max(a.infer_reps // 2, 2), graph=not a.no_graph,
+                                                    f32_arith=arith[mode])
+                    out['inference_d4'][EXTRA_KEY[mode]] = {'dtype': mode, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept,
+                                                            'reps': max(a.infer_reps // 2, 2)}
 
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(a.network, a.size)
 
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or a.ddp_single:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,57 @@ def wrap(model, device_ids=None, bucket_cap_mb=8):
                                                      broadcast_buffers=False)
 
 
+_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+dev = int(sys.argv[1]); torch.cuda.set_device(dev)
+dist.init_process_group('nccl', init_method='env://')
+x = torch.ones(1 << 20, device='cuda'); dist.all_reduce(x); torch.cuda.synchronize()      # communicator bring-up, eager
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    for _ in range(3):
+        dist.all_reduce(x)
+torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    y = x * 2.0; dist.all_reduce(y); z = y + 1.0
+for _ in range(3):
+    g.replay()
+torch.cuda.synchronize()
+ok = bool((z == 3.0).all())
+dist.destroy_process_group()
+sys.exit(0 if ok else 3)
+"""
+
+
+def rccl_graph_probe(device_index, timeout=180):
+    """Can an RCCL collective be captured into a hipGraph and replayed on this box with this torch / RCCL build?  Answered in a
+    THROW-AWAY child process (its own world_size = 1 'nccl' group on `device_index`): a failed capture leaves a process with an
+    invalidated stream and possibly a half-issued collective, which is not recoverable -- so the decision between the captured
+    DDP step and eager launches is taken here, before the real job has put any collective in flight.  -> (ok, detail)."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if not k.startswith(('TORCHELASTIC_', 'GROUP_', 'ROLE_', 'LOCAL_WORLD'))}
+    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), TORCH_NCCL_ASYNC_ERROR_HANDLING='0')
+    try:
+        r = subprocess.run([sys.executable, '-c', _PROBE, str(int(device_index))], env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return False, 'probe timed out after %d s' % timeout
+    return r.returncode == 0, ('ok' if r.returncode == 0 else 'rc %d: %s' % (r.returncode, r.stderr.strip()[-300:]))
+
+
+def wrap_for_capture(model, device_ids=None, bucket_cap_mb=8):
+    """ddp.wrap constructed on a side stream: torch's rule for a DDP module whose step will later be captured as a graph."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        w = wrap(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb)
+    torch.cuda.current_stream().wait_stream(side)
+    return w
+
+
 def shard_batch(images, annotations, rank, world_size):
     """Contiguous equal shards of a global batch (the reference divides batch_size by ngpus, train.py:247)."""
     per = images.shape[0] // world_size

@@ -21,12 +21,22 @@ csv.field_size_limit(1 << 30)
 NXCD, NSIMD = 8, 1024
 
 
+DUR = defaultdict(list)       # kernel name -> dispatch durations (ns) of the SQ / GRBM pass, when the csv carries timestamps
+
+
 def per_launch(d, counters):
     tot = defaultdict(float)
+    seen = set()
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] in counters:
                 tot[(r['Kernel_Name'], r['Dispatch_Id'], r['Counter_Name'])] += float(r['Counter_Value'])
+                if 'GRBM_GUI_ACTIVE' in counters and r.get('Start_Timestamp') and (r['Kernel_Name'], r['Dispatch_Id']) not in seen:
+                    seen.add((r['Kernel_Name'], r['Dispatch_Id']))
+                    try:
+                        DUR[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+                    except (ValueError, KeyError):
+                        pass
     agg = defaultdict(lambda: defaultdict(list))
     for (k, _, c), v in tot.items():
         agg[k][c].append(v)
@@ -76,6 +86,7 @@ def main():
             continue
         e = out.setdefault(s, defaultdict(float))
         e['n_s'] += len(d['GRBM_GUI_ACTIVE']); e['mfma'] += sum(d['SQ_VALU_MFMA_BUSY_CYCLES']); e['grbm'] += sum(d['GRBM_GUI_ACTIVE'])
+        e['dur_ns'] += sum(DUR.get(k, [])); e['n_dur'] += len(DUR.get(k, []))
     kernels = {}
     for s, e in sorted(out.items()):
         r = {}
@@ -86,6 +97,10 @@ def main():
         if e['n_s'] and e['grbm']:
             r.update(mfma_busy_cycles_per_launch=round(e['mfma'] / e['n_s']), grbm_gui_active_sum_per_launch=round(e['grbm'] / e['n_s']),
                      mfma_busy_frac=round(e['mfma'] / (e['grbm'] / NXCD * NSIMD), 4))
+            if e['n_dur'] == e['n_s'] and e['dur_ns']:
+                # effective shader clock while the kernel ran = GRBM_GUI_ACTIVE cycles (per XCD) / the dispatch's wall time (DVFS evidence)
+                r.update(avg_duration_us_profiled=round(e['dur_ns'] / e['n_dur'] / 1e3, 1),
+                         effective_clock_mhz=round((e['grbm'] / NXCD) / e['dur_ns'] * 1e3, 0))
         kernels[s] = r
     res = {'dtype': dtype,
            'source': 'rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (three separate passes) -- '
