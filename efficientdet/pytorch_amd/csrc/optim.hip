@@ -36,6 +36,16 @@ __device__ __forceinline__ float block_sum(float s) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
+// 4 consecutive elements starting at g + i: ONE 16-byte load when the address allows it, four scalar loads otherwise -- the
+// VALUES and everything computed from them are the same either way.  (Round 3 summed aligned tensors float4-wise and unaligned
+// ones element-strided: two summation orders, so the norm -- and through the clip coefficient every parameter -- differed in the
+// last bit between a model whose gradients are separate allocations and the same model under DistributedDataParallel, whose
+// gradients are views into flat buckets at arbitrary 4-byte offsets.  Found by the world_size-1 RCCL test.)
+__device__ __forceinline__ f32x4 load4_any(const float* q, bool al) {
+  if (al) return *(const f32x4*)q;
+  return f32x4{q[0], q[1], q[2], q[3]};
+}
+
 __global__ __launch_bounds__(256) void opt_norm_kernel(const OptK k) {
   const int ti = k.block_tensor[blockIdx.x];
   const float* g = (const float*)k.g[ti];
@@ -43,13 +53,11 @@ __global__ __launch_bounds__(256) void opt_norm_kernel(const OptK k) {
   if (g) {
     const long long n = k.n[ti], off = (long long)(blockIdx.x - k.block_first[ti]) * OPT_CHUNK;
     const long long end = off + OPT_CHUNK < n ? off + OPT_CHUNK : n;
-    if ((((unsigned long long)(g + off)) & 15ull) == 0) {
-      for (long long i = off + threadIdx.x * 4; i < end; i += 1024) {
-        if (i + 3 < end) { const f32x4 x = *(const f32x4*)(g + i); s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]; }
-        else for (long long j = i; j < end; ++j) s += g[j] * g[j];
-      }
-    } else {
-      for (long long i = off + threadIdx.x; i < end; i += 256) s += g[i] * g[i];
+    const bool al = (((unsigned long long)(g + off)) & 15ull) == 0;
+    // thread t owns elements off + 4t .. 4t + 3 (+ 1024 per round) whatever the alignment: ONE summation order
+    for (long long i = off + threadIdx.x * 4; i < end; i += 1024) {
+      if (i + 3 < end) { const f32x4 x = load4_any(g + i, al); s += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]; }
+      else for (long long j = i; j < end; ++j) s += g[j] * g[j];
     }
   }
   s = block_sum(s);
@@ -88,27 +96,34 @@ __global__ __launch_bounds__(256) void opt_adamw_kernel(const OptK kk) {
   const float step_size = k.lr / (1.0f - powf(k.beta1, t)), bc2_sqrt = sqrtf(1.0f - powf(k.beta2, t));
   const long long n = kk.n[ti], off = (long long)(blockIdx.x - kk.block_first[ti]) * OPT_CHUNK;
   const long long end = off + OPT_CHUNK < n ? off + OPT_CHUNK : n;
-  const bool al = ((((unsigned long long)(g + off)) | ((unsigned long long)(p + off)) | ((unsigned long long)(m + off)) |
-                    ((unsigned long long)(v + off))) & 15ull) == 0;
-  if (al) {
-    for (long long i = off + threadIdx.x * 4; i < end; i += 1024) {
-      if (i + 3 < end) {
-        f32x4 gv = *(const f32x4*)(g + i), pv = *(const f32x4*)(p + i), mv = *(const f32x4*)(m + i), vv = *(const f32x4*)(v + i);
+  const bool alg = (((unsigned long long)(g + off)) & 15ull) == 0;
+  const bool alp = ((((unsigned long long)(p + off)) | ((unsigned long long)(m + off)) | ((unsigned long long)(v + off))) & 15ull) == 0;
+  // one code path for the arithmetic (see load4_any): vector or scalar memory operations, identical values
+  for (long long i = off + threadIdx.x * 4; i < end; i += 1024) {
+    if (i + 3 < end) {
+      f32x4 gv = load4_any(g + i, alg), pv = load4_any(p + i, alp), mv = load4_any(m + i, alp), vv = load4_any(v + i, alp);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float pe = pv[e], me = mv[e], ve = vv[e];
-          const float ge = gv[e] * coef;
-          adamw1(pe, me, ve, ge, k, step_size, bc2_sqrt);
-          pv[e] = pe; mv[e] = me; vv[e] = ve; gv[e] = ge;
-        }
-        *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
-        if (kk.write_grad) *(f32x4*)(g + i) = gv;
-      } else {
-        for (long long j = i; j < end; ++j) { const float gj = g[j] * coef; adamw1(p[j], m[j], v[j], gj, k, step_size, bc2_sqrt); if (kk.write_grad) g[j] = gj; }
+      for (int e = 0; e < 4; ++e) {
+        float pe = pv[e], me = mv[e], ve = vv[e];
+        const float ge = gv[e] * coef;
+        adamw1(pe, me, ve, ge, k, step_size, bc2_sqrt);
+        pv[e] = pe; mv[e] = me; vv[e] = ve; gv[e] = ge;
       }
+      if (alp) { *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv; }
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { p[i + e] = pv[e]; m[i + e] = mv[e]; v[i + e] = vv[e]; }
+      }
+      if (kk.write_grad) {
+        if (alg) *(f32x4*)(g + i) = gv;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) g[i + e] = gv[e];
+        }
+      }
+    } else {
+      for (long long j = i; j < end; ++j) { const float gj = g[j] * coef; adamw1(p[j], m[j], v[j], gj, k, step_size, bc2_sqrt); if (kk.write_grad) g[j] = gj; }
     }
-  } else {
-    for (long long i = off + threadIdx.x; i < end; i += 256) { const float gi = g[i] * coef; adamw1(p[i], m[i], v[i], gi, k, step_size, bc2_sqrt); if (kk.write_grad) g[i] = gi; }
   }
 }
 

@@ -205,3 +205,31 @@ def test_clip_adamw_matches_torch(max_norm):
             assert_close(a.detach().cpu(), b.detach().cpu(), 1e-5, 'param step %d' % it)
     st = oa.state_dict()
     assert len(st['state']) == len(shapes)
+
+
+def test_clip_adamw_is_bitwise_independent_of_gradient_alignment():
+    """Gradients handed over as views into a flat bucket at arbitrary 4-byte offsets (DistributedDataParallel with
+    gradient_as_bucket_view) must give the same bits as separately allocated ones: the norm's summation order -- hence the clip
+    coefficient, hence every updated parameter -- may not depend on pointer alignment (found by tests/test_gpu_rccl.py)."""
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 32, 3, 3), (6,), (4099,), (10,), (720, 64, 3, 3), (1,), (8190,)]
+    pa = [torch.randn(s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    pb = [p.detach().clone().requires_grad_(True) for p in pa]
+    oa = ClipAdamW(pa, lr=1e-2, weight_decay=0.01, max_norm=0.1)
+    ob = ClipAdamW(pb, lr=1e-2, weight_decay=0.01, max_norm=0.1)
+    for it in range(3):
+        grads = [torch.randn(s, generator=g).cuda() for s in shapes]
+        n = sum(x.numel() for x in grads)
+        bucket = torch.empty(n + 3, device='cuda')
+        off = 1 + it                                            # 4-, 8-, 12-byte offsets: every tensor lands unaligned somewhere
+        for a, b, gr in zip(pa, pb, grads):
+            a.grad = gr
+            v = bucket[off:off + gr.numel()].view(gr.shape); v.copy_(gr); b.grad = v
+            off += gr.numel()
+        oa.step(); ob.step()
+        torch.cuda.synchronize()
+        assert torch.equal(oa.grad_norm(), ob.grad_norm())
+        for a, b in zip(pa, pb):
+            assert torch.equal(a.detach(), b.detach()), ('step', it, a.shape)
+    assert torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
