@@ -167,7 +167,9 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
     model = build_model(a.network, dtype, dev, True, 'bf16x3' if dtype_name == 'f32_bf16x3' else 'f32')
     ddp.freeze_dead_parameters(model)
     use_ddp = world > 1 or a.ddp_single
-    net = ddp.wrap_for_capture(model, device_ids=[local]) if use_ddp else model
+    # (captured DDP step: the module lives on the stream GraphedTrainStep warms up and captures on; eager DDP: the ambient stream)
+    want_graph = use_ddp and a.ddp_graph_ok and not a.no_graph and not a.torch_optim
+    net = (ddp.wrap_for_capture(model, device_ids=[local]) if want_graph else ddp.wrap(model, device_ids=[local])) if use_ddp else model
     params = [p for p in model.parameters() if p.requires_grad]
     if a.torch_optim:
         opt = torch.optim.AdamW(params, lr=1e-4, fused=True)
@@ -192,8 +194,14 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
-        step()
+    import contextlib
+    cap_stream = getattr(net, '_effdet_capture_stream', None)      # eager steps of a capture-bound DDP module run on ITS stream too
+
+    def on_stream():
+        return torch.cuda.stream(cap_stream) if cap_stream is not None else contextlib.nullcontext()
+    with on_stream():
+        for _ in range(warmup):
+            step()
     sync_all()
     graphed = None
     if (not use_ddp or a.ddp_graph_ok) and not a.no_graph and not a.torch_optim:
@@ -223,8 +231,9 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
             cl_rl = graphed()
         loss = cl_rl[0].mean() + cl_rl[1].mean()
     else:
-        for _ in range(steps):
-            loss = step()
+        with on_stream():
+            for _ in range(steps):
+                loss = step()
     host_dt = time.perf_counter() - t0          # time the HOST needed to issue the steps (a host-bound regime shows as host ~= wall)
     sync_all()
     dt = time.perf_counter() - t0
@@ -242,7 +251,8 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
         # (under DDP its gradient all-reduce is collective); only rank 0 instruments it.
         if rank == 0:
             ops.PROFILE = ops.LaunchProfile()
-        step()
+        with on_stream():
+            step()
         torch.cuda.synchronize()
         if rank == 0:
             summ = ops.PROFILE.summary()
@@ -299,7 +309,7 @@ def inference_leg(network, dtype, dev, img, reps=20, graph=True, f32_arith='f32'
         for _ in range(2):
             model.detect(img)
         detect = lambda: model.detect(img)
-        if graph:      # the same forward + decode replayed as one hipGraph, NMS + gather launched eagerly behind it
+        if graph:      # the same forward + decode + NMS + gather replayed as ONE hipGraph
             from efficientdet.pytorch_amd.graph import GraphedDetect
             try:
                 gd = GraphedDetect(model, img)
@@ -401,7 +411,7 @@ def main():
         out['inference'] = {'workload': 'configs[1]: D0 eval batch %d @ %d: forward + decode + per-image NMS (thr 0.01, IoU 0.5)' % (a.batch, a.size),
                             'dtype': a.dtype, 'ms_per_img': ti, 'forward_only_ms_per_img': tf, 'kept_boxes_img0': kept, 'reps': a.infer_reps,
                             'forward_tflops': round(gf / tf, 2) if gf else None, 'roofline': iroof,
-                            'launch': 'eager launches' if a.no_graph else 'forward + decode as one hipGraph replay, NMS eager (end-to-end number; forward_only is eager)'}
+                            'launch': 'eager launches' if a.no_graph else 'forward + decode + NMS + gather as ONE hipGraph replay (end-to-end number; forward_only is eager)'}
         if not a.no_extra_modes:
             for mode in others:
                 ti, tf, kept, _ = inference_leg(a.network, tdt[mode], dev, img, reps=a.infer_reps, graph=not a.no_graph, f32_arith=arith[mode])

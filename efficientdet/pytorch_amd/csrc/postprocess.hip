@@ -106,6 +106,9 @@ struct NmsWs {
   int* offsets; int* nvalid; int* kept; unsigned* dead; float4* sbox; float4* kbox;
   void* temp; size_t temp_bytes;
   KeptGrid kg;                                      // spatial hash of the kept boxes (cross phase, iou_threshold >= 0.5)
+  // round 4: in-tree radix sort (32-bit keys per image, ping-pong) + the multi-workgroup round
+  unsigned *k32a, *k32b, *v32b, *hist; int T;
+  unsigned long long* rowbits; float4* surv_box; unsigned* surv_idx; int* surv_n; int RND, NW;
 };
 
 __device__ __forceinline__ bool suppresses(const float4& a, float aa, const float4& b, float ab, float thr) {
@@ -227,9 +230,9 @@ __device__ __forceinline__ void kg_insert(const KeptGrid& kg, long long b, long 
 // here the 64 lanes take (cell, entry) pairs -- 8 cells x 8 entries per pass, count and box loads independent of each other --
 // so a candidate costs a handful of round trips and a round of 2048 candidates fills the chip (B x 2048 waves).
 __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __restrict__ sbox, const KeptGrid kg, const int* nvalid,
-                                                             unsigned* dead, long long A, int round, float thr) {
+                                                             unsigned* dead, long long A, int round, float thr, int RND) {
   const int b = blockIdx.y, lane = threadIdx.x & 63;
-  const long long i = (long long)round * ROUND + blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const long long i = (long long)round * RND + blockIdx.x * 4LL + (threadIdx.x >> 6);
   if (i >= nvalid[b]) return;                                        // wave-uniform
   const float4 me = sbox[b * A + i];
   const float ma = box_area(me);
@@ -291,13 +294,13 @@ __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __res
 
 // Kernel A: candidates of round `round` vs boxes kept in earlier rounds (split over blockIdx.z).
 __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict__ sbox, const float4* kbox, const int* nvalid,
-                                                       const int* kept, unsigned* dead, long long A, int round, int splits, float thr) {
+                                                       const int* kept, unsigned* dead, long long A, int round, int splits, float thr, int RND) {
   __shared__ float4 kb[NT + 8];
   __shared__ float ka[NT + 8];
   const int b = blockIdx.x, sub = blockIdx.y, sp = blockIdx.z;
   const int nv = nvalid[b], kc = kept[b];
-  const long long i = (long long)round * ROUND + sub * NT + threadIdx.x;
-  if ((long long)round * ROUND + (long long)sub * NT >= nv) return;
+  const long long i = (long long)round * RND + sub * NT + threadIdx.x;
+  if ((long long)round * RND + (long long)sub * NT >= nv) return;
   const int k0 = (int)((long long)kc * sp / splits), k1 = (int)((long long)kc * (sp + 1) / splits);
   if (k0 >= k1) return;
   const bool valid = i < nv;
@@ -460,6 +463,223 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
   (void)sh;
 }
 
+
+// ------------------------------------------------------------------ NMS, round 4: in-tree sort + a round spread over the GPU
+// (1) Stable LSD radix sort of the B equal-length segments (one per image) of 32-bit keys with their anchor indices: 4 passes of
+//     8 bits, each pass = histogram per 4096-key tile -> per-image exclusive scan over (digit, tile) -> stable scatter (inside a
+//     workgroup the keys are ranked 256 at a time: wave-level match by 8 ballots, per-wave digit counts, running digit cursors).
+//     Replaces rocprim::radix_sort_pairs (the one third-party device routine on the path; its captured replay faulted, which kept
+//     NMS out of the detection graph).  Nothing here depends on run-time data for its launch geometry: capture-safe.
+// (2) A round (RND = 2048 candidates; 4096 for > 64 k anchors) is three launches: the cross phase above (whole GPU) marks
+//     candidates suppressed by boxes kept in EARLIER rounds; nms_matrix_kernel (G workgroups per image) compacts the round's
+//     survivors and computes their suppression bit-matrix -- one wave per (64-row block, 64-column word), every lane its own row
+//     against the same 64 staged boxes, one coalesced 512-byte store of the word column -- into global memory (word-major); and
+//     nms_resolve_kernel (one WAVE per image) walks the rows in blocks of 64 exactly like the single-workgroup kernel did (earlier
+//     kept words AND-ed against the row, one ballot per kept box inside the block), appends the kept boxes in order and files them
+//     into the kept-box grid.  The old per-image round kernel did all of this on ONE CU per image (32 of 256 CUs at B = 32) and was
+//     2/3 of the decode + NMS time.
+constexpr int RS_TILE = 4096;                    // keys per workgroup and pass
+
+__global__ __launch_bounds__(256) void nms_keys32_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals,
+                                                         int* nvalid, int* kept, unsigned* dead, long long A) {
+  const int b = blockIdx.y;
+  __shared__ int cnt[4];
+  int mine = 0;
+  for (long long a = blockIdx.x * 256LL + threadIdx.x; a < A; a += (long long)gridDim.x * 256) {
+    const long long i = (long long)b * A + a;
+    const float s = score[i];
+    unsigned k = 0xffffffffu;
+    if (s > thr) {
+      unsigned u = __float_as_uint(s);
+      u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;     // ascending-orderable
+      k = ~u;                                         // descending score
+      if (k == 0xffffffffu) k = 0xfffffffeu;
+      ++mine;
+    }
+    keys[i] = k; vals[i] = (unsigned)a; dead[i] = 0u;
+  }
+  mine = (int)wave_sum((float)mine);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    if (t) atomicAdd(nvalid + b, t);
+    if (blockIdx.x == 0) kept[b] = 0;
+  }
+}
+
+// hist[b][digit][tile]
+__global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ hist, long long A, int T, int shift) {
+  __shared__ unsigned h[256];
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  h[tid] = 0u;
+  __syncthreads();
+  const unsigned* k = keys + (long long)b * A;
+  const long long i0 = (long long)tile * RS_TILE, i1 = min(A, i0 + RS_TILE);
+  for (long long i = i0 + tid; i < i1; i += 256) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+  __syncthreads();
+  hist[((long long)b * 256 + tid) * T + tile] = h[tid];
+}
+
+// per image: exclusive scan over (digit, tile) in digit-major order, in place
+__global__ __launch_bounds__(256) void rs_scan_kernel(unsigned* __restrict__ hist, int T) {
+  __shared__ unsigned tot[256];
+  const int b = blockIdx.x, d = threadIdx.x;
+  unsigned* row = hist + ((long long)b * 256 + d) * T;
+  unsigned s = 0u;
+  for (int t = 0; t < T; ++t) s += row[t];
+  tot[d] = s;
+  __syncthreads();
+  if (d == 0) { unsigned run = 0u; for (int q = 0; q < 256; ++q) { const unsigned c = tot[q]; tot[q] = run; run += c; } }
+  __syncthreads();
+  unsigned run = tot[d];
+  for (int t = 0; t < T; ++t) { const unsigned c = row[t]; row[t] = run; run += c; }
+}
+
+__global__ __launch_bounds__(256) void rs_scatter_kernel(const unsigned* __restrict__ kin, const unsigned* __restrict__ vin,
+                                                         unsigned* __restrict__ kout, unsigned* __restrict__ vout,
+                                                         const unsigned* __restrict__ hist, long long A, int T, int shift) {
+  __shared__ unsigned cur[256];                  // next output slot of each digit for this tile
+  __shared__ unsigned wcnt[4][256];              // per-wave digit counts of the current 256-key chunk
+  const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  cur[tid] = hist[((long long)b * 256 + tid) * T + tile];
+  const long long base = (long long)b * A, i0 = (long long)tile * RS_TILE;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  for (int c = 0; c < RS_TILE / 256; ++c) {
+    const long long i = i0 + c * 256 + tid;
+    if (i0 + c * 256 >= A) break;                                      // uniform
+    const bool valid = i < A;
+    const unsigned key = valid ? kin[base + i] : 0u, val = valid ? vin[base + i] : 0u;
+    const unsigned d = (key >> shift) & 255u;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+    __syncthreads();
+    unsigned long long peers = __ballot(valid);                        // lanes of this wave holding the same digit
+#pragma unroll
+    for (int bit = 0; bit < 8; ++bit) {
+      const bool on = (d >> bit) & 1u;
+      const unsigned long long bb = __ballot(on);
+      peers &= on ? bb : ~bb;
+    }
+    const int rank = __popcll(peers & lt);
+    if (valid && rank == 0) wcnt[wave][d] = (unsigned)__popcll(peers);
+    __syncthreads();
+    if (valid) {
+      unsigned pos = cur[d] + (unsigned)rank;
+      for (int w = 0; w < wave; ++w) pos += wcnt[w][d];
+      kout[base + pos] = key; vout[base + pos] = val;
+    }
+    __syncthreads();
+    cur[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    __syncthreads();                                                   // (the next chunk zeroes wcnt)
+  }
+}
+
+struct NmsRound { unsigned long long* rowbits; float4* surv_box; unsigned* surv_idx; int* surv_n; int RND, NW; };
+
+// grid (G, B): the survivors of round `round` of image b and the word columns (rb, w), w <= rb, of their suppression bit-matrix.
+// rowbits[b][w][r] bit j: survivor 64 w + j (an EARLIER survivor) suppresses survivor r.
+__global__ __launch_bounds__(256) void nms_matrix_kernel(const float4* __restrict__ sbox, const unsigned* __restrict__ sidx,
+                                                         const int* __restrict__ nvalid, const unsigned* __restrict__ dead,
+                                                         const NmsRound q, long long A, int round, float thr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float4* tb = (float4*)smem_raw;                                      // [RND + 64] survivor boxes
+  float* ta = (float*)(tb + q.RND + 64);                               // [RND + 64] areas
+  __shared__ int wsum[4];
+  const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = nvalid[b];
+  const long long r0 = (long long)round * q.RND;
+  if (r0 >= nv) return;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int S = 0;
+  for (int c0 = 0; c0 < q.RND; c0 += 256) {
+    if (r0 + c0 >= nv) break;                                          // uniform
+    const long long i = r0 + c0 + tid;
+    const bool alive = i < nv && dead[b * A + i] == 0u;
+    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (alive) me = sbox[b * A + i];
+    const unsigned long long bal = __ballot(alive);
+    if (lane == 0) wsum[wave] = __popcll(bal);
+    __syncthreads();
+    int off = S, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
+    if (alive) {
+      const int s = off + __popcll(bal & lt);
+      tb[s] = me; ta[s] = (me.z - me.x) * (me.w - me.y);
+      if (g == 0) { q.surv_box[(long long)b * q.RND + s] = me; q.surv_idx[(long long)b * q.RND + s] = sidx[b * A + i]; }
+    }
+    S += tot;
+    __syncthreads();
+  }
+  if (tid < 64) { tb[S + tid] = no_box(); ta[S + tid] = 0.f; }         // columns past S suppress nothing
+  if (g == 0 && tid == 0) q.surv_n[b] = S;
+  __syncthreads();
+  const int nb = (S + 63) >> 6, items = nb * (nb + 1) / 2;
+  for (int item = g * 4 + wave; item < items; item += G * 4) {         // (rb, w) pairs in row-block-major order
+    int rb = (int)((sqrtf(8.f * (float)item + 1.f) - 1.f) * 0.5f);
+    while ((rb + 1) * (rb + 2) / 2 <= item) ++rb;
+    while (rb * (rb + 1) / 2 > item) --rb;
+    const int w = item - rb * (rb + 1) / 2;
+    const int r = rb * 64 + lane;
+    const float4 me = tb[r]; const float ma = ta[r];                   // (rows past S read the sentinels: all-zero words)
+    unsigned long long bits = 0ull;
+#pragma unroll 1
+    for (int j0 = 0; j0 < 64; j0 += 8) {
+      float4 c[8]; float ca[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { c[u] = tb[w * 64 + j0 + u]; ca[u] = ta[w * 64 + j0 + u]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (suppresses(me, ma, c[u], ca[u], thr)) bits |= 1ull << (j0 + u);
+    }
+    if (w == rb) bits &= lt;                                           // only EARLIER survivors count
+    if (r < S) q.rowbits[((long long)b * q.NW + w) * q.RND + r] = bits;
+  }
+}
+
+// grid B, ONE wave per image: the greedy order of the round's survivors from the bit-matrix, == sequential greedy NMS
+__global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const int* __restrict__ nvalid, int* kept, float4* kbox, int* out_idx,
+                                                         long long A, int round, const KeptGrid kg) {
+  __shared__ unsigned long long Kw[64];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  if ((long long)round * q.RND >= nvalid[b]) return;
+  const int S = q.surv_n[b];
+  int kc = kept[b];
+  const int nw = (S + 63) >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const unsigned long long* rows = q.rowbits + (long long)b * q.NW * q.RND;
+  for (int blk = 0; blk < nw; ++blk) {
+    const int r = blk * 64 + lane;
+    unsigned long long hit = 0ull;
+    int w = 0;
+    for (; w + 3 < blk; w += 4) {                                      // independent loads: their L2 round trips overlap
+      const unsigned long long m0 = rows[(long long)w * q.RND + r], m1 = rows[(long long)(w + 1) * q.RND + r];
+      const unsigned long long m2 = rows[(long long)(w + 2) * q.RND + r], m3 = rows[(long long)(w + 3) * q.RND + r];
+      hit |= (m0 & Kw[w]) | (m1 & Kw[w + 1]) | (m2 & Kw[w + 2]) | (m3 & Kw[w + 3]);
+    }
+    for (; w < blk; ++w) hit |= rows[(long long)w * q.RND + r] & Kw[w];
+    const bool gone = r >= S || hit != 0ull;
+    const unsigned long long diag = r < S ? rows[(long long)blk * q.RND + r] : 0ull;
+    unsigned long long cand = __ballot(!gone), keep = 0ull;
+    while (cand) {                                                     // uniform
+      const int i = __builtin_ctzll(cand);
+      keep |= 1ull << i;
+      cand &= ~(__ballot((diag >> i) & 1ull) | (1ull << i));           // a row's bits only name earlier rows: lanes > i
+    }
+    if (lane == 0) Kw[blk] = keep;
+    __syncthreads();                                                   // (one wave: orders the LDS write before the next block's reads)
+    if ((keep >> lane) & 1ull) {
+      const int pos = kc + __popcll(keep & lt);
+      const float4 bx = q.surv_box[(long long)b * q.RND + r];
+      kbox[b * A + pos] = bx;
+      out_idx[b * A + pos] = (int)q.surv_idx[(long long)b * q.RND + r];
+      if (kg.kcount) kg_insert(kg, b, A, bx);                          // file it for the later rounds' cross phase
+    }
+    kc += __popcll(keep);
+  }
+  if (lane == 0) kept[b] = kc;
+}
+
 __global__ void gather_dets_kernel(const float* __restrict__ boxes, const float* __restrict__ score, const int* __restrict__ label,
                                    const int* __restrict__ idx, const int* __restrict__ count, float* __restrict__ os,
                                    long long* __restrict__ ol, float* __restrict__ ob, long long A, int B) {
@@ -485,6 +705,14 @@ size_t sort_temp_bytes(long long total, int B) {
   return bytes;
 }
 
+// candidates per round of the multi-workgroup form: 2048 (D0 @512: 24 rounds), 4096 above 64 k anchors (D4 @1024: 48 rounds);
+// EFFDET_NMS_ROUND overrides (A/B)
+inline int nms_round_size(long long A) {
+  static const int env = getenv("EFFDET_NMS_ROUND") ? atoi(getenv("EFFDET_NMS_ROUND")) : 0;
+  if (env >= 256 && env <= 4096 && (env & 63) == 0) return env;
+  return A > 65536 ? 4096 : 2048;
+}
+
 size_t carve(NmsWs& w, void* base, int B, long long A) {
   const size_t n = (size_t)B * A;
   size_t off = 0;
@@ -500,6 +728,13 @@ size_t carve(NmsWs& w, void* base, int B, long long A) {
   w.kg.HT = ht;
   w.kg.kcount = (int*)take((size_t)B * ht * 4); w.kg.kover_n = (int*)take((size_t)B * 4);
   w.kg.kcell = (float4*)take((size_t)B * ht * KG_CAP * 16); w.kg.kover = (float4*)take(n * 16);
+  // round 4 (the 32-bit key buffers alias nothing of the above: the rocPRIM path, kept for A/B under EFFDET_NMS_V1, still owns its own)
+  w.T = (int)((A + RS_TILE - 1) / RS_TILE);
+  w.k32a = (unsigned*)take(n * 4); w.k32b = (unsigned*)take(n * 4); w.v32b = (unsigned*)take(n * 4);
+  w.hist = (unsigned*)take((size_t)B * 256 * w.T * 4);
+  w.RND = nms_round_size(A); w.NW = w.RND / 64;
+  w.rowbits = (unsigned long long*)take((size_t)B * w.NW * w.RND * 8);
+  w.surv_box = (float4*)take((size_t)B * w.RND * 16); w.surv_idx = (unsigned*)take((size_t)B * w.RND * 4); w.surv_n = (int*)take((size_t)B * 4);
   return off;
 }
 
@@ -567,14 +802,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * A;
   if (hipMemsetAsync(w.nvalid, 0, (size_t)B * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-  { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(nms_keys_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B); }
-  EFFDET_CHECK_LAUNCH();
-  size_t tb = w.temp_bytes;
-  if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, (unsigned)key_bits(B), st, false) != hipSuccess)
-    return EFFDET_ELAUNCH;
-  hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
-  EFFDET_CHECK_LAUNCH();
+  static const int v1 = getenv("EFFDET_NMS_V1") ? atoi(getenv("EFFDET_NMS_V1")) : 0;      // A/B switch: 1 = the round-3 path (rocPRIM sort, one workgroup per image and round)
   static const int grid_env = getenv("EFFDET_NMS_GRID") ? atoi(getenv("EFFDET_NMS_GRID")) : 1;       // A/B switch (0 = brute-force cross phase)
   const bool use_grid = grid_env && iou_threshold >= 0.5f;
   KeptGrid kg = w.kg;
@@ -584,19 +812,61 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   } else {
     kg.kcount = nullptr;
   }
+  if (!v1) {
+    // ---- keys, in-tree stable radix sort per image (4 x 8 bits), boxes in sorted order ----
+    { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
+      hipLaunchKernelGGL(nms_keys32_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.k32a, w.vals_in, w.nvalid, w.kept, w.dead, A); }
+    EFFDET_CHECK_LAUNCH();
+    unsigned *ki = w.k32a, *vi = w.vals_in, *ko = w.k32b, *vo = w.v32b;
+    for (int pass = 0; pass < 4; ++pass) {
+      hipLaunchKernelGGL(rs_hist_kernel, dim3(w.T, B), dim3(256), 0, st, (const unsigned*)ki, w.hist, A, w.T, pass * 8);
+      hipLaunchKernelGGL(rs_scan_kernel, dim3(B), dim3(256), 0, st, w.hist, w.T);
+      hipLaunchKernelGGL(rs_scatter_kernel, dim3(w.T, B), dim3(256), 0, st, (const unsigned*)ki, (const unsigned*)vi, ko, vo, (const unsigned*)w.hist, A, w.T, pass * 8);
+      EFFDET_CHECK_LAUNCH();
+      unsigned* t = ki; ki = ko; ko = t; t = vi; vi = vo; vo = t;
+    }
+    // (4 passes: the sorted pairs are back in k32a / vals_in)
+    hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, (const unsigned*)vi, w.nvalid, w.sbox, A, B);
+    EFFDET_CHECK_LAUNCH();
+    // ---- rounds: cross phase (whole GPU) -> survivors + bit-matrix (G workgroups per image) -> greedy resolve (one wave per image) ----
+    NmsRound q; q.rowbits = w.rowbits; q.surv_box = w.surv_box; q.surv_idx = w.surv_idx; q.surv_n = w.surv_n; q.RND = w.RND; q.NW = w.NW;
+    const int RND = w.RND, rounds = (int)((A + RND - 1) / RND);
+    int G = 2048 / B; if (G < 2) G = 2; if (G > 16) G = 16;                          // ~2048 workgroups of 4 waves per launch
+    const size_t lds2 = (size_t)(RND + 64) * (16 + 4);
+    EFFDET_SET_MAX_LDS((nms_matrix_kernel), (size_t)(4096 + 64) * (16 + 4));      // (the largest round size: the attribute is set once per device)
+    for (int r = 0; r < rounds; ++r) {
+      if (r > 0 && use_grid) {
+        hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(RND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
+        EFFDET_CHECK_LAUNCH();
+      } else if (r > 0) {
+        hipLaunchKernelGGL(nms_cross_kernel, dim3(B, RND / NT, 16), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, 16, iou_threshold, RND);
+        EFFDET_CHECK_LAUNCH();
+      }
+      hipLaunchKernelGGL(nms_matrix_kernel, dim3(G, B), dim3(256), lds2, st, w.sbox, (const unsigned*)vi, w.nvalid, w.dead, q, A, r, iou_threshold);
+      hipLaunchKernelGGL(nms_resolve_kernel, dim3(B), dim3(64), 0, st, q, w.nvalid, w.kept, w.kbox, out_idx, A, r, kg);
+      EFFDET_CHECK_LAUNCH();
+    }
+    if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
+    return EFFDET_OK;
+  }
+  { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(nms_keys_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B); }
+  EFFDET_CHECK_LAUNCH();
+  size_t tb = w.temp_bytes;
+  if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, (unsigned)key_bits(B), st, false) != hipSuccess)
+    return EFFDET_ELAUNCH;
+  hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
+  EFFDET_CHECK_LAUNCH();
   const size_t lds = (size_t)16 * NT * 8 + (size_t)(NT + 8) * 16 + (size_t)(NT + 8) * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
   EFFDET_SET_MAX_LDS((nms_round_kernel), lds);
-  // (Measured and dropped: overlapping the hash probe of round r+1 -- against boxes kept up to round r-1, on a side stream --
-  //  with round r, plus a short brute-force pass for round r's own boxes.  Exact, but the two cross-stream event waits per
-  //  round cost more than the ~70 us they hide: D0 0.288 -> 0.301 ms/img, D4 2.44 -> 2.59.)
   const int rounds = (int)((A + ROUND - 1) / ROUND);
   for (int r = 0; r < rounds; ++r) {
     if (r > 0 && use_grid) {
-      hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(ROUND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold);
+      hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(ROUND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, ROUND);
       EFFDET_CHECK_LAUNCH();
     } else if (r > 0) {
       constexpr int SPLITS = SUBS >= 8 ? 4 : (SUBS >= 4 ? 8 : 16);      // keep ~1000 workgroups per launch at B = 32
-      hipLaunchKernelGGL(nms_cross_kernel, dim3(B, SUBS, SPLITS), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, SPLITS, iou_threshold);
+      hipLaunchKernelGGL(nms_cross_kernel, dim3(B, SUBS, SPLITS), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, SPLITS, iou_threshold, ROUND);
       EFFDET_CHECK_LAUNCH();
     }
     hipLaunchKernelGGL(nms_round_kernel, dim3(B), dim3(NT), lds, st, w.sbox, w.vals_out, w.kbox, w.nvalid, w.kept, w.dead, out_idx, A, r, iou_threshold, kg);

@@ -61,7 +61,7 @@ with torch.cuda.stream(side):
         dist.all_reduce(x)
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g):
+with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):      # (the watchdog thread polls events: see graph.py)
     y = x * 2.0; dist.all_reduce(y); z = y + 1.0
 for _ in range(3):
     g.replay()
@@ -95,12 +95,18 @@ def rccl_graph_probe(device_index, timeout=180):
 
 
 def wrap_for_capture(model, device_ids=None, bucket_cap_mb=8):
-    """ddp.wrap constructed on a side stream: torch's rule for a DDP module whose step will later be captured as a graph."""
+    """ddp.wrap for a step that will be captured as a hipGraph (graph.GraphedTrainStep): DistributedDataParallel stashes the
+    parameters' AccumulateGrad nodes at construction and those nodes -- with DDP's bucket-copy hooks -- keep running on the stream
+    that was current THEN.  The module is therefore built on a dedicated side stream which GraphedTrainStep then uses for its
+    warm-up iterations AND as the capture stream (`_effdet_capture_stream`): forward, backward, hooks and optimizer are one stream
+    inside the graph, RCCL's own stream being the only fork.  (Built on one stream and captured on another, the gradient copies
+    into the buckets ran on a third branch of the graph and the replays read half-written buckets: measured, round 4.)"""
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         w = wrap(model, device_ids=device_ids, bucket_cap_mb=bucket_cap_mb)
     torch.cuda.current_stream().wait_stream(side)
+    w._effdet_capture_stream = side
     return w
 
 

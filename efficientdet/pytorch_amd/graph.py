@@ -13,7 +13,8 @@ optimizer.param_groups before every replay, so lr schedulers keep working; only 
         step.images.copy_(batch_images); step.annotations.copy_(batch_annots)
         cls_loss, reg_loss = step()                                       # device tensors, valid until the next call
 
-Single-process, single-GPU (DDP's bucket hooks are left to eager mode).  Drop every reference to losses of earlier EAGER steps
+Under DistributedDataParallel (one process per GPU) build the module with ddp.wrap_for_capture and give the constructor
+warmup >= 11: DDP's bucketed RCCL all-reduces are then captured with the step (tests/test_gpu_rccl.py).  Drop every reference to losses of earlier EAGER steps
 before constructing this (a live loss keeps that step's autograd graph and its default-stream AccumulateGrad nodes alive, which
 a capture on another stream must not touch)."""
 import torch
@@ -38,16 +39,23 @@ class GraphedTrainStep:
         self.model, self.optimizer = model, optimizer
         self.images, self.annotations = images.clone(), annotations.clone()      # static input buffers of the graph
         self.clip_fn = clip_fn                  # e.g. lambda: clip_grad_norm_(params, 0.1) for stock optimizers (ClipAdamW clips itself)
-        side = torch.cuda.Stream()
+        # ONE side stream for the warm-up AND the capture; a DDP module built by ddp.wrap_for_capture brings the stream its
+        # AccumulateGrad nodes / bucket hooks already live on
+        side = getattr(model, '_effdet_capture_stream', None) or torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):           # warm-up on a side stream: records the ParamPrep table, sizes the zero pool, and
+        with torch.cuda.stream(side):           # warm-up on the side stream: records the ParamPrep table, sizes the zero pool, and
             for _ in range(max(1, warmup)):     # (re)creates the AccumulateGrad nodes off the legacy default stream, which a
                 self._step()                    # capture must not touch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         _build_pending_tables(model)            # (a table recorded by the warm-up is built here: no allocation / H2D copy under capture)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # Under torch.distributed the process group's watchdog THREAD polls the events of earlier collectives (hipEventQuery); in
+        # the default 'global' capture mode that call from another thread is "not permitted when stream is capturing" and kills
+        # the process (seen with a bare all-reduce capture right behind eager collectives).  'thread_local' confines the
+        # unsafe-call check to the capturing thread.
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode='thread_local' if dist_on else 'global'):
             self.losses = self._step()
         torch.cuda.synchronize()
         self._hyper0 = self._hyper_sig()
@@ -80,10 +88,10 @@ class GraphedTrainStep:
 
 
 class GraphedDetect:
-    """Eval forward + decode (models/efficientdet.py:57-72 for every image of the batch) captured as ONE hipGraph for a fixed
-    batch shape -- the ~270 launches of the network become one graph launch -- followed by the on-device NMS + gather launched
-    eagerly.  (The NMS's radix sort is rocPRIM's: its host side stages launch parameters that do not survive a graph replay --
-    the second replay of a captured rocprim::radix_sort_pairs faults -- so the ~60 NMS launches stay outside the graph.)
+    """Eval forward + decode + on-device NMS + gather (models/efficientdet.py:57-86 for every image of the batch) captured as ONE
+    hipGraph for a fixed batch shape: the ~270 launches of the network and the ~90 of the post-processing become one graph launch.
+    (Round 4: the NMS's sort is an in-tree radix sort whose launch geometry depends on shapes only; the rocPRIM sort it replaces
+    faulted on the second replay of a captured call, which had kept sort + NMS + gather outside the graph.)
 
         det = GraphedDetect(model, images)            # warm-up + capture
         det.images.copy_(batch); results = det()      # -> [(scores[K], labels[K] int64, boxes[K,4]) per image], score-descending
@@ -100,7 +108,10 @@ class GraphedDetect:
         def run():
             with torch.no_grad():
                 cls, reg, anc = model.forward_raw(self.images)
-                return ops.decode_score(anc, reg, cls, H, W)
+                boxes, score, label = ops.decode_score(anc, reg, cls, H, W)
+                idx, count = ops.nms(boxes, score, float(model.threshold), float(model.iou_threshold))
+                s, l, b = ops.gather_dets(boxes, score, label, idx, count)
+                return s, l, b, count
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -110,14 +121,17 @@ class GraphedDetect:
         torch.cuda.synchronize()
         _build_pending_tables(model)
         self.graph = torch.cuda.CUDAGraph()
+        self.thresholds = (float(model.threshold), float(model.iou_threshold))       # baked into the captured launches
         with torch.cuda.graph(self.graph):
-            self.boxes, self.score, self.label = run()
+            self.s, self.l, self.b, self.count = run()
         torch.cuda.synchronize()
 
     def __call__(self):
-        ops, m = self.ops, self.model
+        m = self.model
+        if (float(m.threshold), float(m.iou_threshold)) != self.thresholds:
+            raise RuntimeError('GraphedDetect: model.threshold / iou_threshold changed after capture (they are kernel arguments of the '
+                               'captured NMS); build a new GraphedDetect')
         self.graph.replay()
-        idx, count = ops.nms(self.boxes, self.score, float(m.threshold), float(m.iou_threshold))
-        s, l, b = ops.gather_dets(self.boxes, self.score, self.label, idx, count)
-        counts = count.tolist()                            # the one device->host sync (the reference syncs too)
+        counts = self.count.tolist()                       # the one device->host sync (the reference syncs too)
+        s, l, b = self.s, self.l, self.b
         return [(s[i, :n], l[i, :n], b[i, :n]) for i, n in enumerate(counts)]

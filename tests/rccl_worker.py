@@ -49,12 +49,10 @@ def main():
         m._dc.update(seed=1234, step=0)                      # drop_connect ACTIVE, same Philox stream in every model of this test
         m.train(); m.is_training = True; m.freeze_bn()
         ddp.freeze_dead_parameters(m)
-        if wrap:
-            side = torch.cuda.Stream()                       # (torch's rule for capturing DDP later: construct it on a side stream)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                w = ddp.wrap(m, device_ids=[0])
-            torch.cuda.current_stream().wait_stream(side)
+        if wrap == 'capture':
+            w = ddp.wrap_for_capture(m, device_ids=[0])      # built on the stream GraphedTrainStep will warm up and capture on
+        elif wrap:
+            w = ddp.wrap(m, device_ids=[0])
         else:
             w = m
         opt = ClipAdamW([p for p in m.parameters() if p.requires_grad], lr=lr, max_norm=0.1)
@@ -86,7 +84,7 @@ def main():
     # ---- stage 3: the DDP step captured as a hipGraph with its RCCL all-reduces inside (11 eager iterations first: DDP rebuilds
     #      its buckets after the first one and torch asks for 11 before a capture), replays vs the same number of eager DDP steps
     me, we, oe = build(True)
-    mg, wg, og = build(True)
+    mg, wg, og = build('capture')
     WARM, REPLAYS = 11, 3
     le = [step(we, oe) for _ in range(WARM + REPLAYS)]
     torch.cuda.synchronize()
