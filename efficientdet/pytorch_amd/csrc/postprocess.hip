@@ -480,6 +480,15 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
 //     2/3 of the decode + NMS time.
 constexpr int RS_TILE = 4096;                    // keys per workgroup and pass
 
+// The per-call resets as ONE kernel (three integer regions) instead of hipMemsetAsync nodes, and the final count written by the
+// resolve kernel instead of a hipMemcpyAsync: the captured NMS is then made of kernel nodes only.
+__global__ __launch_bounds__(256) void nms_reset_kernel(int* a, long long na, int* b, long long nb, int* c, long long nc) {
+  const long long n = na + nb + nc;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    if (i < na) a[i] = 0; else if (i < na + nb) b[i - na] = 0; else c[i - na - nb] = 0;
+  }
+}
+
 __global__ __launch_bounds__(256) void nms_keys32_kernel(const float* __restrict__ score, float thr, unsigned* keys, unsigned* vals,
                                                          int* nvalid, int* kept, unsigned* dead, long long A) {
   const int b = blockIdx.y;
@@ -639,7 +648,7 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(const float4* __restric
 
 // grid B, ONE wave per image: the greedy order of the round's survivors from the bit-matrix, == sequential greedy NMS
 __global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const int* __restrict__ nvalid, int* kept, float4* kbox, int* out_idx,
-                                                         long long A, int round, const KeptGrid kg) {
+                                                         int* out_count, long long A, int round, const KeptGrid kg) {
   __shared__ unsigned long long Kw[64];
   const int b = blockIdx.x, lane = threadIdx.x;
   if ((long long)round * q.RND >= nvalid[b]) return;
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const
     }
     kc += __popcll(keep);
   }
-  if (lane == 0) kept[b] = kc;
+  if (lane == 0) { kept[b] = kc; out_count[b] = kc; }
 }
 
 __global__ void gather_dets_kernel(const float* __restrict__ boxes, const float* __restrict__ score, const int* __restrict__ label,
@@ -801,14 +810,17 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   if ((long long)need > workspace_bytes) return EFFDET_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * A;
-  if (hipMemsetAsync(w.nvalid, 0, (size_t)B * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
   static const int v1 = getenv("EFFDET_NMS_V1") ? atoi(getenv("EFFDET_NMS_V1")) : 0;      // A/B switch: 1 = the round-3 path (rocPRIM sort, one workgroup per image and round)
   static const int grid_env = getenv("EFFDET_NMS_GRID") ? atoi(getenv("EFFDET_NMS_GRID")) : 1;       // A/B switch (0 = brute-force cross phase)
   const bool use_grid = grid_env && iou_threshold >= 0.5f;
   KeptGrid kg = w.kg;
+  // resets: nvalid [B], out_count [B] (stays 0 for an image without candidates) and, with the kept-box grid, its cell counters
+  hipLaunchKernelGGL(nms_reset_kernel, dim3(use_grid ? 512 : 1), dim3(256), 0, st, w.nvalid, (long long)B, out_count, (long long)B,
+                     use_grid ? kg.kcount : kg.kover_n, use_grid ? (long long)B * kg.HT + 0 : (long long)B);
+  EFFDET_CHECK_LAUNCH();
   if (use_grid) {
-    if (hipMemsetAsync(kg.kcount, 0, (size_t)B * kg.HT * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
-    if (hipMemsetAsync(kg.kover_n, 0, (size_t)B * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+    hipLaunchKernelGGL(nms_reset_kernel, dim3(1), dim3(256), 0, st, kg.kover_n, (long long)B, (int*)nullptr, 0LL, (int*)nullptr, 0LL);
+    EFFDET_CHECK_LAUNCH();
   } else {
     kg.kcount = nullptr;
   }
@@ -843,10 +855,9 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
         EFFDET_CHECK_LAUNCH();
       }
       hipLaunchKernelGGL(nms_matrix_kernel, dim3(G, B), dim3(256), lds2, st, w.sbox, (const unsigned*)vi, w.nvalid, w.dead, q, A, r, iou_threshold);
-      hipLaunchKernelGGL(nms_resolve_kernel, dim3(B), dim3(64), 0, st, q, w.nvalid, w.kept, w.kbox, out_idx, A, r, kg);
+      hipLaunchKernelGGL(nms_resolve_kernel, dim3(B), dim3(64), 0, st, q, w.nvalid, w.kept, w.kbox, out_idx, out_count, A, r, kg);
       EFFDET_CHECK_LAUNCH();
     }
-    if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
     return EFFDET_OK;
   }
   { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
