@@ -233,8 +233,12 @@ __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __res
                                                              unsigned* dead, long long A, int round, float thr, int RND) {
   const int b = blockIdx.y, lane = threadIdx.x & 63;
   const long long i = (long long)round * RND + blockIdx.x * 4LL + (threadIdx.x >> 6);
-  if (i >= nvalid[b]) return;                                        // wave-uniform
+  if (i >= A) return;                                                // wave-uniform (structural bound: sbox has A slots per image)
+  // three independent loads in flight (round 4: the count used to gate the box load -- two dependent L2 round trips per wave)
+  const int nv = nvalid[b];
   const float4 me = sbox[b * A + i];
+  const int no = kg.kover_n[b];
+  if (i >= nv) return;                                               // wave-uniform
   const float ma = box_area(me);
   if (!box_live(me, ma)) return;
   const float ex = 1.0e-4f * (me.z - me.x) + 1.0e-6f, ey = 1.0e-4f * (me.w - me.y) + 1.0e-6f;
@@ -265,24 +269,42 @@ __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __res
       if (e < min(kg.kcount[hs], KG_CAP)) { const float4 q = kg.kcell[hs * KG_CAP + e]; hit = suppresses(me, ma, q, box_area(q), thr); }
     }
   } else {
-    const int e = lane & 7;
-    for (int c0 = 0; c0 < T; c0 += 8) {
-      const int c = c0 + (lane >> 3);
-      bool h = false;
-      if (c < T) {
-        const int k = (c >= base[1]) + (c >= base[2]) + (c >= base[3]);
-        const int r = c - base[k], nx = nxa[k];
-        const int cy = r / nx, cx = r - cy * nx;
-        const long long hs = (long long)b * kg.HT + cell_hash(l0 + k, cxa[k] + cx, cya[k] + cy, mask);
-        const int n = kg.kcount[hs];
-        const float4 q = kg.kcell[hs * KG_CAP + e];               // (the slot exists whether or not it is filled: no dependent load)
-        h = e < n && suppresses(me, ma, q, box_area(q), thr);
+    // Two dependent steps instead of streaming every probed cell: (1) one lane per CELL reads its 4-byte occupancy count -- the count
+    // table is 4 MB for 32 images and lives in L2, and ~85 % of the probed cells are empty; (2) the lanes then take (non-empty cell,
+    // entry) pairs, 8 cells x 8 entries per pass.  Reading the 128-byte line of EVERY probed cell (round 3: ~50 cells per candidate out
+    // of a 134 MB table) moved ~400 MB per round: the kernel ran at the bandwidth of random 128-byte lines, 73-80 us per round.
+    const int e = lane & 7, slot = lane >> 3;
+    for (int c0 = 0; c0 < T && !hit; c0 += 64) {
+      const int c = c0 + lane;
+      const bool in = c < T;
+      const int cc = in ? c : 0;
+      const int k = (cc >= base[1]) + (cc >= base[2]) + (cc >= base[3]);
+      const int r = cc - base[k], nx = nxa[k] > 0 ? nxa[k] : 1;
+      const int cy = r / nx, cx = r - cy * nx;
+      const long long hs = (long long)b * kg.HT + cell_hash(l0 + k, cxa[k] + cx, cya[k] + cy, mask);
+      const int cnt = kg.kcount[hs];                                   // (lanes past T read cell 0 of their first octave: masked)
+      const int n = in ? min(cnt, KG_CAP) : 0;
+      unsigned long long ne = __ballot(n > 0);                         // non-empty cells of this pass (uniform)
+      const int hs_lo = (int)(hs & 0xffffffffll), hs_hi = (int)(hs >> 32);
+      while (ne) {                                                     // uniform: up to 8 non-empty cells per step
+        int src = 0, found = 0;
+        unsigned long long m = ne;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; ++q8) {
+          const int pos = m ? __builtin_ctzll(m) : 0;
+          if (q8 == slot) { src = pos; found = m != 0ull; }
+          m &= m - 1ull;                                               // (0 & anything stays 0)
+        }
+        ne = m;
+        const int n_s = __shfl(n, src, 64);
+        const long long hs_s = ((long long)__shfl(hs_hi, src, 64) << 32) | (unsigned)__shfl(hs_lo, src, 64);
+        const float4 q = kg.kcell[hs_s * KG_CAP + e];                  // (src = 0 for unused slots: a valid line, masked by found)
+        const bool h = found && e < n_s && suppresses(me, ma, q, box_area(q), thr);
+        if (__ballot(h)) { hit = true; break; }
       }
-      if (__ballot(h)) { hit = true; break; }
     }
   }
   if (!__ballot(hit)) {
-    const int no = kg.kover_n[b];
     for (int e0 = 0; e0 < no; e0 += 64) {
       bool h = false;
       if (e0 + lane < no) { const float4 q = kg.kover[b * A + e0 + lane]; h = suppresses(me, ma, q, box_area(q), thr); }
@@ -478,7 +500,7 @@ __global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict_
 //     kept words AND-ed against the row, one ballot per kept box inside the block), appends the kept boxes in order and files them
 //     into the kept-box grid.  The old per-image round kernel did all of this on ONE CU per image (32 of 256 CUs at B = 32) and was
 //     2/3 of the decode + NMS time.
-constexpr int RS_TILE = 4096;                    // keys per workgroup and pass
+constexpr int RS_TILE = 2048;                    // keys per workgroup and pass
 
 // The per-call resets as ONE kernel (three integer regions) instead of hipMemsetAsync nodes, and the final count written by the
 // resolve kernel instead of a hipMemcpyAsync: the captured NMS is then made of kernel nodes only.
@@ -594,31 +616,48 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(const float4* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float4* tb = (float4*)smem_raw;                                      // [RND + 64] survivor boxes
   float* ta = (float*)(tb + q.RND + 64);                               // [RND + 64] areas
-  __shared__ int wsum[4];
+  __shared__ int wcnt[8][4];
   const int g = blockIdx.x, G = gridDim.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nv = nvalid[b];
   const long long r0 = (long long)round * q.RND;
   if (r0 >= nv) return;
   const unsigned long long lt = (1ull << lane) - 1ull;
   int S = 0;
-  for (int c0 = 0; c0 < q.RND; c0 += 256) {
-    if (r0 + c0 >= nv) break;                                          // uniform
-    const long long i = r0 + c0 + tid;
-    const bool alive = i < nv && dead[b * A + i] == 0u;
-    float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (alive) me = sbox[b * A + i];
-    const unsigned long long bal = __ballot(alive);
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int off = S, tot = 0;
+  for (int h0 = 0; h0 < q.RND; h0 += 2048) {                           // 8 chunks of 256 candidates at a time: their loads share a round trip
+    if (r0 + h0 >= nv) break;                                          // uniform
+    unsigned dd[8]; float4 bx[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { const int c = wsum[w]; if (w < wave) off += c; tot += c; }
-    if (alive) {
-      const int s = off + __popcll(bal & lt);
-      tb[s] = me; ta[s] = (me.z - me.x) * (me.w - me.y);
-      if (g == 0) { q.surv_box[(long long)b * q.RND + s] = me; q.surv_idx[(long long)b * q.RND + s] = sidx[b * A + i]; }
+    for (int u = 0; u < 8; ++u) {
+      const long long i = r0 + h0 + u * 256 + tid;
+      const long long ii = i < A ? i : A - 1;                          // (always a valid slot; masked below)
+      dd[u] = dead[b * A + ii]; bx[u] = sbox[b * A + ii];
     }
-    S += tot;
+    // order-preserving compaction of the 8 chunks with TWO barriers (all ballots, then all offsets) instead of two per chunk
+    unsigned long long bal[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c0 = h0 + u * 256;
+      const long long i = r0 + c0 + tid;
+      const bool alive = c0 < q.RND && i < nv && dd[u] == 0u;
+      bal[u] = __ballot(alive);
+      if (lane == 0) wcnt[u][wave] = __popcll(bal[u]);
+    }
+    __syncthreads();
+    int run = S;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int off = run, tot = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { const int c = wcnt[u][w]; if (w < wave) off += c; tot += c; }
+      if ((bal[u] >> lane) & 1ull) {
+        const int sl = off + __popcll(bal[u] & lt);
+        const float4 me = bx[u];
+        tb[sl] = me; ta[sl] = (me.z - me.x) * (me.w - me.y);
+        if (g == 0) { q.surv_box[(long long)b * q.RND + sl] = me; q.surv_idx[(long long)b * q.RND + sl] = sidx[b * A + r0 + h0 + u * 256 + tid]; }
+      }
+      run += tot;
+    }
+    S = run;
     __syncthreads();
   }
   if (tid < 64) { tb[S + tid] = no_box(); ta[S + tid] = 0.f; }         // columns past S suppress nothing
@@ -646,10 +685,15 @@ __global__ __launch_bounds__(256) void nms_matrix_kernel(const float4* __restric
   }
 }
 
-// grid B, ONE wave per image: the greedy order of the round's survivors from the bit-matrix, == sequential greedy NMS
+// grid B, ONE wave per image: the greedy order of the round's survivors from the bit-matrix, == sequential greedy NMS.
+// Column form: once block blk's kept set K is known, every LATER row r' is dead iff rowbits[blk][r'] & K -- the loads of word column
+// blk (rows blk*64 ..) do not depend on K, so they are issued (8 blocks = 8 independent 512-byte loads at a time, the first carrying
+// the block's own diagonal word) before the block's ballot loop and consumed after it: one L2 round trip per block instead of
+// ceil(blk / 4) + 1.  The kept boxes' grid insertion (an atomic whose result addresses a store) is software-pipelined one block
+// behind for the same reason.
 __global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const int* __restrict__ nvalid, int* kept, float4* kbox, int* out_idx,
                                                          int* out_count, long long A, int round, const KeptGrid kg) {
-  __shared__ unsigned long long Kw[64];
+  __shared__ unsigned long long gonew[64];                              // per row block: rows already suppressed by earlier kept boxes
   const int b = blockIdx.x, lane = threadIdx.x;
   if ((long long)round * q.RND >= nvalid[b]) return;
   const int S = q.surv_n[b];
@@ -657,34 +701,73 @@ __global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const
   const int nw = (S + 63) >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const unsigned long long* rows = q.rowbits + (long long)b * q.NW * q.RND;
+  gonew[lane] = 0ull;
+  __syncthreads();
+  // pending grid insertion of the previous block's kept boxes
+  bool pend = false; long long pend_hs = 0; int pend_pos = 0; float4 pend_box = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int blk = 0; blk < nw; ++blk) {
     const int r = blk * 64 + lane;
-    unsigned long long hit = 0ull;
-    int w = 0;
-    for (; w + 3 < blk; w += 4) {                                      // independent loads: their L2 round trips overlap
-      const unsigned long long m0 = rows[(long long)w * q.RND + r], m1 = rows[(long long)(w + 1) * q.RND + r];
-      const unsigned long long m2 = rows[(long long)(w + 2) * q.RND + r], m3 = rows[(long long)(w + 3) * q.RND + r];
-      hit |= (m0 & Kw[w]) | (m1 & Kw[w + 1]) | (m2 & Kw[w + 2]) | (m3 & Kw[w + 3]);
+    // ---- loads of this block: word column blk for row blocks blk .. blk+7 (first = the diagonal word), the block's boxes ----
+    unsigned long long col[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int rr = min((blk + j) * 64 + lane, q.RND - 1);           // (in range; blocks past nw are ignored below)
+      col[j] = rows[(long long)blk * q.RND + rr];
     }
-    for (; w < blk; ++w) hit |= rows[(long long)w * q.RND + r] & Kw[w];
-    const bool gone = r >= S || hit != 0ull;
-    const unsigned long long diag = r < S ? rows[(long long)blk * q.RND + r] : 0ull;
+    const float4 bx = q.surv_box[(long long)b * q.RND + min(r, q.RND - 1)];
+    const unsigned sidx_r = q.surv_idx[(long long)b * q.RND + min(r, q.RND - 1)];
+    // ---- the previous block's pending grid insertion (its atomic has long returned) ----
+    if (pend) {
+      if (pend_pos < KG_CAP) kg.kcell[pend_hs * KG_CAP + pend_pos] = pend_box;
+      else kg.kover[b * A + atomicAdd(kg.kover_n + b, 1)] = pend_box;
+      pend = false;
+    }
+    const bool gone = r >= S || ((gonew[blk] >> lane) & 1ull);
+    const unsigned long long diag = r < S ? col[0] : 0ull;
     unsigned long long cand = __ballot(!gone), keep = 0ull;
     while (cand) {                                                     // uniform
       const int i = __builtin_ctzll(cand);
       keep |= 1ull << i;
       cand &= ~(__ballot((diag >> i) & 1ull) | (1ull << i));           // a row's bits only name earlier rows: lanes > i
     }
-    if (lane == 0) Kw[blk] = keep;
-    __syncthreads();                                                   // (one wave: orders the LDS write before the next block's reads)
+    // ---- later rows suppressed by this block's kept boxes ----
+#pragma unroll
+    for (int j = 1; j < 8; ++j) {
+      const unsigned long long bal = __ballot((col[j] & keep) != 0ull);
+      if (blk + j < nw && lane == 0) gonew[blk + j] |= bal;
+    }
+    for (int b2 = blk + 8; b2 < nw; b2 += 8) {                         // (more than 8 later blocks: S > 512 past this block)
+      unsigned long long c2[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) c2[j] = rows[(long long)blk * q.RND + min((b2 + j) * 64 + lane, q.RND - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long bal = __ballot((c2[j] & keep) != 0ull);
+        if (b2 + j < nw && lane == 0) gonew[b2 + j] |= bal;
+      }
+    }
+    __syncthreads();                                                   // (one wave: orders lane 0's LDS writes before the next block's reads)
+    // ---- append the kept boxes in order; start their grid insertion ----
     if ((keep >> lane) & 1ull) {
       const int pos = kc + __popcll(keep & lt);
-      const float4 bx = q.surv_box[(long long)b * q.RND + r];
       kbox[b * A + pos] = bx;
-      out_idx[b * A + pos] = (int)q.surv_idx[(long long)b * q.RND + r];
-      if (kg.kcount) kg_insert(kg, b, A, bx);                          // file it for the later rounds' cross phase
+      out_idx[b * A + pos] = (int)sidx_r;
+      if (kg.kcount) {
+        const float a = box_area(bx);
+        if (box_live(bx, a)) {
+          const int lvl = octave(a);
+          const float inv = inv_cell(lvl);
+          pend_hs = (long long)b * kg.HT + cell_hash(lvl, cell_of(0.5f * (bx.x + bx.z), inv), cell_of(0.5f * (bx.y + bx.w), inv), (unsigned)kg.HT - 1u);
+          pend_pos = atomicAdd(kg.kcount + pend_hs, 1);
+          pend_box = bx; pend = true;
+        }
+      }
     }
     kc += __popcll(keep);
+  }
+  if (pend) {
+    if (pend_pos < KG_CAP) kg.kcell[pend_hs * KG_CAP + pend_pos] = pend_box;
+    else kg.kover[b * A + atomicAdd(kg.kover_n + b, 1)] = pend_box;
   }
   if (lane == 0) { kept[b] = kc; out_count[b] = kc; }
 }
@@ -826,7 +909,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   }
   if (!v1) {
     // ---- keys, in-tree stable radix sort per image (4 x 8 bits), boxes in sorted order ----
-    { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
+    { long long gx = (A + 2047) / 2048; if (gx > 64) gx = 64;      // (one atomic per workgroup onto nvalid[b]: 32 counters in ONE cache line serialise at ~8 ns each)
       hipLaunchKernelGGL(nms_keys32_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.k32a, w.vals_in, w.nvalid, w.kept, w.dead, A); }
     EFFDET_CHECK_LAUNCH();
     unsigned *ki = w.k32a, *vi = w.vals_in, *ko = w.k32b, *vo = w.v32b;
