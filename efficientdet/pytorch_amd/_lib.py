@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
-ABI_VERSION = 4                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
+ABI_VERSION = 5                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
@@ -34,7 +34,7 @@ class ConvDesc(C.Structure):
                 ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
                 ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
                 ('ldx', C.c_int), ('ldy', C.c_int), ('act', C.c_int), ('res_mode', C.c_int),
-                ('nseg', C.c_int), ('seg', Seg * MAX_SEG)]
+                ('nseg', C.c_int), ('seg', Seg * MAX_SEG), ('w_image_stride', C.c_longlong)]
 
 
 class WgradDesc(C.Structure):
@@ -81,7 +81,7 @@ _lib = None
 
 # every symbol include/effdet_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_conv2d_wgrad_seg_slabs', 'effdet_conv2d_wgrad_kernel', 'effdet_pack_conv_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_backward_tail', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
+    'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_conv2d_wgrad_seg_slabs', 'effdet_conv2d_wgrad_kernel', 'effdet_pack_conv_weight', 'effdet_scale_pack_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_backward_tail', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',

@@ -51,6 +51,7 @@ struct ConvK {
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   int kord;                    // K walk of the persistent kernel: 0 tap-major, 1 channel-group-major
+  long long w_img_bytes;       // != 0: image b reads its own packed weights at w + b * w_img_bytes (one segment, Ho*Wo % BM == 0)
   SegD seg[EFFDET_MAX_SEG];
 };
 
@@ -134,7 +135,9 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   // thread mapping is the per-thread constant (tid&7) ^ ((tid>>4)&7).  Halo / tail / K-padding lanes pass
   // EFFDET_OOB and the hardware writes zeros.  No staging VGPRs, no ds_write, no per-lane branches.
   constexpr unsigned ES = sizeof(T);
-  const u32x4_t rx = make_srd_raw((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd_raw(p.w, p.w_bytes);
+  // (per-image weights: a tile never straddles images -- Ho*Wo % BM == 0, checked by the host -- so the image is workgroup-uniform)
+  const long long w_img = p.w_img_bytes ? (long long)(m_base / HoWo) * p.w_img_bytes : 0ll;
+  const u32x4_t rx = make_srd_raw((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd_raw((const char*)p.w + w_img, p.w_bytes);
   const unsigned xs_a = lds_addr(xs), ws_a = lds_addr(ws);
   const int kc = (tid & 7) ^ ((tid >> 4) & 7), r0 = tid >> 3;
   const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * 8;     // first tile row of this wave's 1-KiB DMA piece
@@ -1215,6 +1218,11 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     k.kord = ((kv == 1 || (kv == 2 && p->Cout <= 64)) && k.cpt % 8 == 0) ? 1 : 0;
   }
   k.nseg = p->nseg;
+  k.w_img_bytes = p->w_image_stride;
+  if (p->w_image_stride) {
+    // per-image weights: one level whose images are whole numbers of 128-pixel tiles, on the implicit-GEMM kernels only
+    if (p->w_image_stride < 0 || (p->w_image_stride & 15) || p->nseg != 1 || splitfmt || (p->seg[0].Ho * p->seg[0].Wo) % BM) return EFFDET_EUNSUPPORTED;
+  }
   int tiles = 0;
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
   for (int s = 0; s < p->nseg; ++s) {
@@ -1242,7 +1250,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   const long long wb = (long long)p->Cout * k.Kc * 16;
   if (wb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
   k.w_bytes = (unsigned)wb;
-  if (p->dtype == EFFDET_BF16 && !p->bc_scale && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
+  if (p->dtype == EFFDET_BF16 && !p->bc_scale && !p->w_image_stride && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
     long long mtot = 0;
     bool fits = true;        // offsets + the tap walk's SGPR offset must stay below the 2-GiB sentinel
     for (int s = 0; s < p->nseg; ++s) {
@@ -1263,7 +1271,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       }
     }
   }
-  if (pw_eligible(p)) return 20;
+  if (!p->w_image_stride && pw_eligible(p)) return 20;
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
   if (p->dtype == EFFDET_F32_SPLIT) {

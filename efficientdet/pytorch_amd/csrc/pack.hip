@@ -48,6 +48,20 @@ __global__ void pack_w_kernel(const float* __restrict__ w, const float* __restri
   }
 }
 
+// out[b][n][k] = w[n][k] * gate[b][k]: the squeeze-excite gate folded into per-image project weights (effdet_scale_pack_weight)
+template <int MODE>    // 0 fp32, 1 bf16x3 groups, 2 bf16
+__global__ void scale_pack_kernel(const float* __restrict__ w, const float* __restrict__ gate, void* __restrict__ out, long long per_image, int Cin,
+                                  long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long b = i / per_image, r = i - b * per_image;
+    const int k = (int)(r % Cin);
+    const float v = w[r] * gate[b * Cin + k];
+    if constexpr (MODE == 0) ((float*)out)[i] = v;
+    else if constexpr (MODE == 1) store_x3((char*)out + b * per_image * 4, r, Cin, v);
+    else ((bf16_t*)out)[i] = f2bf(v);
+  }
+}
+
 // Batched parameter preparation (effdet_prepare_params): workgroup -> (job, 256-element slice) through two small tables.
 __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_job_t* __restrict__ jobs,
                                                              const int* __restrict__ block_job,
@@ -308,6 +322,20 @@ extern "C" int effdet_to_split(const float* src, void* dst, long long n, effdet_
   if (!src || !dst || n < 4 || (n & 3) || ((unsigned long long)src & 15ull) || ((unsigned long long)dst & 127ull) || (const void*)src == dst) return EFFDET_EINVAL;
   long long g = (n / 4 + 255) / 256; if (g > 8192) g = 8192;
   hipLaunchKernelGGL(to_split_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst, n / 4);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+extern "C" int effdet_scale_pack_weight(const float* w, const float* gate, void* out, int dtype, int B, int Cout, int Cin, effdet_stream_t stream) {
+  if (!w || !gate || !out || B < 1 || Cout < 1 || Cin < 1) return EFFDET_EINVAL;
+  if (dtype == EFFDET_F32_BF16X3 && (Cin % 32)) return EFFDET_EUNSUPPORTED;
+  const long long per = (long long)Cout * Cin, total = per * B;
+  long long g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == EFFDET_F32) hipLaunchKernelGGL(scale_pack_kernel<0>, dim3((unsigned)g), dim3(256), 0, st, w, gate, out, per, Cin, total);
+  else if (dtype == EFFDET_F32_BF16X3) hipLaunchKernelGGL(scale_pack_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, w, gate, out, per, Cin, total);
+  else if (dtype == EFFDET_BF16) hipLaunchKernelGGL(scale_pack_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, w, gate, out, per, Cin, total);
+  else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -541,15 +541,15 @@ __global__ __launch_bounds__(256) void nms_keys32_kernel(const float* __restrict
 
 // hist[b][digit][tile]
 __global__ __launch_bounds__(256) void rs_hist_kernel(const unsigned* __restrict__ keys, unsigned* __restrict__ hist, long long A, int T, int shift) {
-  __shared__ unsigned h[256];
+  __shared__ unsigned digit_counter[256];            // (integer LDS atomics: order-independent)
   const int tile = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  h[tid] = 0u;
+  digit_counter[tid] = 0u;
   __syncthreads();
   const unsigned* k = keys + (long long)b * A;
   const long long i0 = (long long)tile * RS_TILE, i1 = min(A, i0 + RS_TILE);
-  for (long long i = i0 + tid; i < i1; i += 256) atomicAdd(&h[(k[i] >> shift) & 255u], 1u);
+  for (long long i = i0 + tid; i < i1; i += 256) atomicAdd(&digit_counter[(k[i] >> shift) & 255u], 1u);
   __syncthreads();
-  hist[((long long)b * 256 + tid) * T + tile] = h[tid];
+  hist[((long long)b * 256 + tid) * T + tile] = digit_counter[tid];
 }
 
 // per image: exclusive scan over (digit, tile) in digit-major order, in place

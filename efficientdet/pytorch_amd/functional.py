@@ -21,6 +21,7 @@ DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: al
 BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
+GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # inference: the SE gate folded into per-image project weights (no channel_scale pass)
 
 
 def chunk_elems(dtype):
@@ -128,12 +129,20 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
     gate, mid, pool = ops.se_gate_fwd(pool_part, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
-    xs = ops.channel_scale(zd, gate, ACT_SWISH) if z_only else ops.channel_scale(xd, gate)
     s2, t2, i2 = ops.bn_fold(P['bn2.weight'], P['bn2.bias'], P['bn2.running_mean'], P['bn2.running_var'], BN_EPS)
     y = Map.new(B, Ho, Wo, blk.cout, dtype, dev)
-    ops.conv2d(xs, ops.pack_weight(P['project.weight'], dtype), y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1,
-               scale=s2, shift=t2, act=ACT_NONE, rowscale=rowscale if blk.skip else None,
-               res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
+    if not train and GATE_IN_WEIGHTS and (Ho * Wo) % 128 == 0:
+        # inference: y = (W diag(gate_b)) x_d -- the gate rides in per-image project weights (a few MB for the whole batch) instead of
+        # a read + write pass over the expanded map (16 channel_scale launches moved 3.2 GB per D0 B = 32 forward: 5 % of it)
+        xs = None
+        wpb, wstride = ops.scale_pack_weight(P['project.weight'], gate, dtype)
+        ops.conv2d(xd, wpb, y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1, scale=s2, shift=t2, act=ACT_NONE,
+                   res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE, w_image_stride=wstride)
+    else:
+        xs = ops.channel_scale(zd, gate, ACT_SWISH) if z_only else ops.channel_scale(xd, gate)
+        ops.conv2d(xs, ops.pack_weight(P['project.weight'], dtype), y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1,
+                   scale=s2, shift=t2, act=ACT_NONE, rowscale=rowscale if blk.skip else None,
+                   res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
     if train:
         sv.update(xe=xe, s1=s1, i1=i1, wk=wk, xd=xd, zd=zd, pool=pool, gate=gate, mid=mid, xs=xs, s2=s2, i2=i2,
                   inv_hw=inv_hw, dw_in_act=dw_in_act)

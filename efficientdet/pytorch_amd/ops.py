@@ -331,8 +331,23 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
     return out
 
 
+def scale_pack_weight(w_oihw, gate, dtype):
+    """Per-image 1x1 weights W_b = W * diag(gate_b), packed for conv2d(..., w_image_stride=...): -> (packed [B][Cout][Cin], image
+    stride in bytes).  The squeeze-excite gate of an MBConv block applied through the project conv's weights instead of a pass
+    over the activations (models/efficientnet.py:86-95)."""
+    Cout, Cin = w_oihw.shape[0], w_oihw.shape[1]
+    assert w_oihw.shape[2:] == (1, 1) and gate.shape[1] == Cin and gate.dtype == torch.float32 and gate.is_contiguous()
+    B = gate.shape[0]
+    code = _mma_dtype_code(dtype, Cin, Cout)
+    out = torch.empty((B, Cout, Cin), dtype=dtype, device=gate.device)
+    L.check(L.lib().effdet_scale_pack_weight(L.ptr(w_oihw.detach()), L.ptr(gate), L.ptr(out), code, B, Cout, Cin, L.stream_ptr()),
+            'effdet_scale_pack_weight')
+    return out, Cout * Cin * out.element_size()
+
+
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
-           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None):
+           res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None,
+           w_image_stride=0):
     """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
     split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
     is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed)."""
@@ -365,6 +380,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.ldy = x0.ld, y0.ld
     d.act, d.res_mode = act, res_mode
+    d.w_image_stride = int(w_image_stride)       # bytes; image b reads its own packed weights (scale_pack_weight)
     _segs(d, xs, ys, base_x, base_y, isx, isy)
     flops = 2.0 * KH * KW * Cin * Cout * sum(y.B * y.H * y.W for y in ys)
     _timed(_igemm_symbol(x0.dtype, d) if PROFILE is not None else '', flops,

@@ -81,8 +81,17 @@ typedef struct {
   int act, res_mode;
   int nseg;
   effdet_seg_t seg[EFFDET_MAX_SEG];
+  long long w_image_stride; /* 0: one weight tensor for every image.  != 0 (BYTES; one segment, Ho*Wo a multiple of 128, the
+                             * implicit-GEMM kernels only): image b reads its OWN packed weights at w + b * w_image_stride -- how the
+                             * squeeze-excite gate of an MBConv block is applied without a pass over the activations:
+                             * W_b = W * diag(gate_b), packed by effdet_scale_pack_weight (models/efficientnet.py:86-95) */
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
+/* Per-image 1x1 weights for effdet_conv_t.w_image_stride:  out[b][n][k] = w[n][k] * gate[b][k]  in the packed layout of `dtype`
+ * (EFFDET_F32: fp32 [Cout][Cin]; EFFDET_F32_BF16X3: the pre-split [32 hi | 32 lo] groups, Cin % 32 == 0; EFFDET_BF16: bf16).
+ * w: fp32 [Cout][Cin] (an OIHW 1x1 weight as is), gate: fp32 [B][Cin].  Image stride of `out` = Cout * Cin * (2 for bf16, else 4) bytes. */
+int effdet_scale_pack_weight(const float* w, const float* gate, void* out, int dtype, int B, int Cout, int Cin, effdet_stream_t stream);
+
 /* Which kernel effdet_conv2d would launch for this descriptor (no device work): a negative EFFDET_E* code, 0..3 = the
  * implicit-GEMM kernel with a 128 / 64 / 32 / 16-channel block tile, 4..7 = the same tiles in the bf16x3 form
  * (EFFDET_F32_BF16X3), >= 10 = 10 + the persistent big-tile variant. */
@@ -515,7 +524,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 4
+#define EFFDET_ABI_VERSION 5
 int effdet_abi_version(void);
 
 #ifdef __cplusplus

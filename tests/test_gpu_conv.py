@@ -534,3 +534,41 @@ def test_integration_md_stub_runs():
     ref = F.relu(F.conv2d(x.bfloat16().float(), w.bfloat16().float(), b, padding=1))
     assert y.shape == (B, H, W, Cout) and y.dtype == torch.bfloat16
     assert_close(y.float().cpu().permute(0, 3, 1, 2), ref, TOL[torch.bfloat16], 'INTEGRATION.md stub')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('bf16x3', [False, True])
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(3, 16, 16, 96, 24), (2, 16, 8, 480, 80), (4, 16, 16, 1152, 320)])
+def test_conv_per_image_weights_fold_the_se_gate(dtype, bf16x3, B, H, W, Cin, Cout):
+    """effdet_conv_t.w_image_stride + effdet_scale_pack_weight: y_b = BN(W diag(gate_b) x_b) (+ residual) == the reference's
+    project conv applied to x * gate (models/efficientnet.py:86-95), for every tile-width / arithmetic the MBConv blocks reach."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    if bf16x3 and dtype != torch.float32:
+        pytest.skip('bf16x3 is an arithmetic of fp32 storage')
+    old = ops.set_f32_arith('bf16x3' if bf16x3 else 'f32')
+    try:
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, Cin, H, W, generator=g)
+        gate = torch.rand(B, Cin, generator=g)
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+        scale = 0.5 + torch.rand(Cout, generator=g); shift = torch.randn(Cout, generator=g) * 0.3
+        r = torch.randn(B, Cout, H, W, generator=g)
+        q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+        wb = q(w.view(1, Cout, Cin) * gate.view(B, 1, Cin))                       # what the pack stores (bf16 mode: rounded once)
+        ref = torch.einsum('bnk,bkhw->bnhw', wb, q(x)) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + q(r)
+        dev = 'cuda'
+        xm = Map.of(x.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+        rm = Map.of(r.permute(0, 2, 3, 1).contiguous().to(dev, dtype))
+        wpb, stride = ops.scale_pack_weight(w.to(dev), gate.to(dev), dtype)
+        ym = Map.new(B, H, W, Cout, dtype, dev)
+        ops.conv2d(xm, wpb, ym, Cin=Cin, Cout=Cout, KH=1, KW=1, scale=scale.to(dev), shift=shift.to(dev), res=rm, res_mode=ops.RES_ADD,
+                   w_image_stride=stride)
+        torch.cuda.synchronize()
+        assert_close(ym.tensor().float().cpu().permute(0, 3, 1, 2), ref, _tol(dtype), 'per-image weights %s' % ((dtype, bf16x3, B, H, W, Cin, Cout),))
+        # images that are not whole 128-pixel tiles are refused, not mis-addressed
+        x2 = Map.of(torch.zeros(B, 8, 8, Cin, device=dev, dtype=dtype)); y2 = Map.new(B, 8, 8, Cout, dtype, dev)
+        with pytest.raises(RuntimeError):
+            ops.conv2d(x2, wpb, y2, Cin=Cin, Cout=Cout, KH=1, KW=1, w_image_stride=stride)
+    finally:
+        ops.set_f32_arith(old)
