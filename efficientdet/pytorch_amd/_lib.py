@@ -11,7 +11,7 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
-ABI_VERSION = 5                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
+ABI_VERSION = 6                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
@@ -53,7 +53,7 @@ class PrepJob(C.Structure):      # effdet_prep_job_t
 
 class UnpackJob(C.Structure):    # effdet_unpack_job_t
     _fields_ = [(n, C.c_void_p) for n in ('g', 'scale', 'w_oihw', 'dw_oihw', 'wsum', 'dsum_part', 'mean', 'invstd', 'dgamma', 'dbeta',
-                                          'dbias_out', 'slab_scale')] + \
+                                          'dbias_out', 'slab_scale', 'slab_cscale')] + \
                [(n, C.c_int) for n in ('accumulate', 'Cout', 'Cin', 'KH', 'KW', 'Cin_pad', 'nslabs', 'slabs_per_scale')]
 
 

@@ -1115,6 +1115,9 @@ int plan(const effdet_wgrad_t* p, WgradK& k, int& splits, int tile = 128) {
     if (eff > best_eff + 0.02) { best_eff = eff; best_mc = mc; }
   }
   long long mchunk = best_mc;
+  // A/B knob (round 4, profiles/r04_kord_fetch.txt): force the split-K count of the multi-level (head) launches
+  static const int force_sc = getenv("EFFDET_WGRAD_FORCE_SPLITS") ? atoi(getenv("EFFDET_WGRAD_FORCE_SPLITS")) : 0;
+  if (force_sc > 0 && p->nseg > 1) mchunk = chunk_for(force_sc);
   if (p->image_splits) {
     // split boundaries on IMAGE boundaries (q splits per image, slab s belongs to image s / q): the per-image partial gradients
     // M_b = dz_b^T x_b are what the squeeze-excite backward and the drop_connect row scale need (effdet_se_dgate_slabs,

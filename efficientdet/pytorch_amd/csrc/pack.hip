@@ -194,7 +194,7 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
 
 namespace {
 int unpack_job_check(const effdet_unpack_job_t& j) {
-  if (j.slab_scale && (j.slabs_per_scale < 1 || j.nslabs % j.slabs_per_scale)) return EFFDET_EINVAL;
+  if ((j.slab_scale || j.slab_cscale) && (j.slabs_per_scale < 1 || j.nslabs % j.slabs_per_scale)) return EFFDET_EINVAL;
   if (!j.g || !j.dw_oihw || ((j.wsum || j.dgamma) && !j.w_oihw) || j.Cout < 1 || j.Cin < 1 || j.KH < 1 || j.KW < 1 || j.Cin_pad < j.Cin ||
       j.nslabs < 1 || (j.Cin_pad & 3)) return EFFDET_EINVAL;
   if (!j.dgamma && j.dsum_part && !j.dbias_out) return EFFDET_EINVAL;          // partial rows without a consumer

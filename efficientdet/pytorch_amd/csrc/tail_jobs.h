@@ -21,6 +21,16 @@ __device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const i
   // slab_scale (optional): slab sl is multiplied by slab_scale[sl / slabs_per_scale] while summing -- per-image slabs
   // (effdet_wgrad_t.image_splits) x the drop_connect row scale of that image: dW = sum_b rs_b * M_b without a scaled copy of dz
   auto fac = [&](int sl) -> float { return slab_scale ? slab_scale[sl / slabs_per_scale] : 1.0f; };
+  // slab_cscale (optional): additionally a per-INPUT-channel factor of the slab's image -- the squeeze-excite gate when the forward
+  // conv ran on per-image weights W diag(gate_b); 4 consecutive packed elements = 4 channels of one tap
+  const float* __restrict__ cscale = j.slab_cscale;
+  auto fac4 = [&](int sl, int pidx) -> f32x4 {
+    const float f = fac(sl);
+    if (!cscale) return f32x4{f, f, f, f};
+    const int ci = pidx % Cin_pad;
+    const f32x4 g4 = *(const f32x4*)(cscale + (long long)(sl / slabs_per_scale) * Cin_pad + ci);
+    return g4 * f;
+  };
   const int taps = KH * KW, np = taps * Cin_pad, n = Cin * taps;
   const float s = scale ? scale[co] : 1.0f;
   // sum_m dz[m][co]: the weight-gradient launch left one partial per split-K slab ([nslabs][Cout]); wave 0 adds them in a fixed
@@ -55,10 +65,10 @@ __device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const i
     if (slice < SL) {
       int sl = slice;
       for (; sl + SL < nslabs; sl += 2 * SL) {
-        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
-        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride) * fac(sl + SL);
+        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac4(sl, grp * 4);
+        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride) * fac4(sl + SL, grp * 4);
       }
-      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac(sl);
+      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac4(sl, grp * 4);
     }
     sred[threadIdx.x] = a0 + a1;
     __syncthreads();
@@ -72,15 +82,15 @@ __device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const i
   // slab loop unrolled x4 so the loads of different slabs are in flight together
   for (int q4 = by * 256 + threadIdx.x; q4 * 4 < np; q4 += gy * 256) {
     const int pidx = q4 * 4;
-    f32x4 a0 = *(const f32x4*)(grow + pidx) * fac(0), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    f32x4 a0 = *(const f32x4*)(grow + pidx) * fac4(0, pidx), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
     int sl = 1;
     for (; sl + 3 < nslabs; sl += 4) {
-      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
-      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride) * fac(sl + 1);
-      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride) * fac(sl + 2);
-      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride) * fac(sl + 3);
+      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac4(sl, pidx);
+      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride) * fac4(sl + 1, pidx);
+      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride) * fac4(sl + 2, pidx);
+      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride) * fac4(sl + 3, pidx);
     }
-    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac(sl);
+    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac4(sl, pidx);
     emit(pidx, (a0 + a1) + (a2 + a3));
   }
   }

@@ -21,7 +21,8 @@ DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: al
 BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
-GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # inference: the SE gate folded into per-image project weights (no channel_scale pass)
+GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
+GATE_IN_WEIGHTS_TRAIN = os.environ.get('EFFDET_GATE_IN_WEIGHTS_TRAIN', '1') == '1'   # ... in training too (fp32 storage, fused SE backward)
 
 
 def chunk_elems(dtype):
@@ -123,7 +124,12 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     wk = ops.dw_pack_weight(P['dw.weight'])
     # training stores the depthwise pre-activation ONLY (the step is bound by HBM write bandwidth, ~2.5 TB/s measured):
     # the gate multiply and the backward of the gate recompute Swish from it
-    z_only = train and not DW_SAVE_Y
+    # gate in per-image project weights (round 4): inference always; training when the fused SE backward applies (it takes the
+    # project conv's weight gradient per image, which is where the gate re-enters) -- the depthwise conv then stores BOTH its
+    # pre-activation (backward) and its Swish output (the project conv's operand) and channel_scale's read + write pass is gone
+    giw = GATE_IN_WEIGHTS and (Ho * Wo) % 128 == 0 and (not train or (
+        GATE_IN_WEIGHTS_TRAIN and SE_FUSED and dtype == torch.float32 and (Ho * Wo) % 32 == 0))
+    z_only = train and not DW_SAVE_Y and not giw
     xd, zd, pool_part = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=True,
                                        save_y=not z_only, in_act=dw_in_act)
     inv_hw = 1.0 / (Ho * Wo)
@@ -131,12 +137,13 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     gate, mid, pool = ops.se_gate_fwd(pool_part, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)
     s2, t2, i2 = ops.bn_fold(P['bn2.weight'], P['bn2.bias'], P['bn2.running_mean'], P['bn2.running_var'], BN_EPS)
     y = Map.new(B, Ho, Wo, blk.cout, dtype, dev)
-    if not train and GATE_IN_WEIGHTS and (Ho * Wo) % 128 == 0:
-        # inference: y = (W diag(gate_b)) x_d -- the gate rides in per-image project weights (a few MB for the whole batch) instead of
+    if giw:
+        # y = (W diag(gate_b)) x_d -- the gate rides in per-image project weights (a few MB for the whole batch) instead of
         # a read + write pass over the expanded map (16 channel_scale launches moved 3.2 GB per D0 B = 32 forward: 5 % of it)
         xs = None
         wpb, wstride = ops.scale_pack_weight(P['project.weight'], gate, dtype)
         ops.conv2d(xd, wpb, y, Cin=blk.cexp, Cout=blk.cout, KH=1, KW=1, scale=s2, shift=t2, act=ACT_NONE,
+                   rowscale=rowscale if blk.skip else None,
                    res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE, w_image_stride=wstride)
     else:
         xs = ops.channel_scale(zd, gate, ACT_SWISH) if z_only else ops.channel_scale(xd, gate)
@@ -145,7 +152,7 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
                    res=x if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
     if train:
         sv.update(xe=xe, s1=s1, i1=i1, wk=wk, xd=xd, zd=zd, pool=pool, gate=gate, mid=mid, xs=xs, s2=s2, i2=i2,
-                  inv_hw=inv_hw, dw_in_act=dw_in_act)
+                  inv_hw=inv_hw, dw_in_act=dw_in_act, giw=giw)
     return y, sv
 
 
@@ -161,18 +168,23 @@ def mbconv_bwd(sv, dy):
     wp = P['project.weight']
     w1 = P['se_reduce.weight'].view(Cs, Ce); w2 = P['se_expand.weight'].view(Ce, Cs)
     hw = dy.H * dy.W
+    giw = sv.get('giw', False)
+    if giw and not (SE_FUSED and hw % 32 == 0):       # (the switch was flipped between forward and backward: tests do that)
+        sv['xs'] = ops.channel_scale(sv['xd'], sv['gate']); giw = False
     if SE_FUSED and hw % (64 if dtype == torch.bfloat16 else 32) == 0:
         # Fused form (no pass over the activations for the gate gradient, dxs never materialised):
         #   per-image partial weight gradients M_b = dy_b^T xs_b (split-K on image boundaries)
         #   dW = sum_b rs_b M_b (slab scale in the unpack);  (dgate*gate)[b][c] = rs_b sum_n W'[n][c] M_b[n][c]
         #   dz_d = (rs_b (dy W') gate[b][c] + dpool[b][c]) * swish'(z_d)   in the epilogue of the project conv's data gradient
         # -- se_dgate (2 tensor reads), se_bwd_apply (2 reads + 1 write) and the drop_connect act_bwd become one extra read of z_d.
-        G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dy, Cin=Ce, Cout=Co, KH=1, KW=1, image_splits=True)
+        # (giw: the forward ran on W diag(gate_b) and x_d; the slabs are then M'_b = dy_b^T x_d,b -- the gate re-enters as a per-(image,
+        #  channel) factor of the unpack, and sum_n W'[n][c] M'_b[n][c] is d(loss)/d(gate) itself, not yet times the gate)
+        G2, dsum2 = ops.conv2d_wgrad(sv['xd'] if giw else sv['xs'], dy, Cin=Ce, Cout=Co, KH=1, KW=1, image_splits=True)
         g['project.weight'], g['bn2.weight'], g['bn2.bias'] = ops.unpack_wgrad_bn(G2, wp, sv['s2'], dsum2, P['bn2.running_mean'], sv['i2'],
-                                                                                 slab_scale=rs)
+                                                                                 slab_scale=rs, slab_cscale=sv['gate'] if giw else None)
         dgg = ops.se_dgate_from_wgrad(G2, wp, sv['s2'], rs, B)
         dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgg, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
-                                                    sv['inv_hw'], times_gate=True)
+                                                    sv['inv_hw'], times_gate=not giw)
         dzd = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
         ops.conv2d(dy, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dzd, Cin=Co, Cout=Ce, KH=1, KW=1, rowscale=rs,
                    bc_scale=sv['gate'], bc_shift=dpool, res=sv['zd'], res_mode=ops.RES_SWISH_GRAD)

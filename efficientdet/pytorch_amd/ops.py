@@ -510,13 +510,18 @@ class unpack_batch:
         return False
 
 
-def _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, **ptrs):
+def _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, slab_cscale=None, **ptrs):
     j = L.UnpackJob()
     j.g, j.dw_oihw, j.slab_scale = g.data_ptr(), dw.data_ptr(), (slab_scale.data_ptr() if slab_scale is not None else None)
     for k, t in ptrs.items():
         setattr(j, k, t.data_ptr() if t is not None else None)
     j.Cout, j.Cin, j.KH, j.KW, j.Cin_pad, j.nslabs = Cout, Cin, KH, KW, (Cin if cin_pad is None else cin_pad), nslabs
     j.slabs_per_scale = nslabs // slab_scale.numel() if slab_scale is not None else 1
+    if slab_cscale is not None:      # [images][Cin_pad] per-input-channel factors (the SE gate): slab s belongs to image s // slabs_per_scale
+        assert slab_cscale.dtype == torch.float32 and slab_cscale.is_contiguous() and slab_cscale.shape[1] == j.Cin_pad
+        assert nslabs % slab_cscale.shape[0] == 0 and (slab_scale is None or slab_scale.numel() == slab_cscale.shape[0])
+        j.slab_cscale = slab_cscale.data_ptr()
+        j.slabs_per_scale = nslabs // slab_cscale.shape[0]
     return j
 
 
@@ -544,9 +549,10 @@ def unpack_wgrad(g, dw_oihw, scale=None, w_oihw=None, wsum=None, accumulate=Fals
     return db
 
 
-def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None, slab_scale=None):
+def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None, slab_scale=None, slab_cscale=None):
     """unpack_wgrad + bn_param_grad in one launch -> (dw, dgamma, dbeta); dsum_part: the [splits][Cout] rows of conv2d_wgrad.
-    slab_scale [B] (per-image slabs of conv2d_wgrad(image_splits=True)): slab s is multiplied by slab_scale[s // (splits / B)]."""
+    slab_scale [B] (per-image slabs of conv2d_wgrad(image_splits=True)): slab s is multiplied by slab_scale[s // (splits / B)].
+    slab_cscale [B][Cin]: and, per input channel, by the image's squeeze-excite gate (forward on per-image weights)."""
     Cout, Cin, KH, KW = w_oihw.shape
     nslabs = g.shape[0] if g.dim() == 4 else 1
     if dsum_part.dim() == 1:
@@ -556,9 +562,9 @@ def unpack_wgrad_bn(g, w_oihw, scale, dsum_part, mean, invstd, cin_pad=None, sla
     dw = torch.empty_like(w_oihw)
     dgb = torch.empty((2, Cout), dtype=torch.float32, device=dw.device)
     wd = w_oihw.detach()
-    job = _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, scale=scale, w_oihw=wd, dsum_part=dsum_part, mean=mean,
+    job = _unpack_job(g, dw, Cout, Cin, KH, KW, cin_pad, nslabs, slab_scale, slab_cscale, scale=scale, w_oihw=wd, dsum_part=dsum_part, mean=mean,
                       invstd=invstd, dgamma=dgb[0], dbeta=dgb[1])
-    _unpack_submit(job, g, dw, scale, wd, dsum_part, mean, invstd, dgb, slab_scale)
+    _unpack_submit(job, g, dw, scale, wd, dsum_part, mean, invstd, dgb, slab_scale, slab_cscale)
     return dw, dgb[0], dgb[1]
 
 

@@ -183,6 +183,10 @@ typedef struct {
   const float* g; const float* scale; const float* w_oihw; float* dw_oihw; float* wsum;
   const float* dsum_part; const float* mean; const float* invstd; float* dgamma; float* dbeta; float* dbias_out;
   const float* slab_scale;
+  const float* slab_cscale; /* optional [nslabs / slabs_per_scale][Cin_pad]: slab s is ALSO multiplied, per input channel c, by
+                             * slab_cscale[s / slabs_per_scale][c] -- the squeeze-excite gate of the image when the project conv ran on
+                             * per-image weights W diag(gate_b) (effdet_conv_t.w_image_stride): its weight gradient is taken against the
+                             * UN-gated activations, M'_b = dy_b^T x_b, and dW = sum_b rs[b] * M'_b * diag(gate_b) */
   int accumulate, Cout, Cin, KH, KW, Cin_pad, nslabs, slabs_per_scale;
 } effdet_unpack_job_t;
 int effdet_unpack_conv_wgrad_batch(const effdet_unpack_job_t* jobs, int njobs, effdet_stream_t stream);
@@ -524,7 +528,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 5
+#define EFFDET_ABI_VERSION 6
 int effdet_abi_version(void);
 
 #ifdef __cplusplus
