@@ -22,7 +22,10 @@ BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     #
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
-GATE_IN_WEIGHTS_TRAIN = os.environ.get('EFFDET_GATE_IN_WEIGHTS_TRAIN', '1') == '1'   # ... in training too (fp32 storage, fused SE backward)
+# ... in training too (fp32 storage, fused SE backward): built, tested, and OFF -- the depthwise forward must then store its Swish
+# output next to the pre-activation, which costs what channel_scale's pass did: 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on)
+# per D0 B = 32 step in one GPU call (round 4)
+GATE_IN_WEIGHTS_TRAIN = os.environ.get('EFFDET_GATE_IN_WEIGHTS_TRAIN', '0') == '1'
 
 
 def chunk_elems(dtype):
