@@ -232,6 +232,184 @@ __global__ __launch_bounds__(256) void dw_fwd_lds_kernel(const DwK p) {
   }
 }
 
+
+// ---------------------------------------------------------------- fused expand (1x1 + BN + Swish) -> depthwise forward (inference)
+// models/efficientnet.py:82-88 in ONE kernel for the high-resolution MBConv blocks (Cin 16..40 -> 6 x Cin channels): the 6x-expanded
+// map -- 805 MB for block 1 of D0 at B = 32 -- is never written to or read from HBM.  Same tile walk, tap loop, BN + Swish epilogue and
+// squeeze-excite partial sums as dw_fwd_lds_kernel (fp32, slabs of 32 expanded channels, one tile buffer); what changes is how the
+// halo'd tile of the slab gets into LDS: the block INPUT tile [pixel slot][Cin] is staged by DMA (lane-linear pieces of 16 channel
+// chunks, zeros outside the image) and the slab's expanded tile is computed from it with exact v_mfma_f32_16x16x4_f32 --
+// A = the slab's 32 x Cin expand weights (fragments live in registers for the whole workgroup), B = 16 pixel slots, D rows =
+// channels, so a lane holds 4 consecutive channels of one pixel = one 16-byte chunk of the tile layout the taps read.  BN0 + Swish in
+// the MFMA epilogue; slots OUTSIDE the image must be ZERO (TF-"same" pads the depthwise INPUT, i.e. the expand OUTPUT: the expand of
+// a padding pixel would be swish(shift), not 0).  The input tile is re-read once per channel slab (Cexp / 32 times a 6x smaller
+// tensor): half the expanded tensor's read and all of its write are saved.  The next tile's input DMA flies under the taps.
+struct DwFuseK { DwK d; const float* xin; const float* we; const float* s0; const float* t0; int Cin; unsigned xin_bytes; };
+
+template <int K, int S, int KS>       // KS = Cin / 4 MFMA k-steps
+__global__ __launch_bounds__(256) void dw_fwd_fused_kernel(const DwFuseK pf) {
+  typedef DwTile<K, S> TL;
+  constexpr int CQ = 8, CE = 4, PX = 64 / CQ, NPIECE = TL::npiece(PX), NSLOT = NPIECE * PX, TILE = NPIECE * 64;
+  constexpr int CIN = KS * 4, NPT = (NSLOT + 15) / 16;
+  constexpr int NXP = ((NPT * 16) * KS + 63) / 64;                    // 1-KiB DMA pieces of the input tile (slots padded to whole px-tiles)
+  const DwK& p = pf.d;
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];
+  uint4* xt = sm;                                                     // [NSLOT][CQ] chunks: the slab's expanded tile
+  float* wt = (float*)(sm + TILE);                                    // [K*K][32] depthwise weights of the slab
+  float* wet = wt + K * K * 32;                                       // [32][CIN] expand weights of the slab
+  float* xin_t = wet + 32 * CIN;                                      // [NXP * 64 / KS...][CIN] input tile, lane-linear DMA image
+  float (*red)[8 * 8] = (float (*)[8 * 8])sm;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.Wo + TL::TW - 1) / TL::TW, tiles_y = (p.Ho + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
+  const int groups = (tpi + p.ppt - 1) / p.ppt;
+  const int2 bs = slab_block(p);
+  const int b = bs.x / groups, t0 = (bs.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = bs.y * CQ;
+  const u32x4_t rx = make_srd_raw(pf.xin, pf.xin_bytes);
+  const unsigned img_off = (unsigned)((long long)b * p.H * p.W * CIN * 4);
+  const unsigned xin_a = lds_addr(xin_t);
+  auto slot_hw = [&](int q, int hi_org, int wi_org, int& hi, int& wi) -> bool {      // LDS pixel slot -> image pixel; false = padding
+    const int ih = q / TL::IWP, r = q - ih * TL::IWP;
+    int iw;
+    if (S == 1) iw = r; else iw = (r < TL::IWH) ? 2 * r : 2 * (r - TL::IWH) + 1;
+    hi = hi_org + ih; wi = wi_org + iw;
+    return q < TL::NPIX && iw < TL::IW && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+  };
+  auto stage_x = [&](int tile) {
+    const int ty = tile / tiles_x, tx_ = tile - ty * tiles_x;
+    const int hi_org = ty * TL::TH * S - p.pad_t, wi_org = tx_ * TL::TW * S - p.pad_l;
+    for (int piece = wave; piece < NXP; piece += 4) {
+      const int e = piece * 64 + lane, q = e / KS, cc = e - q * KS;  // chunk e of the tile = (pixel slot, 4-channel chunk)
+      int hi, wi;
+      const bool ok = slot_hw(q, hi_org, wi_org, hi, wi);
+      dma16_async(rx, (unsigned)__builtin_amdgcn_readfirstlane((int)(xin_a + (unsigned)piece * 1024u)),
+                  ok ? img_off + (unsigned)((hi * p.W + wi) * CIN + cc * 4) * 4u : EFFDET_OOB);
+    }
+  };
+  stage_x(t0);
+  for (int i = tid; i < K * K * 32; i += 256) {
+    const int t = i / 32, c = chunk0 * CE + (i - t * 32);
+    wt[i] = c < p.C ? p.w[t * p.C + c] : 0.f;
+  }
+  for (int i = tid; i < 32 * CIN; i += 256) {
+    const int r = i / CIN, c = chunk0 * CE + r;
+    wet[i] = c < p.C ? pf.we[(long long)c * CIN + (i - r * CIN)] : 0.f;
+  }
+  const int l15 = lane & 15, lk = lane >> 4;
+  // BN0 affine of this lane's 2 x 4 expanded channels (channel tile ct, rows 4 * lk + r)
+  float s0v[2][4], t0v[2][4];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = chunk0 * CE + ct * 16 + 4 * lk + r;
+      s0v[ct][r] = c < p.C ? pf.s0[c] : 0.f; t0v[ct][r] = c < p.C ? pf.t0[c] : 0.f;
+    }
+  // ---- thread = (chunk cq, pixel slot ps) of the tap loop, as in dw_fwd_lds_kernel ----
+  constexpr int NPS = 256 / CQ, NOUT = TL::TH * TL::TW / NPS;
+  const int cq = tid % CQ, ps = tid / CQ;
+  const int c0 = (chunk0 + cq) * CE;
+  const bool cok = chunk0 + cq < p.nch;
+  float sc[CE], sh[CE], psum[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) { sc[e] = 1.f; sh[e] = 0.f; psum[e] = 0.f; }
+  if (cok) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { if (p.scale) sc[e] = p.scale[c0 + e]; if (p.shift) sh[e] = p.shift[c0 + e]; }
+  }
+  const int HoWo = p.Ho * p.Wo;
+  dma_wait_all();
+  __syncthreads();                                                    // input tile, wt, wet are in LDS for every wave
+  float afr[2][KS];                                                   // A fragments: lane (row i = l15, k = lk) of the two 16-channel tiles
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) afr[ct][ks] = wet[(ct * 16 + l15) * CIN + ks * 4 + lk];
+  for (int tile = t0; tile < t1; ++tile) {
+    const int ty = tile / tiles_x, tx_ = tile - ty * tiles_x;
+    const int hi_org = ty * TL::TH * S - p.pad_t, wi_org = tx_ * TL::TW * S - p.pad_l;
+    // ---- expand: xt[slot][32 ch] = swish(bn0(We x[slot])) for the in-image slots, 0 for the padding ----
+    for (int pt = wave; pt < NPT; pt += 4) {
+      const int slot = pt * 16 + l15;
+      float bfr[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bfr[ks] = xin_t[slot * CIN + ks * 4 + lk];
+      f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[0][ks], bfr[ks], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[1][ks], bfr[ks], a1, 0, 0, 0);
+      }
+      int hi, wi;
+      const bool in = slot_hw(slot, hi_org, wi_org, hi, wi);
+      float v0[4], v1[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v0[r] = in ? swishf_(a0[r] * s0v[0][r] + t0v[0][r]) : 0.f;
+        v1[r] = in ? swishf_(a1[r] * s0v[1][r] + t0v[1][r]) : 0.f;
+      }
+      if (slot < NSLOT) { xt[slot * CQ + lk] = Chunk<float>::pack(v0); xt[slot * CQ + 4 + lk] = Chunk<float>::pack(v1); }
+    }
+    __syncthreads();                                                  // the expanded tile is complete; every wave is done with xin_t
+    if (tile + 1 < t1) stage_x(tile + 1);                             // lands under the taps
+    float acc[NOUT][CE];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+    for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const f32x4 wv = *(const f32x4*)(wt + (kh * K + kw) * 32 + cq * CE);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          const int op = ps + NPS * o, oh = op / TL::TW, ow = op - oh * TL::TW;
+          float xv[CE];
+          Chunk<float>::unpack(xt[TL::slot(oh * S + kh, ow * S + kw) * CQ + cq], xv);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) acc[o][e] = fmaf(xv[e], wv[e], acc[o][e]);
+        }
+      }
+    }
+    const int oh0 = ty * TL::TH, ow0 = tx_ * TL::TW;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const int op = ps + NPS * o, oh = oh0 + op / TL::TW, ow = ow0 + op % TL::TW;
+      float yv[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) yv[e] = swishf_(acc[o][e] * sc[e] + sh[e]);
+      if (!cok || oh >= p.Ho || ow >= p.Wo) continue;
+      const long long off = ((long long)b * HoWo + (long long)oh * p.Wo + ow) * p.C + c0;
+      *(uint4*)((float*)p.y + off) = Chunk<float>::pack(yv);
+#pragma unroll
+      for (int e = 0; e < CE; ++e) psum[e] += yv[e];
+    }
+    dma_wait_all();
+    __syncthreads();                                                  // the next input tile has landed; every wave is done with xt
+  }
+  if (p.pool) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float v = psum[e];
+#pragma unroll
+      for (int o = 32; o >= CQ; o >>= 1) v += __shfl_xor(v, o, 64);
+      psum[e] = v;
+    }
+    if (lane < CQ) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) red[wave][lane * 8 + e] = psum[e];
+    }
+    __syncthreads();
+    if (tid < CQ * CE) {
+      const int l = tid / CE, e = tid - l * CE;
+      const float v = red[0][l * 8 + e] + red[1][l * 8 + e] + red[2][l * 8 + e] + red[3][l * 8 + e];
+      const int cch = (chunk0 + l) * CE + e;
+      if (cch < p.C) p.pool[((long long)b * groups + (bs.x - b * groups)) * p.C + cch] = v;
+    }
+  }
+}
+
 // Data gradient.  Output tile = 16 x 16 pixels of dx (input resolution); staged tile = the dz pixels they touch.
 template <int K, int S> struct DgTile {
   static constexpr int TH = 16, TW = (S == 1) ? 8 : 16;                       // 4 / 8 (= 4 classes x 2) outputs per thread
@@ -771,6 +949,63 @@ extern "C" int effdet_dwconv_fwd(const void* x, const float* w, const float* sca
   if (!extent(a, (long long)B * H * W * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_fwd_lds, dtype, k, stride, a, st);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+
+namespace {
+// tile groups per image / tiles per workgroup of the fused expand -> depthwise forward (always 32-channel slabs)
+inline int fused_tiles(int B, int Cexp, int stride, int Ho, int Wo, int& ppt) {
+  const int th = stride == 1 ? 16 : 8, tw = 8;
+  const int nslab = (Cexp / 4 + 7) / 8;
+  const int tpi = ((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
+  ppt = tiles_per_wg((long long)tpi * B * nslab);
+  if (ppt > tpi) ppt = tpi;
+  return (tpi + ppt - 1) / ppt;
+}
+template <int K, int S, int KS>
+int launch_fused(const DwFuseK& f0, hipStream_t st) {
+  typedef DwTile<K, S> TL;
+  DwFuseK f = f0;
+  constexpr int NPIECE = TL::npiece(8), NSLOT = NPIECE * 8, NPT = (NSLOT + 15) / 16, NXP = ((NPT * 16) * KS + 63) / 64;
+  const size_t lds = (size_t)NPIECE * 1024 + (size_t)K * K * 32 * 4 + (size_t)32 * KS * 16 + (size_t)NXP * 1024;
+  (void)fused_tiles(f.d.B, f.d.C, S, f.d.Ho, f.d.Wo, f.d.ppt);
+  f.d.nbuf = 1;
+  const int tpi = ((f.d.Ho + TL::TH - 1) / TL::TH) * ((f.d.Wo + TL::TW - 1) / TL::TW), nslab = (f.d.nch + 7) / 8;
+  dim3 grid = slab_grid(f.d, f.d.B * ((tpi + f.d.ppt - 1) / f.d.ppt), nslab);
+  EFFDET_SET_MAX_LDS((dw_fwd_fused_kernel<K, S, KS>), lds);
+  hipLaunchKernelGGL((dw_fwd_fused_kernel<K, S, KS>), grid, dim3(256), lds, st, f);
+  return EFFDET_OK;
+}
+}  // namespace
+
+extern "C" int effdet_mbconv_expand_dw_pool_groups(int B, int Cexp, int stride, int Ho, int Wo) {
+  if (B < 1 || Cexp < 4 || (Cexp & 3) || (stride != 1 && stride != 2)) return EFFDET_EINVAL;
+  int ppt;
+  return fused_tiles(B, Cexp, stride, Ho, Wo, ppt);
+}
+
+extern "C" int effdet_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                                           const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                           int B, int H, int W, int Cin, int Cexp, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                           effdet_stream_t stream) {
+  if (!x || !w_expand || !scale0 || !shift0 || !w_dw || !y) return EFFDET_EINVAL;
+  if (Cin != 16 && Cin != 24 && Cin != 32 && Cin != 40) return EFFDET_EUNSUPPORTED;      // MFMA k-steps are compile-time
+  DwFuseK f{}; dim3 grid;
+  int rc = fill(f.d, EFFDET_F32, B, H, W, Cexp, k, stride, pad_t, pad_l, Ho, Wo, 4, Ho * Wo, grid);
+  if (rc) return rc;
+  f.d.w = w_dw; f.d.scale = scale1; f.d.shift = shift1; f.d.y = y; f.d.pool = pool;
+  f.xin = x; f.we = w_expand; f.s0 = scale0; f.t0 = shift0; f.Cin = Cin;
+  const long long xb = (long long)B * H * W * Cin * 4;
+  if (xb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
+  f.xin_bytes = (unsigned)xb;
+  hipStream_t st = (hipStream_t)stream;
+#define FUSED_KS(KSV) do { \
+    if (k == 3) { if (stride == 1) launch_fused<3, 1, KSV>(f, st); else launch_fused<3, 2, KSV>(f, st); } \
+    else { if (stride == 1) launch_fused<5, 1, KSV>(f, st); else launch_fused<5, 2, KSV>(f, st); } } while (0)
+  switch (Cin) { case 16: FUSED_KS(4); break; case 24: FUSED_KS(6); break; case 32: FUSED_KS(8); break; default: FUSED_KS(10); break; }
+#undef FUSED_KS
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

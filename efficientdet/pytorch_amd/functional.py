@@ -21,6 +21,7 @@ DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: al
 BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
+FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage, Cin <= 40: expand conv inside the depthwise kernel
 GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
 # ... in training too (fp32 storage, fused SE backward): built, tested, and OFF -- the depthwise forward must then store its Swish
 # output next to the pre-activation, which costs what channel_scale's pass did: 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on)
@@ -105,7 +106,12 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale, 'xpre': xpre}      # xpre: see mbconv_bwd (expand == 1 blocks)
     dw_in_act = ACT_NONE
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
-    if blk.expand != 1:
+    fuse = (not train and FUSE_EXPAND_DW and blk.expand != 1 and dtype == torch.float32 and blk.cin in (16, 24, 32, 40)
+            and x.ld == x.C and x.off == 0)
+    if fuse:
+        s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
+        xe = None            # (the 6x-expanded map exists only tile by tile, in LDS: see ops.expand_dw_fwd)
+    elif blk.expand != 1:
         s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
         if train and EXPAND_Z_ONLY and Ho * Wo > 64:      # (<= 8x8 maps: the direct weight-gradient kernel would Swish every tap load)
             # training stores ONE tensor for the expand conv, its pre-activation: the depthwise forward / weight-gradient kernels
@@ -133,8 +139,12 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     giw = GATE_IN_WEIGHTS and (Ho * Wo) % 128 == 0 and (not train or (
         GATE_IN_WEIGHTS_TRAIN and SE_FUSED and dtype == torch.float32 and (Ho * Wo) % 32 == 0))
     z_only = train and not DW_SAVE_Y and not giw
-    xd, zd, pool_part = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=True,
-                                       save_y=not z_only, in_act=dw_in_act)
+    if fuse:
+        xd, pool_part = ops.expand_dw_fwd(x, P['expand.weight'], s0, t0, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo)
+        zd = None
+    else:
+        xd, zd, pool_part = ops.dwconv_fwd(xe, wk, s1, t1, blk.k, blk.stride, blk.pad[0], blk.pad[0], Ho, Wo, save_z=train, pool=True,
+                                           save_y=not z_only, in_act=dw_in_act)
     inv_hw = 1.0 / (Ho * Wo)
     w1 = P['se_reduce.weight'].view(blk.cse, blk.cexp); w2 = P['se_expand.weight'].view(blk.cexp, blk.cse)
     gate, mid, pool = ops.se_gate_fwd(pool_part, w1, P['se_reduce.bias'], w2, P['se_expand.bias'], inv_hw, save_mid=train)

@@ -700,6 +700,24 @@ def dwconv_fwd(x, w_kkc, scale, shift, k, stride, pad_t, pad_l, Ho, Wo, save_z=F
     return y, z, pool
 
 
+def expand_dw_fwd(x, w_expand, scale0, shift0, w_kkc, scale1, shift1, k, stride, pad_t, pad_l, Ho, Wo):
+    """Inference: expand 1x1 + BN + Swish -> depthwise k x k + BN + Swish in ONE kernel (the expanded map stays in LDS).
+    x: fp32 Map [B,H,W,Cin], Cin in {16, 24, 32, 40}; w_expand: the OIHW 1x1 weight.  -> (y Map [B,Ho,Wo,Cexp], pool_part [B][G][Cexp])."""
+    Cexp, Cin = w_expand.shape[0], w_expand.shape[1]
+    assert x.dtype == torch.float32 and x.C == Cin
+    G = int(L.lib().effdet_mbconv_expand_dw_pool_groups(x.B, Cexp, stride, Ho, Wo))
+    if G < 1:
+        raise RuntimeError('effdet_mbconv_expand_dw_pool_groups: unsupported geometry')
+    pool = torch.empty((x.B, G, Cexp), dtype=torch.float32, device=x.t.device)
+    y = Map.new(x.B, Ho, Wo, Cexp, torch.float32, x.t.device)
+    nbytes = 4 * x.B * (x.H * x.W * Cin * ((Cexp + 31) // 32) + Ho * Wo * Cexp)
+    _timed('dw_fwd_fused_kernel', nbytes, lambda: L.check(L.lib().effdet_mbconv_expand_dw_fwd(
+        L.ptr(x.tensor()), L.ptr(w_expand.detach()), L.ptr(scale0), L.ptr(shift0), L.ptr(w_kkc), L.ptr(scale1), L.ptr(shift1), L.ptr(y.t), L.ptr(pool),
+        x.B, x.H, x.W, Cin, Cexp, k, stride, pad_t, pad_l, Ho, Wo, L.stream_ptr()), 'effdet_mbconv_expand_dw_fwd'),
+        'BYTES fused k%d s%d Cin%d C%d %dx%d' % (k, stride, Cin, Cexp, x.H, x.W))
+    return y, pool
+
+
 def dwconv_dgrad(dz, w_kkc, scale, zprev, H, W, k, stride, pad_t, pad_l):
     dx = Map.new(dz.B, H, W, dz.C, dz.dtype, dz.t.device)
     nbytes = dz.t.element_size() * dz.B * dz.C * (dz.H * dz.W + H * W * (2 if zprev else 1))

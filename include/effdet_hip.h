@@ -267,6 +267,17 @@ int effdet_dwconv_fwd_pool_groups(int dtype, int B, int C, int stride, int Ho, i
 int effdet_dwconv_fwd(const void* x, const float* w_kkc, const float* scale, const float* shift,
                       void* y, void* z, float* pool, int dtype, int B, int H, int W, int C, int k,
                       int stride, int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream);
+/* Fused expand (1x1 conv + frozen BN + Swish) -> depthwise (k x k, BN, Swish) FORWARD of an MBConv block for inference
+ * (models/efficientnet.py:82-88): the 6x-expanded map never touches HBM.  fp32 NHWC; x [B][H][W][Cin], Cin in {16, 24, 32, 40};
+ * w_expand [Cexp][Cin] (the OIHW 1x1 weight as is), scale0/shift0 the folded BN0 [Cexp]; w_dw [k*k][Cexp] (effdet_dw_pack_weight),
+ * scale1/shift1 the folded BN1; y [B][Ho][Wo][Cexp] = the Swish output; pool (optional) [B][G][Cexp] per-(image, tile group)
+ * partial sums for effdet_se_gate_fwd*, G = effdet_mbconv_expand_dw_pool_groups(...). */
+int effdet_mbconv_expand_dw_pool_groups(int B, int Cexp, int stride, int Ho, int Wo);
+int effdet_mbconv_expand_dw_fwd(const float* x, const float* w_expand, const float* scale0, const float* shift0,
+                                const float* w_dw, const float* scale1, const float* shift1, float* y, float* pool,
+                                int B, int H, int W, int Cin, int Cexp, int k, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                effdet_stream_t stream);
+
 /* data gradient: dx[b,h,w,c] = sum_taps dz[b,ho,wo,c] * w[tap][c] * scale[c];  optionally
  * multiplied by swish'(zprev) (the expand conv's saved pre-activation) in the epilogue. */
 int effdet_dwconv_dgrad(const void* dz, const float* w_kkc, const float* scale, const void* zprev,

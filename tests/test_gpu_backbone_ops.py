@@ -220,3 +220,36 @@ def test_se_gate_both_forms(B, C, Cse):
     gd, midd, _ = ops.se_gate_fwd(pool.cuda(), w1.cuda(), b1.cuda(), w2.cuda(), b2.cuda(), inv, save_mid=True)
     torch.cuda.synchronize()
     assert_close(midd.cpu(), mid, 1e-4, 'se mid'); assert_close(gd.cpu(), gate, 1e-4, 'se gate')
+
+
+@pytest.mark.parametrize('cfg', [(2, 32, 32, 16, 3, 2, (0, 1)), (2, 32, 24, 24, 3, 1, (1, 1)), (1, 33, 31, 24, 5, 2, (1, 2)),
+                                 (2, 16, 40, 40, 5, 1, (2, 2)), (3, 17, 9, 32, 3, 1, (1, 1)), (2, 64, 64, 16, 3, 2, (0, 1)),
+                                 (1, 48, 48, 40, 3, 2, (0, 1))])
+def test_fused_expand_depthwise_forward(cfg):
+    """effdet_mbconv_expand_dw_fwd (inference): expand 1x1 + BN + Swish -> depthwise k x k (TF-'same' pad of the EXPANDED map: the
+    expand of a padding pixel is swish(shift), not zero -- the case a fused loader gets wrong first) + BN + Swish, and the
+    squeeze-excite partial sums, vs torch on the same inputs (models/efficientnet.py:82-88); odd sizes, every (k, stride, Cin)."""
+    from efficientdet.pytorch_amd import ops
+    B, H, W, Cin, k, s, (plo, phi) = cfg
+    Cexp = 6 * Cin
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    we = torch.randn(Cexp, Cin, 1, 1, generator=g) / Cin ** 0.5
+    s0 = 0.5 + torch.rand(Cexp, generator=g); t0 = torch.randn(Cexp, generator=g) * 0.5        # large shifts: padding pixels would show
+    wd = torch.randn(Cexp, 1, k, k, generator=g) * (2.0 / (k * k)) ** 0.5
+    s1 = 0.5 + torch.rand(Cexp, generator=g); t1 = torch.randn(Cexp, generator=g) * 0.2
+    e = F.conv2d(x, we) * s0.view(1, -1, 1, 1) + t0.view(1, -1, 1, 1)
+    e = e * torch.sigmoid(e)
+    z = F.conv2d(F.pad(e, [plo, phi, plo, phi]), wd, None, s, 0, 1, Cexp) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)
+    y = z * torch.sigmoid(z)
+    Ho, Wo = y.shape[2:]
+    dev = 'cuda'
+    xm = nhwc(x, torch.float32)
+    wk = ops.dw_pack_weight(wd.to(dev))
+    ym, pp = ops.expand_dw_fwd(xm, we.to(dev), s0.to(dev), t0.to(dev), wk, s1.to(dev), t1.to(dev), k, s, plo, plo, Ho, Wo)
+    torch.cuda.synchronize()
+    assert_close(nchw(ym), y, TOL[torch.float32], 'fused expand + depthwise y %s' % (cfg,))
+    assert pp.shape[0] == B and pp.shape[2] == Cexp
+    assert_close(pp.sum(dim=1).cpu(), y.sum(dim=(2, 3)), 5 * TOL[torch.float32], 'se pool')
+    ym2, pp2 = ops.expand_dw_fwd(xm, we.to(dev), s0.to(dev), t0.to(dev), wk, s1.to(dev), t1.to(dev), k, s, plo, plo, Ho, Wo)
+    assert torch.equal(ym2.tensor(), ym.tensor()) and torch.equal(pp2, pp)                       # bitwise reproducible
