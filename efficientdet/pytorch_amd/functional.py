@@ -21,7 +21,8 @@ DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: al
 BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
-FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage, Cin <= 40: expand conv inside the depthwise kernel
+FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage: expand conv inside the depthwise kernel
+FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').split(','))     # block input widths that take it (A/B)
 GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
 # ... in training too (fp32 storage, fused SE backward): built, tested, and OFF -- the depthwise forward must then store its Swish
 # output next to the pre-activation, which costs what channel_scale's pass did: 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on)
@@ -106,7 +107,10 @@ def mbconv_fwd(x, blk, P, dtype, train, rowscale=None, xpre=None, in_act=ACT_NON
     sv = {'x': x, 'blk': blk, 'P': P, 'rowscale': rowscale, 'xpre': xpre}      # xpre: see mbconv_bwd (expand == 1 blocks)
     dw_in_act = ACT_NONE
     Ho, Wo = conv_out(H, blk.k, blk.stride, blk.pad), conv_out(W, blk.k, blk.stride, blk.pad)
-    fuse = (not train and FUSE_EXPAND_DW and blk.expand != 1 and dtype == torch.float32 and blk.cin in (16, 24, 32, 40)
+    # (measured per block, D0 B = 32 @512, expand + depthwise -> fused: k3/s2 Cin 16 492 -> 335 us, k3/s1 Cin 24 267 -> 216; but
+    #  k5/s2 Cin 24 224 -> 333, k5/s1 Cin 40 157 -> 168, k3/s2 Cin 40 107 -> 143: the k = 5 tiles leave one workgroup per CU and at
+    #  Cin = 40 the expand's MFMA work outweighs the bytes saved -- so only the k = 3, Cin <= 32 blocks take it)
+    fuse = (not train and FUSE_EXPAND_DW and blk.expand != 1 and dtype == torch.float32 and blk.k == 3 and blk.cin in FUSE_CIN
             and x.ld == x.C and x.off == 0)
     if fuse:
         s0, t0, i0 = ops.bn_fold(P['bn0.weight'], P['bn0.bias'], P['bn0.running_mean'], P['bn0.running_var'], BN_EPS)
