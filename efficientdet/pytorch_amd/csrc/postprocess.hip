@@ -98,7 +98,7 @@ constexpr int NT = 1024;          // threads per NMS workgroup = candidates per 
 constexpr int SUBS = EFFDET_NMS_SUBS;
 constexpr int ROUND = SUBS * NT;  // candidates per round
 
-struct KeptGrid { int* kcount; float4* kcell; int* kover_n; float4* kover; int HT; unsigned* kbits; };      // see "spatial hash of the KEPT boxes" below; kbits: 1 bit per slot = occupied
+struct KeptGrid { int* kcount; float4* kcell; int* kover_n; float4* kover; int HT; };      // see "spatial hash of the KEPT boxes" below
 constexpr int KG_CAP = 8;                 // boxes per cell (NMS keeps same-size boxes in one cell sparse); more go to the overflow list
 
 struct NmsWs {
@@ -221,7 +221,6 @@ __device__ __forceinline__ void kg_insert(const KeptGrid& kg, long long b, long 
   const float inv = inv_cell(lvl);
   const long long hs = b * kg.HT + cell_hash(lvl, cell_of(0.5f * (bx.x + bx.z), inv), cell_of(0.5f * (bx.y + bx.w), inv), (unsigned)kg.HT - 1u);
   const int pos = atomicAdd(kg.kcount + hs, 1);
-  if (pos == 0 && kg.kbits) { const long long sl = hs - b * kg.HT; atomicOr(kg.kbits + b * (kg.HT >> 5) + (sl >> 5), 1u << (sl & 31)); }
   if (pos < KG_CAP) kg.kcell[hs * KG_CAP + pos] = bx;
   else kg.kover[b * A + atomicAdd(kg.kover_n + b, 1)] = bx;
 }
@@ -313,101 +312,6 @@ __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __res
     }
   }
   if (__ballot(hit) && lane == 0) dead[b * A + i] = 1u;
-}
-
-
-// Kernel A'' (round 4): the same probe with the image's slot-occupancy BITMAP (HT bits: 4 KiB for D0, 16 KiB for D4) in LDS and 16
-// candidates per wave.  A candidate's ~50 probed cells become one pass of LDS bit tests; only the occupied ones (~15 %) cost a global
-// round trip (count + cell line together), and a workgroup of 64 candidates amortises the kernel-argument / bitmap loads that a
-// one-candidate wave paid per candidate.  (One wave per candidate, counts from global: 51 us per round of 2048 x 32 candidates.)
-__global__ __launch_bounds__(256) void nms_cross_bits_kernel(const float4* __restrict__ sbox, const KeptGrid kg, const int* nvalid,
-                                                             unsigned* dead, long long A, int round, float thr, int RND) {
-  extern __shared__ unsigned bits[];                                  // [HT / 32]
-  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nv = nvalid[b];
-  const long long i0 = (long long)round * RND + blockIdx.x * 64LL;
-  if (i0 >= nv) return;                                               // uniform: nothing of this workgroup is a candidate
-  const int nwords = kg.HT >> 5;
-  for (int w = tid * 4; w < nwords; w += 1024) *(uint4*)(bits + w) = *(const uint4*)(kg.kbits + (long long)b * nwords + w);
-  const int no = kg.kover_n[b];
-  // this wave's 16 boxes: lane c < 16 loads candidate c (one round trip for all of them)
-  const long long iw0 = i0 + wave * 16;
-  float4 mybox = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (lane < 16 && iw0 + lane < A) mybox = sbox[b * A + iw0 + lane];
-  __syncthreads();
-  const unsigned mask = (unsigned)kg.HT - 1u;
-  const int e = lane & 7, slot = lane >> 3;
-  for (int c = 0; c < 16; ++c) {
-    const long long i = iw0 + c;
-    if (i >= nv) break;                                               // wave-uniform
-    float4 me;
-    me.x = __shfl(mybox.x, c, 64); me.y = __shfl(mybox.y, c, 64); me.z = __shfl(mybox.z, c, 64); me.w = __shfl(mybox.w, c, 64);
-    const float ma = box_area(me);
-    if (!box_live(me, ma)) continue;
-    const float ex = 1.0e-4f * (me.z - me.x) + 1.0e-6f, ey = 1.0e-4f * (me.w - me.y) + 1.0e-6f;
-    const float qx0 = me.x - ex, qx1 = me.z + ex, qy0 = me.y - ey, qy1 = me.w + ey;
-    const int l0 = octave(ma * 0.4999995f), l1 = octave(ma * 2.000002f);          // <= 4 octaves
-    int cxa[4], cya[4], nxa[4], base[5];
-    base[0] = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int lvl = l0 + k;
-      int nx = 0, ny = 0; cxa[k] = 0; cya[k] = 0;
-      if (lvl <= l1) {
-        const float inv = inv_cell(lvl);
-        cxa[k] = cell_of(qx0, inv); cya[k] = cell_of(qy0, inv);
-        nx = cell_of(qx1, inv) - cxa[k] + 1; ny = cell_of(qy1, inv) - cya[k] + 1;
-      }
-      nxa[k] = nx;
-      const long long cells = (long long)nx * ny;
-      base[k + 1] = base[k] + (int)(cells > 100000000LL ? 100000000LL : cells);
-    }
-    const int T = base[4];
-    bool hit = false;
-    if (T >= 100000000) {
-      // a box spanning > 1e8 cells: walk the image's occupied slots linearly instead -- every filed box is visited
-      for (long long hs0 = lane; hs0 < (long long)kg.HT * KG_CAP && !__ballot(hit); hs0 += 64) {
-        const long long hs = (long long)b * kg.HT + hs0 / KG_CAP; const int ee = (int)(hs0 % KG_CAP);
-        if (ee < min(kg.kcount[hs], KG_CAP)) { const float4 q = kg.kcell[hs * KG_CAP + ee]; hit = suppresses(me, ma, q, box_area(q), thr); }
-      }
-    } else {
-      for (int c0 = 0; c0 < T && !hit; c0 += 64) {
-        const int cc0 = c0 + lane;
-        const bool in = cc0 < T;
-        const int cc = in ? cc0 : 0;
-        const int k = (cc >= base[1]) + (cc >= base[2]) + (cc >= base[3]);
-        const int r = cc - base[k], nx = nxa[k] > 0 ? nxa[k] : 1;
-        const int cy = r / nx, cx = r - cy * nx;
-        const unsigned sl = cell_hash(l0 + k, cxa[k] + cx, cya[k] + cy, mask);
-        const bool occ = in && ((bits[sl >> 5] >> (sl & 31)) & 1u);
-        unsigned long long ne = __ballot(occ);                         // occupied cells of this pass (uniform)
-        while (ne) {                                                   // uniform: up to 8 occupied cells per step
-          int src = 0, found = 0;
-          unsigned long long m = ne;
-#pragma unroll
-          for (int q8 = 0; q8 < 8; ++q8) {
-            const int pos = m ? __builtin_ctzll(m) : 0;
-            if (q8 == slot) { src = pos; found = m != 0ull; }
-            m &= m - 1ull;
-          }
-          ne = m;
-          const long long hs = (long long)b * kg.HT + (long long)__shfl((int)sl, src, 64);
-          const int n = kg.kcount[hs];                                 // count and cell line of the same slot: one round trip
-          const float4 q = kg.kcell[hs * KG_CAP + e];
-          const bool h = found && e < min(n, KG_CAP) && suppresses(me, ma, q, box_area(q), thr);
-          if (__ballot(h)) { hit = true; break; }
-        }
-      }
-    }
-    if (!__ballot(hit)) {
-      for (int e0 = 0; e0 < no; e0 += 64) {
-        bool h = false;
-        if (e0 + lane < no) { const float4 q = kg.kover[b * A + e0 + lane]; h = suppresses(me, ma, q, box_area(q), thr); }
-        if (__ballot(h)) { hit = true; break; }
-      }
-    }
-    if (__ballot(hit) && lane == 0) dead[b * A + i] = 1u;
-  }
 }
 
 // Kernel A: candidates of round `round` vs boxes kept in earlier rounds (split over blockIdx.z).
@@ -855,7 +759,6 @@ __global__ __launch_bounds__(64) void nms_resolve_kernel(const NmsRound q, const
           const float inv = inv_cell(lvl);
           pend_hs = (long long)b * kg.HT + cell_hash(lvl, cell_of(0.5f * (bx.x + bx.z), inv), cell_of(0.5f * (bx.y + bx.w), inv), (unsigned)kg.HT - 1u);
           pend_pos = atomicAdd(kg.kcount + pend_hs, 1);
-          if (pend_pos == 0) { const long long sl = pend_hs - (long long)b * kg.HT; atomicOr(kg.kbits + (long long)b * (kg.HT >> 5) + (sl >> 5), 1u << (sl & 31)); }
           pend_box = bx; pend = true;
         }
       }
@@ -917,7 +820,6 @@ size_t carve(NmsWs& w, void* base, int B, long long A) {
   w.kg.HT = ht;
   w.kg.kcount = (int*)take((size_t)B * ht * 4); w.kg.kover_n = (int*)take((size_t)B * 4);
   w.kg.kcell = (float4*)take((size_t)B * ht * KG_CAP * 16); w.kg.kover = (float4*)take(n * 16);
-  w.kg.kbits = (unsigned*)take((size_t)B * (ht / 32) * 4);
   // round 4 (the 32-bit key buffers alias nothing of the above: the rocPRIM path, kept for A/B under EFFDET_NMS_V1, still owns its own)
   w.T = (int)((A + RS_TILE - 1) / RS_TILE);
   w.k32a = (unsigned*)take(n * 4); w.k32b = (unsigned*)take(n * 4); w.v32b = (unsigned*)take(n * 4);
@@ -1000,7 +902,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
                      use_grid ? kg.kcount : kg.kover_n, use_grid ? (long long)B * kg.HT + 0 : (long long)B);
   EFFDET_CHECK_LAUNCH();
   if (use_grid) {
-    hipLaunchKernelGGL(nms_reset_kernel, dim3(64), dim3(256), 0, st, kg.kover_n, (long long)B, (int*)kg.kbits, (long long)B * (kg.HT / 32), (int*)nullptr, 0LL);
+    hipLaunchKernelGGL(nms_reset_kernel, dim3(1), dim3(256), 0, st, kg.kover_n, (long long)B, (int*)nullptr, 0LL, (int*)nullptr, 0LL);
     EFFDET_CHECK_LAUNCH();
   } else {
     kg.kcount = nullptr;
@@ -1029,9 +931,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     EFFDET_SET_MAX_LDS((nms_matrix_kernel), (size_t)(4096 + 64) * (16 + 4));      // (the largest round size: the attribute is set once per device)
     for (int r = 0; r < rounds; ++r) {
       if (r > 0 && use_grid) {
-        static const int cross_v = getenv("EFFDET_NMS_CROSS") ? atoi(getenv("EFFDET_NMS_CROSS")) : 2;      // A/B: 1 = one wave per candidate, counts from global
-        if (cross_v == 1) hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(RND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
-        else hipLaunchKernelGGL(nms_cross_bits_kernel, dim3(RND / 64, B), dim3(256), (size_t)(kg.HT / 32) * 4, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
+        hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(RND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
         EFFDET_CHECK_LAUNCH();
       } else if (r > 0) {
         hipLaunchKernelGGL(nms_cross_kernel, dim3(B, RND / NT, 16), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, 16, iou_threshold, RND);
