@@ -314,107 +314,6 @@ __global__ __launch_bounds__(256) void nms_cross_grid_kernel(const float4* __res
   if (__ballot(hit) && lane == 0) dead[b * A + i] = 1u;
 }
 
-
-// Kernel A'' (round 4): FOUR candidates per wave, 16 lanes each.  The one-candidate wave above spends its life in ~5 dependent memory
-// round trips (arguments, box, cell counts, cell lines, store) at 8 waves / SIMD: 65536 waves per round = 8 generations x ~6 us
-// (51 us per round of 2048 x 32 candidates).  Here a wave's trips serve four candidates -- a 16-lane group reads the counts of up to 64
-// cells as four independent loads per lane, then walks its occupied cells two at a time (2 cells x 8 entries = 16 lanes) -- so a round
-// is a quarter of the waves.  (The other direction, 16 candidates per wave one after the other with the occupancy bitmap in LDS, was
-// measured too: 3.16 vs 2.54 ms per D0 batch -- serialising a wave's candidates loses more than the shared loads save.)
-__global__ __launch_bounds__(256) void nms_cross_grid4_kernel(const float4* __restrict__ sbox, const KeptGrid kg, const int* nvalid,
-                                                              unsigned* dead, long long A, int round, float thr, int RND) {
-  const int b = blockIdx.y, lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
-  const long long i = (long long)round * RND + blockIdx.x * 16LL + (threadIdx.x >> 6) * 4 + grp;
-  const long long ii = i < A ? i : A - 1;
-  const int nv = nvalid[b];
-  const float4 me = sbox[b * A + ii];                                 // (16 lanes, one address: a broadcast)
-  const int no = kg.kover_n[b];
-  const float ma = box_area(me);
-  const bool live = i < nv && box_live(me, ma);
-  if (!__ballot(live)) return;
-  const float ex = 1.0e-4f * (me.z - me.x) + 1.0e-6f, ey = 1.0e-4f * (me.w - me.y) + 1.0e-6f;
-  const float qx0 = me.x - ex, qx1 = me.z + ex, qy0 = me.y - ey, qy1 = me.w + ey;
-  const int l0 = octave(ma * 0.4999995f), l1 = octave(ma * 2.000002f);          // <= 4 octaves
-  const unsigned mask = (unsigned)kg.HT - 1u;
-  int cxa[4], cya[4], nxa[4], base[5];
-  base[0] = 0;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int lvl = l0 + k;
-    int nx = 0, ny = 0; cxa[k] = 0; cya[k] = 0;
-    if (live && lvl <= l1) {
-      const float inv = inv_cell(lvl);
-      cxa[k] = cell_of(qx0, inv); cya[k] = cell_of(qy0, inv);
-      nx = cell_of(qx1, inv) - cxa[k] + 1; ny = cell_of(qy1, inv) - cya[k] + 1;
-    }
-    nxa[k] = nx;
-    const long long cells = (long long)nx * ny;
-    base[k + 1] = base[k] + (int)(cells > 100000000LL ? 100000000LL : cells);
-  }
-  const int T = live ? base[4] : 0;                                   // (uniform inside a 16-lane group)
-  bool hit = false;
-  const bool huge = T >= 100000000;
-  if (__ballot(huge)) {
-    // a box spanning > 1e8 cells (coordinates ~1e9 px): its group walks the image's slots linearly -- every filed box is visited
-    for (long long hs0 = gl; hs0 < (long long)kg.HT * KG_CAP; hs0 += 16) {
-      bool h = false;
-      if (huge) {
-        const long long hs = (long long)b * kg.HT + hs0 / KG_CAP; const int ee = (int)(hs0 % KG_CAP);
-        if (ee < min(kg.kcount[hs], KG_CAP)) { const float4 q = kg.kcell[hs * KG_CAP + ee]; h = suppresses(me, ma, q, box_area(q), thr); }
-      }
-      const unsigned gh = (unsigned)(__ballot(h) >> (16 * grp)) & 0xffffu;
-      if (gh) hit = true;
-      if (!__ballot(huge && !hit)) break;
-    }
-  }
-  const int Tn = huge ? 0 : T;
-  int tmax = max(max(__shfl(Tn, 0, 64), __shfl(Tn, 16, 64)), max(__shfl(Tn, 32, 64), __shfl(Tn, 48, 64)));
-  const int e = gl & 7, cs = gl >> 3;
-  for (int c0 = 0; c0 < tmax; c0 += 64) {                             // 64 cells per group and trip: four independent count loads per lane
-    long long hsu[4]; int nu[4];
-    unsigned long long gm = 0ull;                                     // the group's occupied (u, lane16) positions, bit 16 u + lane16
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = c0 + u * 16 + gl;
-      const bool in = c < Tn && !hit;
-      const int cc = in ? c : 0;
-      const int k = (cc >= base[1]) + (cc >= base[2]) + (cc >= base[3]);
-      const int r = cc - base[k], nx = nxa[k] > 0 ? nxa[k] : 1;
-      const int cy = r / nx, cx = r - cy * nx;
-      hsu[u] = (long long)b * kg.HT + cell_hash(l0 + k, cxa[k] + cx, cya[k] + cy, mask);
-      const int cnt = kg.kcount[hsu[u]];
-      nu[u] = in ? min(cnt, KG_CAP) : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) gm |= ((__ballot(nu[u] > 0) >> (16 * grp)) & 0xffffull) << (16 * u);
-    while (__ballot(gm != 0ull && !hit)) {                            // uniform; each group takes its next two occupied cells
-      unsigned long long m = gm;
-      const int p0 = m ? __builtin_ctzll(m) : 0; m &= m - 1ull;
-      const int p1 = m ? __builtin_ctzll(m) : 0; const bool two = m != 0ull; m &= m - 1ull;
-      const bool found = gm != 0ull && (cs == 0 || two);
-      const int pos = cs ? p1 : p0, u = pos >> 4, src = grp * 16 + (pos & 15);
-      gm = m;
-      long long hs = 0; int n = 0;
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {                                // (shuffle all four, select: no dynamic register indexing)
-        const int lo = __shfl((int)(hsu[q4] & 0xffffffffll), src, 64), hi = __shfl((int)(hsu[q4] >> 32), src, 64), nn = __shfl(nu[q4], src, 64);
-        if (q4 == u) { hs = ((long long)hi << 32) | (unsigned)lo; n = nn; }
-      }
-      const float4 q = kg.kcell[hs * KG_CAP + e];                     // (unused slots read position 0's line: valid, masked by found)
-      const bool h = found && !hit && e < n && suppresses(me, ma, q, box_area(q), thr);
-      if ((__ballot(h) >> (16 * grp)) & 0xffffull) hit = true;
-    }
-  }
-  // overflow list of the image (rare): each group scans it 16 entries at a time
-  for (int e0 = 0; e0 < no; e0 += 16) {
-    if (!__ballot(live && !hit)) break;
-    bool h = false;
-    if (live && !hit && e0 + gl < no) { const float4 q = kg.kover[b * A + e0 + gl]; h = suppresses(me, ma, q, box_area(q), thr); }
-    if ((__ballot(h) >> (16 * grp)) & 0xffffull) hit = true;
-  }
-  if (live && hit && gl == 0) dead[b * A + i] = 1u;
-}
-
 // Kernel A: candidates of round `round` vs boxes kept in earlier rounds (split over blockIdx.z).
 __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict__ sbox, const float4* kbox, const int* nvalid,
                                                        const int* kept, unsigned* dead, long long A, int round, int splits, float thr, int RND) {
@@ -1032,9 +931,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     EFFDET_SET_MAX_LDS((nms_matrix_kernel), (size_t)(4096 + 64) * (16 + 4));      // (the largest round size: the attribute is set once per device)
     for (int r = 0; r < rounds; ++r) {
       if (r > 0 && use_grid) {
-        static const int cross_v = getenv("EFFDET_NMS_CROSS") ? atoi(getenv("EFFDET_NMS_CROSS")) : 4;      // A/B: 1 = one candidate per wave, 4 = four
-        if (cross_v == 1) hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(RND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
-        else hipLaunchKernelGGL(nms_cross_grid4_kernel, dim3(RND / 16, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
+        hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(RND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, RND);
         EFFDET_CHECK_LAUNCH();
       } else if (r > 0) {
         hipLaunchKernelGGL(nms_cross_kernel, dim3(B, RND / NT, 16), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, 16, iou_threshold, RND);
