@@ -5,22 +5,18 @@
 //
 // NMS design (worst case of the synthetic benchmark: every one of the 49 104 / 196 416 anchors is a
 // candidate, ~11 % survive):
-//   1. key = ~orderable(score) (invalid -> 0xffffffff), value = anchor index; ONE stable segmented
-//      radix sort (rocPRIM) over the B images gives "descending score, ties by index".
-//   2. candidates are walked in rounds of 8192.  Kernel A (whole GPU: image x 1024-candidate tile
-//      x kept-list split) marks candidates suppressed by boxes kept in EARLIER rounds; kept boxes
-//      are staged through LDS in 1024-box chunks and broadcast-read.
-//   3. Kernel B (one 1024-thread workgroup per image) finishes the round tile by tile: suppress
-//      by boxes kept earlier in this round, compact the survivors with wave ballots + prefix
-//      sums, build their (<=1024)^2 suppression bit-matrix in LDS (word-major; (row, 8-column) work
-//      items dealt to all 1024 threads) and resolve the greedy order with one wave walking the rows
-//      in blocks of 64 (earlier kept words AND-ed against the row, then one ballot per kept box
-//      inside the block) -- exactly the sequential greedy result.  Kept boxes / indices are
-//      appended in order and filed into the kept-box grid.
-//   All loops are bounded by device-side counts; the host launches ceil(A/8192) rounds blindly.
+//   1. key = ~orderable(score) (invalid -> 0xffffffff), value = anchor index; an in-tree stable LSD
+//      radix sort of the B per-image segments gives "descending score, ties by index".
+//   2. candidates are walked in rounds of 2048 (4096 above 64 k anchors).  The cross phase (whole GPU, one wave
+//      per candidate) marks candidates suppressed by boxes kept in EARLIER rounds through the spatial
+//      hash of the kept boxes (brute force over the kept list for iou_threshold < 0.5).
+//   3. nms_matrix_kernel (several workgroups per image) compacts the round's survivors and builds their
+//      suppression bit-matrix; nms_resolve_kernel (one wave per image) walks the rows in blocks of 64 --
+//      exactly the sequential greedy result -- appends the kept boxes in order and files them into the grid.
+//   All loops are bounded by device-side counts; the host launches ceil(A / round) rounds blindly; every
+//   launch geometry depends on shapes only and the call consists of kernel nodes only: capture-safe.
 #include "common.h"
 #include <stdlib.h>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace {
 
@@ -89,22 +85,12 @@ __global__ __launch_bounds__(256) void decode_score_kernel(const float* __restri
 
 // ------------------------------------------------------------------ NMS
 constexpr int NT = 1024;          // threads per NMS workgroup = candidates per tile
-#ifndef EFFDET_NMS_SUBS
-#define EFFDET_NMS_SUBS 2
-#endif
-// Tiles per round.  Inside a round the per-image workgroup (ONE CU) checks each tile against the boxes kept earlier in the
-// same round -- VALU-bound work that grows with SUBS^2 -- whereas boxes kept in earlier rounds are handled by the
-// whole-GPU cross kernel; 8 -> 2 tiles per round moved 3/4 of that work onto the 256 CUs for 18 more (small) launches.
-constexpr int SUBS = EFFDET_NMS_SUBS;
-constexpr int ROUND = SUBS * NT;  // candidates per round
 
 struct KeptGrid { int* kcount; float4* kcell; int* kover_n; float4* kover; int HT; };      // see "spatial hash of the KEPT boxes" below
 constexpr int KG_CAP = 8;                 // boxes per cell (NMS keeps same-size boxes in one cell sparse); more go to the overflow list
 
 struct NmsWs {
-  unsigned long long* keys_in; unsigned long long* keys_out; unsigned* vals_in; unsigned* vals_out;
-  int* offsets; int* nvalid; int* kept; unsigned* dead; float4* sbox; float4* kbox;
-  void* temp; size_t temp_bytes;
+  unsigned* vals_in; int* nvalid; int* kept; unsigned* dead; float4* sbox; float4* kbox;
   KeptGrid kg;                                      // spatial hash of the kept boxes (cross phase, iou_threshold >= 0.5)
   // round 4: in-tree radix sort (32-bit keys per image, ping-pong) + the multi-workgroup round
   unsigned *k32a, *k32b, *v32b, *hist; int T;
@@ -141,40 +127,6 @@ __device__ __forceinline__ bool scan_kept(const float4& me, float ma, const floa
 }
 // sentinel for the padding slots: empty box far away -> negative overlap width -> never suppresses
 __device__ __forceinline__ float4 no_box() { return make_float4(-3.0e30f, -3.0e30f, -3.0e30f, -3.0e30f); }
-
-__global__ __launch_bounds__(256) void nms_keys_kernel(const float* __restrict__ score, float thr, unsigned long long* keys, unsigned* vals,
-                                                       int* nvalid, int* offsets, int* kept, unsigned* dead, long long A, int B) {
-  // grid (x, B): one image per blockIdx.y, so the valid count is a ballot + one atomic per wave-leader block sum
-  const int b = blockIdx.y;
-  __shared__ int cnt[4];
-  int mine = 0;
-  for (long long a = blockIdx.x * 256LL + threadIdx.x; a < A; a += (long long)gridDim.x * 256) {
-    const long long i = (long long)b * A + a;
-    const float s = score[i];
-    unsigned k = 0xffffffffu;
-    if (s > thr) {
-      unsigned u = __float_as_uint(s);
-      u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;     // ascending-orderable
-      k = ~u;                                         // descending score
-      if (k == 0xffffffffu) k = 0xfffffffeu;
-      ++mine;
-    }
-    // one GLOBAL stable radix sort over (image, descending score) instead of a segmented sort (3x faster for 32 segments
-    // of 49k keys): the image index rides in the upper key bits
-    keys[i] = ((unsigned long long)b << 32) | k; vals[i] = (unsigned)a; dead[i] = 0u;
-  }
-  mine = (int)wave_sum((float)mine);
-  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int t = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-    if (t) atomicAdd(nvalid + b, t);
-    if (blockIdx.x == 0) {
-      kept[b] = 0; offsets[b] = (int)(b * A);
-      if (b == B - 1) offsets[B] = (int)((long long)B * A);
-    }
-  }
-}
 
 __global__ void nms_gather_kernel(const float* __restrict__ boxes, const unsigned* __restrict__ idx, const int* __restrict__ nvalid,
                                   float4* __restrict__ sbox, long long A, int B) {
@@ -340,151 +292,6 @@ __global__ __launch_bounds__(NT) void nms_cross_kernel(const float4* __restrict_
   }
   if (valid && !alive) dead[b * A + i] = 1u;
 }
-
-#ifdef EFFDET_NMS_PROF
-__device__ unsigned long long nms_prof[8];
-#define PROF_T(i) do { if (tid == 0 && b == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); nms_prof[i] += t_ - tp; tp = t_; } } while (0)
-#else
-#define PROF_T(i) do {} while (0)
-#endif
-// Kernel B: finish round `round` for one image per workgroup.
-__global__ __launch_bounds__(NT) void nms_round_kernel(const float4* __restrict__ sbox, const unsigned* __restrict__ sidx, float4* kbox,
-                                                       const int* nvalid, int* kept, const unsigned* dead, int* out_idx,
-                                                       long long A, int round, float thr, const KeptGrid kg) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned long long* mask = (unsigned long long*)smem_raw;           // [16][NT] word-major
-  float4* tb = (float4*)(smem_raw + (size_t)16 * NT * 8);            // [NT + 8] boxes (kept chunk / survivors)
-  float* ta = (float*)(tb + NT + 8);                                  // [NT + 8] areas
-  unsigned* tidx = (unsigned*)(ta + NT + 8);                          // [NT] survivor anchor idx
-  unsigned long long* keptb = (unsigned long long*)(tidx + NT);       // [16]
-  unsigned long long* deadb = keptb + 16;                             // [16]
-  int* wsum = (int*)(deadb + 16);                                     // [16] per-wave counts
-  int* sh = wsum + 16;                                                // [4] scalars
-
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nv = nvalid[b];
-  if ((long long)round * ROUND >= nv) return;
-  int kc = kept[b];
-  const int kc_round0 = kc;
-#ifdef EFFDET_NMS_PROF
-  unsigned long long tp = __builtin_readcyclecounter();
-#endif
-
-  for (int sub = 0; sub < SUBS; ++sub) {
-    const long long tile0 = (long long)round * ROUND + (long long)sub * NT;
-    if (tile0 >= nv) break;                                            // uniform
-    const long long i = tile0 + tid;
-    const bool valid = i < nv;
-    float4 me = make_float4(0, 0, 0, 0); float ma = 0.f; unsigned myidx = 0;
-    bool alive = false;
-    if (valid) { me = sbox[b * A + i]; ma = (me.z - me.x) * (me.w - me.y); myidx = sidx[b * A + i]; alive = dead[b * A + i] == 0u; }
-    // ---- phase a': vs boxes kept earlier in THIS round ----
-    for (int c0 = kc_round0; c0 < kc; c0 += NT) {
-      const int n = min(NT, kc - c0);
-      __syncthreads();
-      if (tid < n) { const float4 q = kbox[b * A + c0 + tid]; tb[tid] = q; ta[tid] = (q.z - q.x) * (q.w - q.y); }
-      else if (tid < n + 8) { tb[tid] = no_box(); ta[tid] = 0.f; }
-      if (tid < 8) { tb[NT + tid] = no_box(); ta[NT + tid] = 0.f; }
-      __syncthreads();
-      alive = scan_kept(me, ma, tb, ta, n, alive, thr);
-    }
-    __syncthreads();
-    PROF_T(0);
-    // ---- order-preserving compaction of the survivors ----
-    const unsigned long long bal = __ballot(alive);
-    const int wrank = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[wave] = __popcll(bal);
-    __syncthreads();
-    int woff = 0, S = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const int c = wsum[q]; if (q < wave) woff += c; S += c; }
-    if (alive) { const int s = woff + wrank; tb[s] = me; ta[s] = ma; tidx[s] = myidx; }
-    if (tid < 16) { keptb[tid] = 0ull; deadb[tid] = 0ull; }
-    __syncthreads();
-    PROF_T(1);
-    if (S == 0) continue;                                              // uniform
-    // ---- suppression bit-matrix among the S survivors (row s, bits j < s), word-major in LDS ----
-    // Work items are (row, 8-column group) pairs dealt round-robin to all 1024 threads and OR-ed into the row's words: with
-    // one thread per ROW the last wave did S/8 steps while 13 of 16 waves idled (typical S ~ 150: 3 busy waves).
-    const int nw = (S + 63) >> 6;
-    if (tid < S) for (int w = 0; w < nw; ++w) mask[(size_t)w * NT + tid] = 0ull;
-    __syncthreads();
-    {
-      const int G = (S + 7) >> 3;
-      const int items = S * G;
-#pragma unroll 1
-      for (int item = tid; item < items; item += NT) {
-        const int r = item / G, c0 = (item - r * G) << 3;
-        if (c0 >= r) continue;                         // only earlier survivors count
-        const float4 mb = tb[r]; const float mba = ta[r];
-        float4 q[8]; float qa[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { q[u] = tb[c0 + u]; qa[u] = ta[c0 + u]; }   // slots >= S (stale) land on bits >= r: dropped below
-        unsigned bits = 0u;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (suppresses(mb, mba, q[u], qa[u], thr)) bits |= 1u << u;
-        const int lim = r - c0;
-        if (lim < 8) bits &= (1u << lim) - 1u;
-        if (bits) atomicOr(&mask[(size_t)(c0 >> 6) * NT + r], (unsigned long long)bits << (c0 & 63));
-      }
-    }
-    __syncthreads();
-    PROF_T(2);
-    // ---- greedy order, resolved by ONE wave in blocks of 64 rows (a workgroup-wide fixed point needs ~chain-length
-    //      barrier rounds; here a block costs one pass over the earlier kept words + one ballot per box it keeps) ----
-    if (wave == 0) {
-      unsigned long long Kw[16];
-#pragma unroll
-      for (int blk = 0; blk < 16; ++blk) {
-        Kw[blk] = 0ull;
-        if (blk < nw) {                                  // uniform
-          const int r = blk * 64 + lane;
-          bool gone = r >= S;
-#pragma unroll
-          for (int w = 0; w < blk; ++w) if (mask[(size_t)w * NT + r] & Kw[w]) gone = true;
-          const unsigned long long diag = mask[(size_t)blk * NT + r];
-          unsigned long long cand = __ballot(!gone), keep = 0ull;
-          while (cand) {                                 // uniform
-            const int i = __builtin_ctzll(cand);
-            keep |= 1ull << i;
-            cand &= ~(__ballot((diag >> i) & 1ull) | (1ull << i));   // a row's bits only name earlier rows: lanes > i
-          }
-          Kw[blk] = keep;
-          if (lane == 0) keptb[blk] = keep;
-        }
-      }
-    }
-    __syncthreads();
-    const int status = (tid < S && ((keptb[tid >> 6] >> (tid & 63)) & 1ull)) ? 1 : 2;
-    PROF_T(3);
-#ifdef EFFDET_NMS_PROF
-    if (tid == 0 && b == 0) { nms_prof[5] += S; nms_prof[6] += 1; }
-#endif
-    // ---- append the kept survivors in order ----
-    const bool k = status == 1;
-    const unsigned long long kbal = __ballot(k);
-    const int krank = __popcll(kbal & ((1ull << lane) - 1ull));
-    __syncthreads();
-    if (lane == 0) wsum[wave] = __popcll(kbal);
-    __syncthreads();
-    int koff = 0, KT = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) { const int c = wsum[q]; if (q < wave) koff += c; KT += c; }
-    if (k) {
-      const int pos = kc + koff + krank;
-      kbox[b * A + pos] = tb[tid];
-      out_idx[b * A + pos] = (int)tidx[tid];
-      if (kg.kcount) kg_insert(kg, b, A, tb[tid]);          // file it for the later rounds' cross phase
-    }
-    kc += KT;
-    __threadfence_block();
-    __syncthreads();
-    PROF_T(4);
-  }
-  if (tid == 0) kept[b] = kc;
-  (void)sh;
-}
-
 
 // ------------------------------------------------------------------ NMS, round 4: in-tree sort + a round spread over the GPU
 // (1) Stable LSD radix sort of the B equal-length segments (one per image) of 32-bit keys with their anchor indices: 4 passes of
@@ -788,15 +595,6 @@ __global__ void gather_dets_kernel(const float* __restrict__ boxes, const float*
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
-inline int key_bits(int B) { int bits = 32; while ((1LL << (bits - 32)) < B) ++bits; return bits; }
-
-size_t sort_temp_bytes(long long total, int B) {
-  size_t bytes = 0;
-  unsigned long long* k = nullptr; unsigned* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)total, 0u, (unsigned)key_bits(B), (hipStream_t)0, false);
-  return bytes;
-}
-
 // candidates per round of the multi-workgroup form: 2048 (D0 @512: 24 rounds), 4096 above 64 k anchors (D4 @1024: 48 rounds);
 // EFFDET_NMS_ROUND overrides (A/B)
 inline int nms_round_size(long long A) {
@@ -809,18 +607,15 @@ size_t carve(NmsWs& w, void* base, int B, long long A) {
   const size_t n = (size_t)B * A;
   size_t off = 0;
   auto take = [&](size_t bytes) { void* p = base ? (char*)base + off : nullptr; off += al(bytes); return p; };
-  w.keys_in = (unsigned long long*)take(n * 8); w.keys_out = (unsigned long long*)take(n * 8);
-  w.vals_in = (unsigned*)take(n * 4); w.vals_out = (unsigned*)take(n * 4);
+  w.vals_in = (unsigned*)take(n * 4);
   w.dead = (unsigned*)take(n * 4);
   w.sbox = (float4*)take(n * 16); w.kbox = (float4*)take(n * 16);
-  w.offsets = (int*)take((size_t)(B + 1) * 4); w.nvalid = (int*)take((size_t)B * 4); w.kept = (int*)take((size_t)B * 4);
-  w.temp_bytes = sort_temp_bytes((long long)n, B);
-  w.temp = take(w.temp_bytes);
+  w.nvalid = (int*)take((size_t)B * 4); w.kept = (int*)take((size_t)B * 4);
   int ht = 1024; while (ht < A / 2) ht <<= 1;      // hash slots per image (kept boxes are a fraction of the candidates), a power of two
   w.kg.HT = ht;
   w.kg.kcount = (int*)take((size_t)B * ht * 4); w.kg.kover_n = (int*)take((size_t)B * 4);
   w.kg.kcell = (float4*)take((size_t)B * ht * KG_CAP * 16); w.kg.kover = (float4*)take(n * 16);
-  // round 4 (the 32-bit key buffers alias nothing of the above: the rocPRIM path, kept for A/B under EFFDET_NMS_V1, still owns its own)
+  // in-tree radix sort (32-bit keys per image, ping-pong) + the multi-workgroup round
   w.T = (int)((A + RS_TILE - 1) / RS_TILE);
   w.k32a = (unsigned*)take(n * 4); w.k32b = (unsigned*)take(n * 4); w.v32b = (unsigned*)take(n * 4);
   w.hist = (unsigned*)take((size_t)B * 256 * w.T * 4);
@@ -893,7 +688,6 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   if ((long long)need > workspace_bytes) return EFFDET_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)B * A;
-  static const int v1 = getenv("EFFDET_NMS_V1") ? atoi(getenv("EFFDET_NMS_V1")) : 0;      // A/B switch: 1 = the round-3 path (rocPRIM sort, one workgroup per image and round)
   static const int grid_env = getenv("EFFDET_NMS_GRID") ? atoi(getenv("EFFDET_NMS_GRID")) : 1;       // A/B switch (0 = brute-force cross phase)
   const bool use_grid = grid_env && iou_threshold >= 0.5f;
   KeptGrid kg = w.kg;
@@ -907,8 +701,8 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
   } else {
     kg.kcount = nullptr;
   }
-  if (!v1) {
-    // ---- keys, in-tree stable radix sort per image (4 x 8 bits), boxes in sorted order ----
+  // ---- keys, in-tree stable radix sort per image (4 x 8 bits), boxes in sorted order ----
+  {
     { long long gx = (A + 2047) / 2048; if (gx > 64) gx = 64;      // (one atomic per workgroup onto nvalid[b]: 32 counters in ONE cache line serialise at ~8 ns each)
       hipLaunchKernelGGL(nms_keys32_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.k32a, w.vals_in, w.nvalid, w.kept, w.dead, A); }
     EFFDET_CHECK_LAUNCH();
@@ -943,40 +737,7 @@ extern "C" int effdet_nms(const float* boxes, const float* score, float threshol
     }
     return EFFDET_OK;
   }
-  { long long gx = (A + 255) / 256; if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(nms_keys_kernel, dim3((unsigned)gx, B), dim3(256), 0, st, score, threshold, w.keys_in, w.vals_in, w.nvalid, w.offsets, w.kept, w.dead, A, B); }
-  EFFDET_CHECK_LAUNCH();
-  size_t tb = w.temp_bytes;
-  if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)n, 0u, (unsigned)key_bits(B), st, false) != hipSuccess)
-    return EFFDET_ELAUNCH;
-  hipLaunchKernelGGL(nms_gather_kernel, dim3(grid_for(n)), dim3(256), 0, st, boxes, w.vals_out, w.nvalid, w.sbox, A, B);
-  EFFDET_CHECK_LAUNCH();
-  const size_t lds = (size_t)16 * NT * 8 + (size_t)(NT + 8) * 16 + (size_t)(NT + 8) * 4 + (size_t)NT * 4 + 16 * 8 * 2 + 16 * 4 + 16;
-  EFFDET_SET_MAX_LDS((nms_round_kernel), lds);
-  const int rounds = (int)((A + ROUND - 1) / ROUND);
-  for (int r = 0; r < rounds; ++r) {
-    if (r > 0 && use_grid) {
-      hipLaunchKernelGGL(nms_cross_grid_kernel, dim3(ROUND / 4, B), dim3(256), 0, st, w.sbox, kg, w.nvalid, w.dead, A, r, iou_threshold, ROUND);
-      EFFDET_CHECK_LAUNCH();
-    } else if (r > 0) {
-      constexpr int SPLITS = SUBS >= 8 ? 4 : (SUBS >= 4 ? 8 : 16);      // keep ~1000 workgroups per launch at B = 32
-      hipLaunchKernelGGL(nms_cross_kernel, dim3(B, SUBS, SPLITS), dim3(NT), 0, st, w.sbox, w.kbox, w.nvalid, w.kept, w.dead, A, r, SPLITS, iou_threshold, ROUND);
-      EFFDET_CHECK_LAUNCH();
-    }
-    hipLaunchKernelGGL(nms_round_kernel, dim3(B), dim3(NT), lds, st, w.sbox, w.vals_out, w.kbox, w.nvalid, w.kept, w.dead, out_idx, A, r, iou_threshold, kg);
-    EFFDET_CHECK_LAUNCH();
-  }
-  if (hipMemcpyAsync(out_count, w.kept, (size_t)B * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return EFFDET_ELAUNCH;
-  return EFFDET_OK;
 }
-
-#ifdef EFFDET_NMS_PROF
-extern "C" int effdet_nms_prof(unsigned long long* out) {
-  unsigned long long z[8] = {0};
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(nms_prof), sizeof(z)) != hipSuccess) return -1;
-  return hipMemcpyToSymbol(HIP_SYMBOL(nms_prof), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
 
 extern "C" int effdet_gather_dets(const float* boxes, const float* score, const int* label, const int* idx, const int* count,
                                   float* out_scores, long long* out_labels, float* out_boxes, int B, long long A,

@@ -403,10 +403,13 @@ int effdet_decode_score(const float* anchors, const float* reg, const float* cls
  * (models/efficientdet.py:73-86 and torchvision.ops.nms semantics: suppress IoU > thr).
  * Everything stays on the device; no host round trip.
  * Outputs (per image, capacity A each): out_idx [B][A] (indices into the anchor list, in kept
- * order), out_count [B].  workspace: effdet_nms_workspace_bytes(B, A) bytes = per candidate (B*A of them) 2 x 8 B sort
- * keys + 3 x 4 B values / flags + 3 x 16 B boxes (sorted, kept, hash overflow) + the radix sort's scratch, plus the kept-box
- * spatial hash: HT = 2^k >= max(1024, A/2) slots per image x (4 B counter + 8 x 16 B entries) -- 134 MB for D0 at B = 32 (A = 49 104)
- * and for D4 @1024 at B = 8 (A = 196 416); every call clears the B*HT counters (B*HT*4 bytes) with one memset. */
+ * order), out_count [B].  workspace: effdet_nms_workspace_bytes(B, A) bytes = per candidate (B*A of them) 2 x 4 B sort
+ * keys + 2 x 4 B indices + 4 B flag + 3 x 16 B boxes (sorted, kept, hash overflow), the radix sort's digit histograms
+ * (B x 256 x ceil(A / 2048) x 4 B), a round's survivor list and suppression bit-matrix (round = 2048 candidates, 4096 above 64 k
+ * anchors: B x round^2 / 8 bytes), plus the kept-box spatial hash: HT = 2^k >= max(1024, A/2) slots per image x (4 B counter +
+ * 8 x 16 B entries) -- 134 MB for D0 at B = 32 (A = 49 104) and for D4 @1024 at B = 8 (A = 196 416).
+ * The sort is in-tree (stable LSD radix, 4 x 8 bits, per image); the call enqueues KERNELS only (no memset / memcpy nodes, launch
+ * geometry a function of B and A alone), so it can be captured into a hipGraph and replayed (graph.GraphedDetect does). */
 long long effdet_nms_workspace_bytes(int B, long long A);
 int effdet_nms(const float* boxes, const float* score, float threshold, float iou_threshold, int* out_idx,
                int* out_count, void* workspace, long long workspace_bytes, int B, long long A,
