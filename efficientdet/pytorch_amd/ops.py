@@ -483,7 +483,8 @@ class _TailBatch:
 
 
 UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'      # A/B switch: 0 = every tail job is its own launch
-TAIL_KEEP_BYTES = int(os.environ.get('EFFDET_TAIL_KEEP_MB', '256')) << 20  # flush early once the deferred jobs pin this much workspace
+TAIL_KEEP_BYTES = int(os.environ.get('EFFDET_TAIL_KEEP_MB', '2048')) << 20  # flush early once the deferred jobs pin this much workspace (256 MB split the
+# D0 head's ten unpacks over three launches: 515 -> 704 us of tail time per step; the chains of few jobs do not fill the GPU)
 
 
 def _cur_batch():
