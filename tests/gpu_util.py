@@ -23,3 +23,23 @@ def assert_close_scale(got, ref, tol, what=''):
     assert bool(torch.isfinite(got).all()), what
     err = float((got - ref).abs().max()); scale = float(ref.abs().max()) + 1e-30
     assert err <= tol * scale, '%s: max abs err %g > %g * ref max %g' % (what, err, tol, scale)
+
+
+def unmatched_detections(got, ref, score_tol, box_tol=1e-2):
+    """Compare two detection lists (scores, labels, boxes) as SETS: every reference detection must have its own partner with the same
+    label, every box coordinate within box_tol pixels and the score within score_tol (absolute).  -> (number of reference detections
+    without a partner, number of extra detections).  Used where neighbouring scores are closer than conv rounding, so the ORDER of two
+    near-tied boxes is not defined but their membership is."""
+    import numpy as np
+    gs, gl, gb = (np.asarray(t.detach().cpu() if hasattr(t, 'detach') else t) for t in got)
+    rs, rl, rb = (np.asarray(t.detach().cpu() if hasattr(t, 'detach') else t) for t in ref)
+    free = np.ones(len(gs), dtype=bool)
+    missing = 0
+    for i in range(len(rs)):
+        ok = free & (gl == rl[i]) & (np.abs(gs - rs[i]) <= score_tol) & (np.abs(gb - rb[i]).max(axis=1) <= box_tol if len(gs) else free)
+        j = np.nonzero(ok)[0]
+        if len(j):
+            free[j[np.argmin(np.abs(gs[j] - rs[i]))]] = False
+        else:
+            missing += 1
+    return missing, int(free.sum())

@@ -90,6 +90,24 @@ def test_complete_detection_lists_when_scores_are_separated(golden_dir, case):
         np.testing.assert_allclose(bx.numpy(), g[f'det{b}_boxes'], rtol=1e-4, atol=1e-3)
 
 
+def test_complete_detection_lists_dense(golden_dir):
+    """Oracle == the real reference on the COMPLETE lists of a configs[1]-geometry case that keeps ~100 boxes per image (compared as
+    sets: neighbouring scores are closer than conv rounding, so two near-tied boxes may swap places but not drop out)."""
+    from tests.gpu_util import unmatched_detections
+    g = _load(golden_dir, 'd0_512_dets_dense')
+    net, nc = str(g['network']), int(g['num_classes'])
+    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
+    img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
+    with torch.no_grad():
+        dets = O.detect(sd, net, nc, img, threshold=float(g['threshold']))
+    for b, (s, c, bx) in enumerate(dets):
+        ref = (g[f'det{b}_scores'], g[f'det{b}_labels'], g[f'det{b}_boxes'])
+        assert len(ref[0]) >= 50 and len(s) == len(ref[0])
+        assert unmatched_detections((s, c, bx), ref, score_tol=1e-5) == (0, 0)
+        assert bool((s[:-1] >= s[1:]).all())
+
+
 @pytest.mark.parametrize('case', ['d0_128_train', 'd1_128_train', 'd0_512_train'])                  # last: BASELINE configs[2] geometry
 def test_train_losses_and_grads(golden_dir, case):
     g = _load(golden_dir, case)
