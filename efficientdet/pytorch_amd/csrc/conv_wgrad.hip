@@ -487,6 +487,7 @@ __global__ __launch_bounds__(NW * 64) void conv_wgrad_tr_kernel(const WgradK p) 
 //   Stage = 32 pixels: dz [4 row groups][4 pieces] + x [4][4] pieces of 8 pixels x 128 B = 32 KiB, two stages, two workgroups per
 //   CU (4 waves / SIMD).  Waves 0-3 stage dz (row group w, its four 64-wide pieces), waves 4-7 stage x: one scalar pixel cursor per
 //   wave, four DMA instructions per stage.  LDS image of a piece and the fragment addressing are those of conv_wgrad_tr_kernel.
+template <int ALLR>     // 1: all 24 fragment reads of a K-step issued before its first MFMA (A/B knob EFFDET_WGRAD_SPLIT_ALLR)
 __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradK p) {
   constexpr unsigned OPB = 16384, BUFB = 2 * OPB, RG = 4096;     // operand / stage / row-group (8 pixels x 4 pieces) bytes
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -599,6 +600,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradK p) {
       uint4 bh[2], bl[2];
 #pragma unroll
       for (int b = 0; b < 2; ++b) { bh[b] = frag(b_addr[b] + cur); bl[b] = frag(b_addr[2 + b] + cur); }
+      if constexpr (ALLR) {
+        uint4 ah[2][2], al[2][2];
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi)
+#pragma unroll
+          for (int a = 0; a < 2; ++a) { ah[gi][a] = frag(a_addr[gi][a] + cur); al[gi][a] = frag(a_addr[gi][2 + a] + cur); }
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+              for (int b = 0; b < 2; ++b) WMma<bf16_t>::run(t == 0 ? al[gi][a] : ah[gi][a], t == 1 ? bl[b] : bh[b], acc[gi][a][b]);
+          if (want_bias) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) { WMma<bf16_t>::run(al[gi][a], ones, bsum[gi][a]); WMma<bf16_t>::run(ah[gi][a], ones, bsum[gi][a]); }
+          }
+        }
+      } else {
 #pragma unroll
       for (int gi = 0; gi < 2; ++gi) {
         uint4 ah[2], al[2];
@@ -615,6 +636,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_split_kernel(const WgradK p) {
 #pragma unroll
           for (int a = 0; a < 2; ++a) { WMma<bf16_t>::run(al[a], ones, bsum[gi][a]); WMma<bf16_t>::run(ah[a], ones, bsum[gi][a]); }
         }
+      }
       }
     }
 #pragma unroll
@@ -1333,8 +1355,14 @@ extern "C" int effdet_conv2d_wgrad(const effdet_wgrad_t* p, void* workspace, lon
     }
     const size_t lds4 = (size_t)4 * 128 * 8 * sizeof(uint4);      // 2 stages x (dz 16 KiB + x 16 KiB)
     hipStream_t st4 = (hipStream_t)stream;
-    EFFDET_SET_MAX_LDS(conv_wgrad_split_kernel, lds4);
-    hipLaunchKernelGGL(conv_wgrad_split_kernel, dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(512), lds4, st4, k);
+    // all fragment reads of a K-step ahead of its MFMAs (122 VGPRs instead of 106, still 4 waves / SIMD): +2.5 .. 3.5 % on the
+    // 256-channel head shapes (342 -> 355, 353 -> 362 TFLOP/s standalone), -2.5 % on 64 -> 256 -- so by input width (A/B: env 0 / 1)
+    static const int allr_env = getenv("EFFDET_WGRAD_SPLIT_ALLR") ? atoi(getenv("EFFDET_WGRAD_SPLIT_ALLR")) : -1;
+    const int allr = allr_env >= 0 ? allr_env : (p->Cin >= 128 ? 1 : 0);
+    EFFDET_SET_MAX_LDS(conv_wgrad_split_kernel<0>, lds4);
+    EFFDET_SET_MAX_LDS(conv_wgrad_split_kernel<1>, lds4);
+    if (allr) hipLaunchKernelGGL(conv_wgrad_split_kernel<1>, dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(512), lds4, st4, k);
+    else hipLaunchKernelGGL(conv_wgrad_split_kernel<0>, dim3((unsigned)(k.ntiles * k.jtiles * splits)), dim3(512), lds4, st4, k);
     EFFDET_CHECK_LAUNCH();
     if (p->dw) {
       long long g = (nalg / 4 + 255) / 256; if (g < 1) g = 1; if (g > 4096) g = 4096;
