@@ -364,8 +364,8 @@ def main():
     d0_512 = a.network == 'efficientdet-d0' and a.size == 512
 
     MODE_NOTE = {
-        'f32_bf16x3': 'fp32 storage, bf16x3 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): outputs within 3e-4 of tensor scale, '
-                      'losses / gradient norms within 1e-3 of the real reference (tests/test_gpu_model.py) -- the parity-qualified headline mode',
+        'f32_bf16x3': 'fp32 storage, bf16x3 MFMA products (hi*hi + hi*lo + lo*hi, fp32 accumulate): class probabilities within 1e-3 element-relative, '
+                      'box deltas / taps 2.5e-3, losses / gradient norms within 1e-3 of the real reference (tests/test_gpu_model.py) -- the parity-qualified headline mode',
         'f32': 'fp32 storage, exact-fp32 MFMA products (v_mfma_f32_16x16x4_f32): the strict parity mode (1e-3 element-relative)',
         'bf16': 'bf16 storage + bf16 MFMA products: throughput mode, gated at 2.5e-2 of tensor scale (10 % D4) -- NOT a parity mode',
     }
