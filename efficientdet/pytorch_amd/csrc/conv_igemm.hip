@@ -370,6 +370,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     for (int kt = 0; kt < nk; ++kt) {
       const int c = kt % NS;
       loadsp(c, f);
+      // (round 4: a sched_barrier here -- all 12 fragment reads ahead of the 24 MFMAs, 108 instead of 94 VGPRs -- measured +-0:
+      //  373 / 369 vs 373-378 / 365 TFLOP/s on the tower forward / data gradient, 27.65-27.70 ms/step either way)
       mmasp(f);
       if (kt + 1 < nk) {
         wait_tile(issued - (kt + 2));      // tile kt+1 has landed (NS == 2: issued one whole K-step ago; NS == 4: three) ...
