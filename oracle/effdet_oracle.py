@@ -114,12 +114,15 @@ def backbone_blocks(network):
 # --------------------------------------------------------------------------
 
 def make_state_dict(network='efficientdet-d0', num_classes=80, W_bifpn=None, D_bifpn=None,
-                    seed=0, randomize_bn=True):
+                    seed=0, randomize_bn=True, bn2_gain=1.0):
     """Deterministic weights shared by oracle, reference (via load_state_dict) and HIP path.
     Conv weights follow the reference's own init N(0, sqrt(2/(k*k*Cout)))
     (models/efficientdet.py:47-53); BN statistics/affine, biases and fusion weights are randomised
     mildly so every term of the arithmetic is exercised (the reference's defaults of 0/1 would
-    hide bugs).  Key set == reference ``EfficientDet(...).state_dict()`` (checked in make_golden)."""
+    hide bugs).  Key set == reference ``EfficientDet(...).state_dict()`` (checked in make_golden).
+    ``bn2_gain`` scales the affine weight of every MBConv project BN: the reference's fan-out init makes the signal grow from block
+    to block, and over the 45 blocks of B6 the loss lands at ~50 where the reference's own gradients move by 1e-3 under a 3e-7
+    input scaling (tools/flip_sensitivity.py) -- the D6 fixtures use 0.5 so that they test kernels, not chaos."""
     cfg = EFFICIENTDET[network]
     W = cfg['W_bifpn'] if W_bifpn is None else W_bifpn
     D = cfg['D_bifpn'] if D_bifpn is None else D_bifpn
@@ -161,6 +164,8 @@ def make_state_dict(network='efficientdet-d0', num_classes=80, W_bifpn=None, D_b
         conv(p + '_se_expand', b['cexp'], b['cse'], 1, bias=True)
         conv(p + '_project_conv', b['cout'], b['cexp'], 1)
         bn(p + '_bn2', b['cout'])
+        if bn2_gain != 1.0:
+            sd[p + '_bn2.weight'] = sd[p + '_bn2.weight'] * bn2_gain
     # dead tensors that exist in the reference state_dict but are never executed
     conv('backbone._conv_head', head_c, blocks[-1]['cout'], 1)
     bn('backbone._bn1', head_c)
@@ -444,6 +449,12 @@ def detect(sd, network, num_classes, img, threshold=0.01, iou_threshold=0.5, D_b
 def train_losses(sd, network, num_classes, img, annots, D_bifpn=None, drop_masks=None, keep=None):
     cls, reg, anc = forward_raw(sd, network, num_classes, img, D_bifpn, drop_masks, keep)
     return focal_loss(cls, reg, anc, annots)
+
+
+def golden_state_dict(g):
+    """The state dict a tests/golden/*.npz fixture was produced with (network, num_classes, seed and, when present, bn2_gain)."""
+    return make_state_dict(str(g['network']), int(g['num_classes']), seed=int(g['seed']),
+                           bn2_gain=float(g['bn2_gain']) if 'bn2_gain' in getattr(g, 'files', g) else 1.0)
 
 
 def synthetic_batch(B, S, seed=1, max_boxes=8, num_classes=80):

@@ -94,8 +94,8 @@ def taps_from_reference(m, img):
     return taps, hooks
 
 
-def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=True, seed=0, dets=True):
-    sd = O.make_state_dict(network, num_classes, seed=seed)
+def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=True, seed=0, dets=True, bn2_gain=1.0):
+    sd = O.make_state_dict(network, num_classes, seed=seed, bn2_gain=bn2_gain)
     m = build_ref(EfficientDet, network, num_classes, sd, is_training=False, threshold=threshold)
     m.eval()
     img, _ = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
@@ -109,7 +109,7 @@ def case_eval(EfficientDet, name, network, num_classes, B, S, threshold, full=Tr
         h_.remove()
     with torch.no_grad():                                # the reference only post-processes image 0 (Q8)
         dets = [m(img[b:b + 1]) for b in range(B)] if dets else []
-    d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed, threshold=threshold,
+    d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed, threshold=threshold, bn2_gain=bn2_gain,
              anchors_sha256=sha(anc.numpy()), anchors_first=anc[0, :4].numpy(), anchors_last=anc[0, -4:].numpy(),
              cls_summary=summary(cls), reg_summary=summary(reg), cls_sample=sample(cls, 4096), reg_sample=sample(reg, 4096))
     if full:
@@ -208,8 +208,8 @@ def case_dets_dense(EfficientDet, name, network, num_classes, B, S, gain=0.5, se
     print(name, 'threshold', thr, 'candidates', [int(d[f'det{b}_ncand']) for b in range(B)], 'kept', [len(x[0]) for x in dets])
 
 
-def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_last=True, drop_connect=0.0):
-    sd = O.make_state_dict(network, num_classes, seed=seed)
+def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_last=True, drop_connect=0.0, nsample=64, bn2_gain=1.0):
+    sd = O.make_state_dict(network, num_classes, seed=seed, bn2_gain=bn2_gain)
     m = build_ref(EfficientDet, network, num_classes, sd, is_training=True)
     m.train(); m.is_training = True; m.freeze_bn()
     img, ann = O.synthetic_batch(B, S, seed=1, num_classes=num_classes)
@@ -236,7 +236,7 @@ def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_las
             torch.rand = real_rand
     (cl.mean() + rl.mean()).backward()
     d = dict(network=network, num_classes=num_classes, B=B, S=S, seed=seed,
-             cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), annots=ann.numpy())
+             cls_loss=cl.detach().numpy(), reg_loss=rl.detach().numpy(), annots=ann.numpy(), grad_nsample=nsample, bn2_gain=bn2_gain)
     if drop_connect:
         _, blocks, _, _ = O.backbone_blocks(network)
         skip_idx = [i for i, b in enumerate(blocks) if b['skip']]
@@ -250,7 +250,7 @@ def case_train(EfficientDet, name, network, num_classes, B, S, seed=0, empty_las
     for k, p in m.named_parameters():
         if p.grad is None:
             dead.append(k); continue
-        d['grad_' + k + '_sample'] = sample(p.grad, 64)
+        d['grad_' + k + '_sample'] = sample(p.grad, nsample)
         d['grad_' + k + '_summary'] = summary(p.grad)
     d['dead_params'] = np.array(dead)
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **d)
@@ -279,9 +279,22 @@ CASES = {
     'd0_128_train': lambda E: case_train(E, 'd0_128_train', 'efficientdet-d0', 20, 3, 128),
     'd0_512_eval': lambda E: case_eval(E, 'd0_512_eval', 'efficientdet-d0', 80, 1, 512, threshold=0.6, full=False),
     'd4_256_eval': lambda E: case_eval(E, 'd4_256_eval', 'efficientdet-d4', 4, 1, 256, threshold=0.5, full=False),
+    # forward (eval) fixtures for every other model family (d7 = d6's architecture): head outputs + stage-boundary taps, forward only
+    'd1_128_eval': lambda E: case_eval(E, 'd1_128_eval', 'efficientdet-d1', 6, 1, 128, threshold=0.5, full=False, dets=False),
+    'd2_128_eval': lambda E: case_eval(E, 'd2_128_eval', 'efficientdet-d2', 5, 1, 128, threshold=0.5, full=False, dets=False),
+    'd3_128_eval': lambda E: case_eval(E, 'd3_128_eval', 'efficientdet-d3', 4, 1, 128, threshold=0.5, full=False, dets=False),
+    'd5_128_eval': lambda E: case_eval(E, 'd5_128_eval', 'efficientdet-d5', 3, 1, 128, threshold=0.5, full=False, dets=False),
+    'd6_128_eval': lambda E: case_eval(E, 'd6_128_eval', 'efficientdet-d6', 3, 1, 128, threshold=0.5, full=False, dets=False, bn2_gain=0.5),
     'd1_128_train': lambda E: case_train(E, 'd1_128_train', 'efficientdet-d1', 6, 2, 128),
     # the BASELINE.json geometries themselves: configs[2] = D0 train @512 with every parameter gradient,
     # configs[4] = D4 @1024 (80 classes, the COCO shape both are quoted on)
+    # every other model family of the reference's table (train.py / models/efficientdet.py MODEL_MAP): d7 is d6's architecture at
+    # another input size, so d6 covers both
+    'd2_128_train': lambda E: case_train(E, 'd2_128_train', 'efficientdet-d2', 5, 2, 128, nsample=16),
+    'd3_128_train': lambda E: case_train(E, 'd3_128_train', 'efficientdet-d3', 4, 2, 128, nsample=16),
+    'd5_128_train': lambda E: case_train(E, 'd5_128_train', 'efficientdet-d5', 3, 2, 128, nsample=16),
+    'd6_128_train': lambda E: case_train(E, 'd6_128_train', 'efficientdet-d6', 3, 2, 128, nsample=16, bn2_gain=0.5),
+    'd3_256_train': lambda E: case_train(E, 'd3_256_train', 'efficientdet-d3', 4, 2, 256, nsample=16),
     'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),
     'd4_1024_eval': lambda E: case_eval(E, 'd4_1024_eval', 'efficientdet-d4', 80, 1, 1024, threshold=0.6, full=False, dets=False),
     'd0_128_dets_separated': lambda E: case_dets_separated(E, 'd0_128_dets_separated', 'efficientdet-d0', 20, 2, 128),

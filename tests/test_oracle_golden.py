@@ -16,6 +16,13 @@ def _load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name + '.npz'), allow_pickle=False)
 
 
+# one train-mode golden per model family of the reference's table (d7 is d6's architecture at another input size); the last is
+# BASELINE configs[2]'s geometry
+# forward fixtures: every family at 128^2, BASELINE configs[1] (D0 @512) and configs[4] (D4 @1024) geometries
+EVAL_CASES = ['d0_128_eval', 'd1_128_eval', 'd2_128_eval', 'd3_128_eval', 'd5_128_eval', 'd6_128_eval', 'd0_512_eval', 'd4_256_eval', 'd4_1024_eval']
+TRAIN_CASES = ['d0_128_train', 'd1_128_train', 'd2_128_train', 'd3_128_train', 'd5_128_train', 'd6_128_train', 'd0_512_train']
+
+
 def _sample(t, n):
     f = t.detach().reshape(-1)
     idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).long()
@@ -35,11 +42,11 @@ def test_anchors_bit_exact(golden_dir):
         np.testing.assert_array_equal(a[0, :18], g[f'head_{H}x{W}'])
 
 
-@pytest.mark.parametrize('case', ['d0_128_eval', 'd0_512_eval', 'd4_256_eval', 'd4_1024_eval'])     # last: BASELINE configs[4] geometry
+@pytest.mark.parametrize('case', EVAL_CASES)
 def test_eval_forward_matches_reference(golden_dir, case):
     g = _load(golden_dir, case)
     net, nc, B, S = str(g['network']), int(g['num_classes']), int(g['B']), int(g['S'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     img, _ = O.synthetic_batch(B, S, seed=1, num_classes=nc)
     with torch.no_grad():
         cls, reg, anc, taps = O.forward_raw(sd, net, nc, img, taps=True)
@@ -61,7 +68,7 @@ def test_nms_and_detections(golden_dir, case):
     keep = O.nms_greedy(torch.from_numpy(g['nms_boxes']), torch.from_numpy(g['nms_scores']), 0.5)
     np.testing.assert_array_equal(keep.numpy(), g['nms_keep'])
     net, nc, B, S = str(g['network']), int(g['num_classes']), int(g['B']), int(g['S'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     img, _ = O.synthetic_batch(B, S, seed=1, num_classes=nc)
     with torch.no_grad():
         dets = O.detect(sd, net, nc, img, threshold=float(g['threshold']))
@@ -78,7 +85,7 @@ def test_complete_detection_lists_when_scores_are_separated(golden_dir, case):
     """Oracle == the real reference on every score / label / box of a case with well-separated candidate scores."""
     g = _load(golden_dir, case)
     net, nc = str(g['network']), int(g['num_classes'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
     img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
     with torch.no_grad():
@@ -96,7 +103,7 @@ def test_complete_detection_lists_dense(golden_dir):
     from tests.gpu_util import unmatched_detections
     g = _load(golden_dir, 'd0_512_dets_dense')
     net, nc = str(g['network']), int(g['num_classes'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
     img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
     with torch.no_grad():
@@ -108,12 +115,13 @@ def test_complete_detection_lists_dense(golden_dir):
         assert bool((s[:-1] >= s[1:]).all())
 
 
-@pytest.mark.parametrize('case', ['d0_128_train', 'd1_128_train', 'd0_512_train'])                  # last: BASELINE configs[2] geometry
+@pytest.mark.parametrize('case', TRAIN_CASES)
 def test_train_losses_and_grads(golden_dir, case):
     g = _load(golden_dir, case)
     net, nc, B, S = str(g['network']), int(g['num_classes']), int(g['B']), int(g['S'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     dead = set(str(x) for x in g['dead_params'])
+    NS = int(g['grad_nsample']) if 'grad_nsample' in g.files else 64
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items()
               if v.is_floating_point() and 'running_' not in k}
     live = dict(sd); live.update(params)
@@ -132,7 +140,7 @@ def test_train_losses_and_grads(golden_dir, case):
         got = p.grad.double()
         l2 = float((got * got).sum().sqrt())
         assert abs(l2 - ref[2]) <= 2e-3 * max(ref[2], 1e-12) + 1e-9, (k, l2, ref[2])
-        np.testing.assert_allclose(_sample(p.grad, 64), g['grad_' + k + '_sample'],
+        np.testing.assert_allclose(_sample(p.grad, NS), g['grad_' + k + '_sample'],
                                    rtol=5e-3, atol=1e-4 * max(ref[2], 1e-9), err_msg=k)
         checked += 1
     assert checked > 100

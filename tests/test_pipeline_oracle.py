@@ -49,7 +49,7 @@ def test_oracle_reproduces_reference_drop_connect_golden(golden_dir):
     Bernoulli masks injected (models/utils.py:79-90, models/efficientnet.py:98-101)."""
     g = np.load(os.path.join(golden_dir, 'd0_128_dropconnect.npz'), allow_pickle=False)
     net, nc = str(g['network']), int(g['num_classes'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
     masks = {int(i): torch.from_numpy(m) for i, m in zip(g['drop_blocks'], g['drop_masks'])}
     keep = {int(i): float(k) for i, k in zip(g['drop_blocks'], g['drop_keep'])}

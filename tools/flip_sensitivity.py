@@ -6,7 +6,9 @@ through a DISCONTINUITY of the network (a head ReLU whose pre-activation is ~1e-
 smooth-L1 switch at |d| = 1/9) falling the other way.  Prints, per perturbation, the tensors whose norm moved by > 1e-5 relative to
 the unperturbed run, and writes the per-tensor MAXIMUM over the perturbations to tests/golden/<case>_flipsens.npz -- the measured
 instability of the REFERENCE arithmetic itself, which tests/test_gpu_model.py adds to the 1e-3 gate of exactly those tensors.
-    python tools/flip_sensitivity.py d1_128_train [n=12] [--write]"""
+    python tools/flip_sensitivity.py d1_128_train [n=12] [--write] [--eps=3e-7] [--noise]
+--eps: the perturbation bound; --noise: an independent factor (1 + eps u), u ~ U(-1, 1), per image ELEMENT instead of one scale for
+the image (what an arithmetic with a per-operand rounding of eps does to the first layer); neither is written to the golden."""
 import os
 import sys
 
@@ -21,11 +23,11 @@ from oracle import effdet_oracle as O      # noqa: E402
 def norms(g, scale):
     net, nc = str(g['network']), int(g['num_classes'])
     dead = set(str(x) for x in g['dead_params'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     params = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running_' not in k and k not in dead}
     live = dict(sd); live.update(params)
     img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
-    cl, rl = O.train_losses(live, net, nc, img * scale, torch.from_numpy(g['annots']))
+    cl, rl = O.train_losses(live, net, nc, img * scale, torch.from_numpy(g['annots']))       # scale: a float or a tensor like img
     (cl.mean() + rl.mean()).backward()
     return {k: float(p.grad.double().norm()) for k, p in params.items()}
 
@@ -38,9 +40,17 @@ def main():
     base = norms(g, 1.0)
     worst = {k: 0.0 for k in base}
     rng = np.random.RandomState(0)
+    bound = ([float(a[6:]) for a in sys.argv if a.startswith('--eps=')] or [3e-7])[0]
+    noise = '--noise' in sys.argv
+    assert not ('--write' in sys.argv and (noise or bound != 3e-7)), 'the golden holds the 3e-7 scaling only'
     for i in range(n):
-        eps = float(rng.uniform(-3e-7, 3e-7))
-        cur = norms(g, 1.0 + eps)
+        eps = float(rng.uniform(-bound, bound))
+        if noise:
+            B, S = int(g['B']), int(g['S'])
+            gen = torch.Generator().manual_seed(100 + i)
+            cur = norms(g, 1.0 + bound * (2.0 * torch.rand(B, 3, S, S, generator=gen) - 1.0))
+        else:
+            cur = norms(g, 1.0 + eps)
         moved = sorted(((abs(cur[k] - base[k]) / max(base[k], 1e-300), k) for k in base), reverse=True)
         for r, k in moved:
             worst[k] = max(worst[k], r)

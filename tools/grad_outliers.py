@@ -33,7 +33,7 @@ for case in cases:
         for fused in (True, False):
             Fn.SE_FUSED = fused
             m = EfficientDet(nc, network=net, W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'], compute_dtype=torch.float32, f32_arith=arith)
-            m.load_state_dict(O.make_state_dict(net, nc, seed=int(g['seed']))); m.backbone.drop_connect_rate = 0.0
+            m.load_state_dict(O.golden_state_dict(g)); m.backbone.drop_connect_rate = 0.0
             m = m.cuda(); m.train(); m.is_training = True; m.freeze_bn()
             img, _ = O.synthetic_batch(int(g['B']), int(g['S']), seed=1, num_classes=nc)
             cl, rl = m([img.cuda(), torch.from_numpy(g['annots']).cuda()]); (cl.mean() + rl.mean()).backward(); torch.cuda.synchronize()

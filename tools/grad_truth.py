@@ -22,7 +22,7 @@ from oracle import effdet_oracle as O      # noqa: E402
 def f64_norms(case):
     g = np.load(os.path.join(ROOT, 'tests', 'golden', case + '.npz'), allow_pickle=False)
     net, nc = str(g['network']), int(g['num_classes'])
-    sd = O.make_state_dict(net, nc, seed=int(g['seed']))
+    sd = O.golden_state_dict(g)
     dead = set(str(x) for x in g['dead_params'])
     params = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running_' not in k and k not in dead}
     live = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
