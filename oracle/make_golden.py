@@ -294,7 +294,6 @@ CASES = {
     'd3_128_train': lambda E: case_train(E, 'd3_128_train', 'efficientdet-d3', 4, 2, 128, nsample=16),
     'd5_128_train': lambda E: case_train(E, 'd5_128_train', 'efficientdet-d5', 3, 2, 128, nsample=16),
     'd6_128_train': lambda E: case_train(E, 'd6_128_train', 'efficientdet-d6', 3, 2, 128, nsample=16, bn2_gain=0.5),
-    'd3_256_train': lambda E: case_train(E, 'd3_256_train', 'efficientdet-d3', 4, 2, 256, nsample=16),
     'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),
     'd4_1024_eval': lambda E: case_eval(E, 'd4_1024_eval', 'efficientdet-d4', 80, 1, 1024, threshold=0.6, full=False, dets=False),
     'd0_128_dets_separated': lambda E: case_dets_separated(E, 'd0_128_dets_separated', 'efficientdet-d0', 20, 2, 128),
