@@ -292,6 +292,7 @@ CASES = {
     # another input size, so d6 covers both
     'd2_128_train': lambda E: case_train(E, 'd2_128_train', 'efficientdet-d2', 5, 2, 128, nsample=16),
     'd3_128_train': lambda E: case_train(E, 'd3_128_train', 'efficientdet-d3', 4, 2, 128, nsample=16),
+    'd4_128_train': lambda E: case_train(E, 'd4_128_train', 'efficientdet-d4', 4, 2, 128, nsample=16),
     'd5_128_train': lambda E: case_train(E, 'd5_128_train', 'efficientdet-d5', 3, 2, 128, nsample=16),
     'd6_128_train': lambda E: case_train(E, 'd6_128_train', 'efficientdet-d6', 3, 2, 128, nsample=16, bn2_gain=0.5),
     'd0_512_train': lambda E: case_train(E, 'd0_512_train', 'efficientdet-d0', 80, 2, 512, empty_last=False),

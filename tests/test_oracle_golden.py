@@ -20,7 +20,7 @@ def _load(golden_dir, name):
 # BASELINE configs[2]'s geometry
 # forward fixtures: every family at 128^2, BASELINE configs[1] (D0 @512) and configs[4] (D4 @1024) geometries
 EVAL_CASES = ['d0_128_eval', 'd1_128_eval', 'd2_128_eval', 'd3_128_eval', 'd5_128_eval', 'd6_128_eval', 'd0_512_eval', 'd4_256_eval', 'd4_1024_eval']
-TRAIN_CASES = ['d0_128_train', 'd1_128_train', 'd2_128_train', 'd3_128_train', 'd5_128_train', 'd6_128_train', 'd0_512_train']
+TRAIN_CASES = ['d0_128_train', 'd1_128_train', 'd2_128_train', 'd3_128_train', 'd4_128_train', 'd5_128_train', 'd6_128_train', 'd0_512_train']
 
 
 def _sample(t, n):
