@@ -351,7 +351,13 @@ def main():
         backend = os.environ.get('EFFDET_BENCH_BACKEND', 'nccl')                             # 'nccl' IS RCCL on ROCm
         if backend == 'nccl' and not a.no_ddp_graph and not a.no_graph and not a.torch_optim:
             # pre-flight, BEFORE this job owns a communicator: can this box capture + replay an RCCL collective inside a hipGraph?
-            ok, probe_note = ddp.rccl_graph_probe(local)
+            # (N > 1: the ranks' probe children form their own N-rank group next to the job's port -- the real xGMI all-reduce is what
+            #  gets captured, not a single-rank copy)
+            if world > 1:
+                ok, probe_note = ddp.rccl_graph_probe(local, rank=rank, world_size=world,
+                                                      port=ddp.probe_port(os.environ.get('MASTER_PORT', '29500')))
+            else:
+                ok, probe_note = ddp.rccl_graph_probe(local)
         else:
             ok, probe_note = False, 'not probed (%s)' % ('backend %s' % backend if backend != 'nccl' else 'graph capture disabled by flag')
         if a.ddp_single:

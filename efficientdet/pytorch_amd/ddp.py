@@ -60,38 +60,54 @@ with torch.cuda.stream(side):
     for _ in range(3):
         dist.all_reduce(x)
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+x.fill_(1.0); torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):      # (the watchdog thread polls events: see graph.py)
     y = x * 2.0; dist.all_reduce(y); z = y + 1.0
 for _ in range(3):
     g.replay()
 torch.cuda.synchronize()
-ok = bool((z == 3.0).all())
+ok = bool((z == 2.0 * dist.get_world_size() + 1.0).all())
+dist.all_reduce(x); torch.cuda.synchronize()          # every rank is past its replays before any rank leaves (peers read each other's buffers)
 print('RCCL_CAPTURE_' + ('OK' if ok else 'WRONG'), flush=True)
 os._exit(0)        # the verdict is out; skip the teardown (destroying a group whose collectives live in a graph may abort)
 """
 
 
-def rccl_graph_probe(device_index, timeout=180):
-    """Can an RCCL collective be captured into a hipGraph and replayed on this box with this torch / RCCL build?  Answered in a
-    THROW-AWAY child process (its own world_size = 1 'nccl' group on `device_index`): a failed capture leaves a process with an
-    invalidated stream and possibly a half-issued collective, which is not recoverable -- so the decision between the captured
-    DDP step and eager launches is taken here, before the real job has put any collective in flight.  -> (ok, detail)."""
+def rccl_graph_probe(device_index, timeout=180, rank=0, world_size=1, port=None):
+    """Can an RCCL collective be captured into a hipGraph and replayed on this box with this torch / RCCL build?  Answered in
+    THROW-AWAY child processes: a failed capture leaves a process with an invalidated stream and possibly a half-issued collective,
+    which is not recoverable -- so the decision between the captured DDP step and eager launches is taken here, before the real job
+    has put any collective in flight.  world_size = 1: one child with its own single-rank 'nccl' group on `device_index`.
+    world_size = N (every rank of the job calls this at the same time with ITS rank and the SAME `port`): the N children form their own
+    N-rank group on that port, so what is captured and replayed is the real multi-GPU all-reduce over xGMI, not the single-rank copy.
+    A child that fails, hangs or times out makes its parent answer False; the callers must still agree on the minimum over ranks
+    (bench.py does, with the job's own first all-reduce).  -> (ok, detail)"""
     import socket
     import subprocess
     import sys
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    if port is None:
+        if world_size != 1:
+            raise ValueError('a multi-rank probe needs one rendezvous port shared by all ranks')
+        s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = {k: v for k, v in os.environ.items() if not k.startswith(('TORCHELASTIC_', 'GROUP_', 'ROLE_', 'LOCAL_WORLD'))}
-    env.update(RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), TORCH_NCCL_ASYNC_ERROR_HANDLING='0')
+    env.update(RANK=str(int(rank)), LOCAL_RANK=str(int(device_index)), WORLD_SIZE=str(int(world_size)), MASTER_ADDR='127.0.0.1',
+               MASTER_PORT=str(int(port)), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+               TORCH_NCCL_ASYNC_ERROR_HANDLING='0')
     try:
         r = subprocess.run([sys.executable, '-c', _PROBE, str(int(device_index))], env=env, capture_output=True, text=True, timeout=timeout)
     except subprocess.TimeoutExpired:
         return False, 'probe timed out after %d s' % timeout
     if 'RCCL_CAPTURE_OK' in r.stdout:
-        return True, 'ok (all-reduce captured into a hipGraph and replayed 3x in a world_size-1 child process)'
+        return True, 'ok (all-reduce captured into a hipGraph and replayed 3x by a world_size-%d group of child processes)' % world_size
     err = [l for l in r.stderr.strip().splitlines() if 'Error' in l or 'error' in l or 'what()' in l]
     return False, 'rc %d: %s' % (r.returncode, (' / '.join(err[:3]) or r.stderr.strip()[-300:])[:600])
+
+
+def probe_port(master_port):
+    """The rendezvous port of a multi-rank probe, derived from the job's own MASTER_PORT (which the launcher's store occupies)."""
+    p = int(master_port)
+    return p + 101 if p + 101 < 65000 else p - 101
 
 
 def wrap_for_capture(model, device_ids=None, bucket_cap_mb=8):

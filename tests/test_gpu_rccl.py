@@ -56,3 +56,17 @@ def test_ddp_step_with_rccl_all_reduce_captured_as_hipgraph(rccl_run):
     # parameters after 14 steps: eager vs 11 warm-ups + 3 replays (the gate of test_graphed_train_step_tracks_eager: AdamW sign noise)
     assert res['graph_param_diff_mean'] < 0.5 * res['lr'] and res['graph_param_diff_max'] <= res['steps'] * 2 * res['lr'] + 1e-6, res
     assert np.isfinite(res['graph_second_batch_loss']) and res['graph_second_batch_loss'] != lg[-1]
+
+
+def test_capture_probe_answers_in_child_processes():
+    """bench.py's pre-flight (ddp.rccl_graph_probe): the single-rank form, and the multi-rank form's rendezvous (the ranks' children meet
+    on a port of their own, RANK / WORLD_SIZE taken from the caller) exercised with the one rank this box has."""
+    sys.path.insert(0, ROOT)
+    from efficientdet.pytorch_amd import ddp
+    ok, note = ddp.rccl_graph_probe(0)
+    assert ok and 'world_size-1' in note, note
+    ok, note = ddp.rccl_graph_probe(0, rank=0, world_size=1, port=ddp.probe_port(_free_port()))
+    assert ok, note
+    # a rank whose peers never show up must come back with a verdict, not hang the job: world_size 2 with nobody at rank 1
+    ok, note = ddp.rccl_graph_probe(0, timeout=20, rank=0, world_size=2, port=_free_port())
+    assert not ok and 'timed out' in note, note

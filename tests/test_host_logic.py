@@ -269,3 +269,13 @@ def test_tail_batch_is_thread_local_and_bounds_pinned_bytes(monkeypatch):
         assert [n for _, n in launched] == [2] and ops._cur_batch().keep == []
         ops._cur_batch().add(L.TAIL_UNPACK, L.UnpackJob(), torch.empty(10))
     assert [n for _, n in launched] == [2, 1]
+
+
+def test_capture_probe_port_and_arguments():
+    """ddp.probe_port: next to the job's MASTER_PORT, never on it, inside the port range; a multi-rank probe without a shared port is refused."""
+    from efficientdet.pytorch_amd import ddp
+    for p in (29500, 1024, 64990, 65535):
+        q = ddp.probe_port(str(p))
+        assert q != p and 1024 <= q < 65536 and abs(q - p) == 101
+    with pytest.raises(ValueError):
+        ddp.rccl_graph_probe(0, rank=1, world_size=2)
