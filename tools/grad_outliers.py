@@ -1,6 +1,6 @@
 """GPU: per-parameter gradient-norm deviations of the HIP path from the real reference's goldens AND from the fp64 oracle
 (tests/golden/<case>_f64norms.npz, tools/grad_truth.py), both parity modes, fused / unfused squeeze-excite backward.
-    python tools/grad_outliers.py [case ...]      -> gpurun_out/grad_outliers.txt"""
+    python tools/grad_outliers.py [case ...]      -> gpurun_out/grad_outliers.txt, gpurun_out/grad_deviations.npz (every tensor)"""
 import os
 import sys
 
@@ -15,6 +15,7 @@ from efficientdet.pytorch_amd import functional as Fn                    # noqa:
 
 cases = sys.argv[1:] or ['d0_128_train', 'd1_128_train', 'd0_512_train']
 lines = []
+dump = {}       # case|arith -> (names, relative gradient-norm deviations from the reference golden)
 
 
 def say(s):
@@ -44,6 +45,8 @@ for case in cases:
                 ref = float(g['grad_' + k + '_summary'][2]); l2 = float(p.grad.double().norm())
                 r64 = abs(l2 - t64[k]) / max(t64[k], 1e-300) if t64 and k in t64 else float('nan')
                 rows.append((abs(l2 - ref) / max(ref, 1e-12), k, ref, r64))
+            if fused:
+                dump['%s|%s' % (case, arith)] = (np.array([r[1] for r in rows]), np.array([r[0] for r in rows]))
             rows.sort(reverse=True)
             say('%s %s se_fused=%d: tensors > 1e-3: %d, > 3e-4: %d, > 1e-4: %d' % (case, arith, fused, sum(r[0] > 1e-3 for r in rows),
                                                                              sum(r[0] > 3e-4 for r in rows), sum(r[0] > 1e-4 for r in rows)))
@@ -53,3 +56,4 @@ Fn.SE_FUSED = True
 d = os.path.join(ROOT, 'gpurun_out')
 if os.path.isdir(d):
     open(os.path.join(d, 'grad_outliers.txt'), 'w').write('\n'.join(lines) + '\n')
+    np.savez(os.path.join(d, 'grad_deviations.npz'), **{k + '|names': v[0] for k, v in dump.items()}, **{k + '|rel': v[1] for k, v in dump.items()})
