@@ -23,6 +23,15 @@ def init_process_group_from_env(backend=None):
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    if backend == 'nccl':
+        # ProcessGroupNCCL's watchdog thread polls the end events of the collectives it tracks.  With the DDP step captured in a
+        # hipGraph, HIP answers such a query with hipErrorCapturedEvent when the event's last record sits in a capture that is still
+        # open ("operation not permitted on an event last recorded in a capturing stream"; CUDA answers the query) -- the watchdog
+        # then throws, and by default the exception is re-thrown into std::terminate: one bench.py --ddp-single run in ~20 died
+        # that way (round 4, right behind the capture).  The query error is not a communication failure; let the watchdog log it
+        # and retire instead of taking the job down.  (graph.GraphedTrainStep also gives it time to retire the warm-up's collectives.)
+        os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
+        os.environ.setdefault('TORCH_NCCL_ENABLE_MONITORING', '0')      # (a retired watchdog has no heartbeat: do not kill the job for that)
     dist.init_process_group(backend=backend, init_method='env://')
 
 
@@ -61,6 +70,7 @@ with torch.cuda.stream(side):
         dist.all_reduce(x)
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
 x.fill_(1.0); torch.cuda.synchronize()
+import time; time.sleep(1.0)     # the watchdog retires the eager collectives before their stream starts capturing (graph.py)
 g = torch.cuda.CUDAGraph()
 with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):      # (the watchdog thread polls events: see graph.py)
     y = x * 2.0; dist.all_reduce(y); z = y + 1.0

@@ -32,6 +32,20 @@ def _build_pending_tables(model):
             prep._build()
 
 
+def _drain_collective_watchdog(seconds=None):
+    """ProcessGroupNCCL's watchdog thread retires finished collectives by polling their end events every ~100 ms.  The warm-up's
+    all-reduces are finished here (device synchronised) but not necessarily RETIRED -- and once the capture below pulls RCCL's stream
+    into capture mode, HIP refuses hipEventQuery on an event whose stream is capturing (`hipErrorCapturedEvent`, "operation not
+    permitted on an event last recorded in a capturing stream") even though the record itself happened before the capture: the
+    watchdog throws and the process aborts.  Seen in about one bench run out of four (round 4).  CUDA answers such a query, which is why
+    the stock eager-warm-up -> capture recipe carries no wait; here the watchdog gets ten of its polling periods to empty its list."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        import os
+        import time
+        time.sleep(float(os.environ.get('EFFDET_WATCHDOG_DRAIN_S', '1.0')) if seconds is None else seconds)     # (0: the A/B that shows the race)
+        torch.cuda.synchronize()
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, images, annotations, warmup=2, clip_fn=None):
         if not images.is_cuda:
@@ -48,6 +62,7 @@ class GraphedTrainStep:
                 self._step()                    # capture must not touch
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        _drain_collective_watchdog()
         _build_pending_tables(model)            # (a table recorded by the warm-up is built here: no allocation / H2D copy under capture)
         self.graph = torch.cuda.CUDAGraph()
         # Under torch.distributed the process group's watchdog THREAD polls the events of earlier collectives (hipEventQuery); in
@@ -122,7 +137,10 @@ class GraphedDetect:
         _build_pending_tables(model)
         self.graph = torch.cuda.CUDAGraph()
         self.thresholds = (float(model.threshold), float(model.iou_threshold))       # baked into the captured launches
-        with torch.cuda.graph(self.graph):
+        # (inside a torch.distributed job the process group's watchdog thread polls events while this capture is open: 'thread_local'
+        #  confines the unsafe-call check to this thread, as in GraphedTrainStep)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local' if dist_on else 'global'):
             self.s, self.l, self.b, self.count = run()
         torch.cuda.synchronize()
 

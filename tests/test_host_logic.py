@@ -279,3 +279,25 @@ def test_capture_probe_port_and_arguments():
         assert q != p and 1024 <= q < 65536 and abs(q - p) == 101
     with pytest.raises(ValueError):
         ddp.rccl_graph_probe(0, rank=1, world_size=2)
+
+
+def test_nccl_init_keeps_a_watchdog_query_error_from_killing_the_job(monkeypatch):
+    """ddp.init_process_group_from_env('nccl'): the watchdog's spurious hipErrorCapturedEvent (captured DDP step) must not be re-thrown
+    into std::terminate, and a retired watchdog must not trip the heartbeat monitor; explicit user settings win."""
+    import torch.distributed as dist
+    from efficientdet.pytorch_amd import ddp
+    calls = []
+    monkeypatch.setattr(dist, 'is_initialized', lambda: False)
+    monkeypatch.setattr(dist, 'init_process_group', lambda **kw: calls.append(kw))
+    for k in ('TORCH_NCCL_RETHROW_CUDA_ERRORS', 'TORCH_NCCL_ENABLE_MONITORING', 'MASTER_ADDR', 'MASTER_PORT'):
+        monkeypatch.delenv(k, raising=False)
+    ddp.init_process_group_from_env('nccl')
+    assert os.environ['TORCH_NCCL_RETHROW_CUDA_ERRORS'] == '0' and os.environ['TORCH_NCCL_ENABLE_MONITORING'] == '0'
+    assert calls == [dict(backend='nccl', init_method='env://')] and os.environ['MASTER_ADDR'] == '127.0.0.1'
+    monkeypatch.setenv('TORCH_NCCL_RETHROW_CUDA_ERRORS', '1')
+    ddp.init_process_group_from_env('nccl')
+    assert os.environ['TORCH_NCCL_RETHROW_CUDA_ERRORS'] == '1'
+    for k in ('TORCH_NCCL_RETHROW_CUDA_ERRORS', 'TORCH_NCCL_ENABLE_MONITORING'):
+        monkeypatch.delenv(k, raising=False)
+    ddp.init_process_group_from_env('gloo')
+    assert 'TORCH_NCCL_RETHROW_CUDA_ERRORS' not in os.environ
