@@ -48,6 +48,7 @@ struct ConvK {
   int cpt;   // chunks per tap (= Cin/CE)
   int act, res_mode, out_f32, vec_ok;
   int out_split;               // y (and a ReLU-mask res) are in the split layout: 32-channel groups of [32 x bf16 hi | 32 x bf16 lo]
+  void* ysplit;                // plain-fp32 convs only: the output values a SECOND time, in the split layout (same row addressing as y)
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   int kord;                    // K walk of the persistent kernel: 0 tap-major, 1 channel-group-major
@@ -447,6 +448,20 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
         char* dst = (char*)p.y + orow * 4 + goff;
         *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
         return;
+      }
+    }
+    if constexpr (SPLIT == 0 && sizeof(T) == 4) {
+      if (p.ysplit) {
+        // exact-fp32 forward whose BACKWARD runs the split-layout bf16x3 kernels ('f32_bwd_bf16x3'): the same values once more as
+        // [32 x bf16 hi | 32 x bf16 lo] groups -- operand of the next layer's weight gradient, ReLU mask of this layer's data gradient.
+        // (two 8-byte stores per lane next to the 16-byte one: +1 write stream of 4 B/element instead of a read + write conversion pass)
+        const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
+        uint2 hi, lo;
+        hi.x = pack2bf(v[0], v[1]); hi.y = pack2bf(v[2], v[3]);
+        lo.x = pack2bf(v[0] - __uint_as_float(hi.x << 16), v[1] - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack2bf(v[2] - __uint_as_float(hi.y << 16), v[3] - __uint_as_float(hi.y & 0xffff0000u));
+        char* dst = (char*)p.ysplit + orow * 4 + goff;
+        *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
       }
     }
     if (p.res_mode != EFFDET_RES_NONE) {
@@ -1200,7 +1215,13 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       if (!p->out_f32 && (p->seg[s].out_off % 32 || p->seg[s].out_bstride % 32)) return EFFDET_EUNSUPPORTED;
     }
   } else if (p->out_f32 && (p->z || p->res_mode != EFFDET_RES_NONE)) return EFFDET_EUNSUPPORTED;
-  k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res;
+  if (p->y_split) {
+    // second, split-layout copy of the output: exact-fp32 convs writing whole 32-channel groups on 128-byte aligned rows, no residual op
+    if (p->dtype != EFFDET_F32 || p->out_f32 || p->res_mode != EFFDET_RES_NONE || p->Cout % 32 || p->ldy % 32) return EFFDET_EUNSUPPORTED;
+    for (int s = 0; s < p->nseg; ++s)
+      if (p->seg[s].out_off % 32 || p->seg[s].out_bstride % 32) return EFFDET_EUNSUPPORTED;
+  }
+  k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res; k.ysplit = p->y_split;
   k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
   k.bc_scale = p->bc_scale; k.bc_shift = p->bc_shift;
   if ((p->bc_scale != nullptr) != (p->bc_shift != nullptr)) return EFFDET_EINVAL;
@@ -1273,7 +1294,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       }
     }
   }
-  if (!p->w_image_stride && pw_eligible(p)) return 20;
+  if (!p->w_image_stride && !p->y_split && pw_eligible(p)) return 20;
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
   if (p->dtype == EFFDET_F32_SPLIT) {

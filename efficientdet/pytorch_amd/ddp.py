@@ -15,21 +15,26 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group_from_env(backend=None):
-    """env:// rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), NCCL(=RCCL) on GPU, gloo on CPU."""
+def init_process_group_from_env(backend=None, for_capture=False):
+    """env:// rendezvous (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), NCCL(=RCCL) on GPU, gloo on CPU.
+
+    for_capture=True -- ONLY for a job that will capture its DDP step as a hipGraph (wrap_for_capture + graph.GraphedTrainStep):
+    ProcessGroupNCCL's watchdog thread polls the end events of the collectives it tracks, and HIP answers such a query with
+    hipErrorCapturedEvent when the event's last record sits in a capture that is still open ("operation not permitted on an event last
+    recorded in a capturing stream"; CUDA answers the query).  The watchdog then throws, and by default the exception is re-thrown into
+    std::terminate: one captured bench run in ~20 died that way (round 4, right behind the capture).  For such a job the two defaults
+    below let the watchdog log the query error and retire instead of taking the job down.  THE PRICE: with the re-throw off and the
+    heartbeat monitor disabled, a real GPU fault, a dead peer or a collective that never completes is no longer turned into an abort by
+    the process group -- the job needs its own hang detection (bench.py runs captured legs in child processes under a timeout and falls
+    back to eager DDP).  Plain eager DDP (for_capture=False, the default) keeps torch's failure detection untouched.
+    Explicit settings in the environment always win."""
     if dist.is_initialized():
         return
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
-    if backend == 'nccl':
-        # ProcessGroupNCCL's watchdog thread polls the end events of the collectives it tracks.  With the DDP step captured in a
-        # hipGraph, HIP answers such a query with hipErrorCapturedEvent when the event's last record sits in a capture that is still
-        # open ("operation not permitted on an event last recorded in a capturing stream"; CUDA answers the query) -- the watchdog
-        # then throws, and by default the exception is re-thrown into std::terminate: one bench.py --ddp-single run in ~20 died
-        # that way (round 4, right behind the capture).  The query error is not a communication failure; let the watchdog log it
-        # and retire instead of taking the job down.  (graph.GraphedTrainStep also gives it time to retire the warm-up's collectives.)
+    if backend == 'nccl' and for_capture:
         os.environ.setdefault('TORCH_NCCL_RETHROW_CUDA_ERRORS', '0')
         os.environ.setdefault('TORCH_NCCL_ENABLE_MONITORING', '0')      # (a retired watchdog has no heartbeat: do not kill the job for that)
     dist.init_process_group(backend=backend, init_method='env://')

@@ -150,7 +150,7 @@ def _t(m):
 class _StemFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, w, gamma, beta, mean, var, pad, dtype, train, link=None):
-        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH_BWD
         if isinstance(img, PackedImages) and (img.map.dtype != dtype or img.map.C != Fn.chunk_elems(dtype)):
             raise RuntimeError('PackedImages were packed for %s / %d channels, the model computes in %s'
                                % (img.map.dtype, img.map.C, dtype))
@@ -164,7 +164,7 @@ class _StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
+        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
         fused = bool(ctx.link and ctx.link.pop('dz_done', False))
         dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()), dy_is_dz=fused)
         ctx.saved = None
@@ -181,7 +181,7 @@ STEM_LINK = os.environ.get('EFFDET_STEM_LINK', '1') == '1'        # A/B switch: 
 class _MBConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blk, dtype, rowscale, buffers, train, *params):
-        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH_BWD
         P = dict(buffers)
         keys = [k for k in _MB_KEYS if not (blk.expand == 1 and k in ('expand.weight', 'bn0.weight', 'bn0.bias'))]
         P.update(dict(zip(keys, params)))
@@ -205,7 +205,7 @@ class _MBConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
+        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
         with ops.unpack_batch():                                   # the node's weight-gradient unpacks leave as one launch
             dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
@@ -222,7 +222,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, nlev, stack, train, *args):
-        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH_BWD
         feats = [Map.of(t) for t in args[:nlev]]
         rest = args[nlev:]
         lw, lb = rest[0:nlev], rest[nlev:2 * nlev]
@@ -241,7 +241,7 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
+        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
         feats, lw, saved_mods, dtype, nlev, stack = ctx.saved
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
@@ -268,7 +268,7 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, num_classes, train, *args):
-        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH_BWD
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
@@ -277,7 +277,7 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
+        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
         saved, cls, dtype = ctx.saved
         dlogit, dr = ops.head_out_bwd(dcls.contiguous().float(), cls, dreg.contiguous().float(), dtype)
         with ops.unpack_batch():
@@ -295,7 +295,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dtype, num_classes, anchors, annots, train, *args):
-        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH
+        ctx.prep, ctx.arith = ops.get_prep(), ops.F32_ARITH_BWD
         p = [Map.of(t) for t in args[:5]]
         HP = dict(zip(_HEAD_KEYS, args[5:]))
         cls, reg, saved = Fn.head_fwd(p, HP, num_classes, dtype, train)
@@ -313,7 +313,7 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gcls, greg):
-        ops.set_f32_arith(ctx.arith); ops.set_prep(ctx.prep)       # this model's arithmetic + parameter arena, whatever ran in between
+        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
         saved, cls, reg, anchors, annots, ws, dtype, dpix, dld = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
         if dpix is not None:
@@ -351,8 +351,11 @@ class EfficientDet(nn.Module):
         self.num_classes = num_classes
         self.compute_dtype = compute_dtype
         # MFMA arithmetic on fp32 storage: 'f32' = exact fp32 products (v_mfma_f32_16x16x4_f32), 'bf16x3' = operands split into
-        # bf16 hi + lo, three bf16 MFMAs per product (~16 mantissa bits; ~2x the fp32 matrix-pipe rate).  Ignored for bf16.
-        assert f32_arith in ('f32', 'bf16x3')
+        # bf16 hi + lo, three bf16 MFMAs per product (~16 mantissa bits; ~2x the fp32 matrix-pipe rate), 'f32_bwd_bf16x3' = every
+        # forward value in exact fp32 (bit for bit the 'f32' forward), only the gradient convolutions in the bf16x3 form.
+        # Ignored for bf16.
+        if f32_arith not in ops.MODEL_ARITH:
+            raise ValueError('f32_arith must be one of %s' % (sorted(ops.MODEL_ARITH),))
         self.f32_arith = f32_arith
         self._prep = {}                                         # (compute dtype, device) -> ops.ParamPrep (batched per-step repacks)
         self._dc = {}                                           # drop_connect generator state (seed, step counter, per-device keep table)
@@ -437,7 +440,7 @@ class EfficientDet(nn.Module):
         bb, dt = self.backbone, self.compute_dtype
         # every forward path starts here: replay (or start recording) this model's batched parameter preparation
         key = (dt, img.device, self.f32_arith)
-        ops.set_f32_arith(self.f32_arith)
+        ops.set_model_arith(self.f32_arith)
         if not self.batched_prep or getattr(self, '_is_replica', False):
             # (replicas of nn.DataParallel are rebuilt every forward with fresh parameter tensors: nothing to record against)
             ops.set_prep(None)

@@ -384,12 +384,13 @@ HEAD_SPLIT = os.environ.get('EFFDET_HEAD_SPLIT', '1') == '1'     # A/B switch: s
 _split_ok = {}
 
 
-def head_uses_split(B, sizes, Wc, dtype):
+def head_uses_split(B, sizes, Wc, dtype, arith=None):
     """bf16x3 arithmetic on fp32 storage: the RetinaHead's activations and gradients live in the SPLIT layout (every 32 channels
     as [32 x bf16 hi | 32 x bf16 lo], same 4 bytes per element) so that the head's convs and weight gradients -- 95 % of the
     step's FLOPs -- read ready-made MFMA operands instead of splitting fp32 values in registers in every K-step.  Needs pyramid
-    levels the split weight-gradient kernel can take (whole 8-pixel runs per row); otherwise the plain-fp32 path stays."""
-    if not (HEAD_SPLIT and dtype == torch.float32 and ops.F32_ARITH == 'bf16x3' and Wc % 32 == 0):
+    levels the split weight-gradient kernel can take (whole 8-pixel runs per row); otherwise the plain-fp32 path stays.
+    arith: the arithmetic asked about (default: the one the launches use now)."""
+    if not (HEAD_SPLIT and dtype == torch.float32 and (arith or ops.F32_ARITH) == 'bf16x3' and Wc % 32 == 0):
         return False
     key = (B, tuple(sizes), Wc)
     if key not in _split_ok:
@@ -397,39 +398,54 @@ def head_uses_split(B, sizes, Wc, dtype):
     return _split_ok[key]
 
 
+def _pyramid_to_split(src_maps, B, sizes, C_, dtype, dev):
+    """A pyramid activation (plain fp32, one tensor per level) -> a fresh flat level-major buffer holding it in the split layout."""
+    _, dst = pyramid_alloc(B, sizes, C_, dtype, dev)
+    for s_, d_ in zip(src_maps, dst):
+        n = s_.B * s_.H * s_.W * s_.C
+        ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(s_.tensor()), ops.C.c_void_p(d_.addr()), ops.C.c_longlong(n), ops.L.stream_ptr()),
+                    'effdet_to_split')
+    return dst
+
+
 def head_fwd(p, HP, num_classes, dtype, train):
     """models/retinahead.py:109-132 for all 5 levels per launch (weights are shared across levels).
     p: 5 Maps; HP: dict of head parameter tensors.  -> classification [B,A,nc] fp32 (probabilities),
-    regression [B,A,4] fp32."""
+    regression [B,A,4] fp32.
+    Arithmetic 'f32_bwd_bf16x3' (forward exact, gradients in the three-product form): the forward below runs on plain fp32
+    activations with exact-fp32 products, and every activation the BACKWARD will read -- the pyramid and the eight tower outputs,
+    operands of the weight gradients and ReLU masks of the data gradients -- is stored a second time in the split layout by the
+    conv that produces it (`ysplit`: the epilogue writes both forms; the plain copy dies with the next layer), so that head_bwd
+    runs the split-layout gradient kernels unchanged."""
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     sizes = [(m.H, m.W) for m in p]
     A = sum(h * w for (h, w) in sizes) * 9
     split = head_uses_split(B, sizes, Wc, dtype)
+    split_bwd = (not split) and train and ops.F32_ARITH_BWD == 'bf16x3' and head_uses_split(B, sizes, Wc, dtype, 'bf16x3')
     pin = p
-    if split:                 # the pyramid once in the split layout: operand of both towers' first conv and of their weight gradients
-        _, pin = pyramid_alloc(B, sizes, Wc, dtype, dev)
-        for src, dst in zip(p, pin):
-            L_ = src.B * src.H * src.W * src.C
-            ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(src.tensor()), ops.C.c_void_p(dst.addr()), ops.C.c_longlong(L_), ops.L.stream_ptr()),
-                        'effdet_to_split')
+    if split or split_bwd:    # the pyramid once in the split layout: operand of both towers' first conv and of their weight gradients
+        pin = _pyramid_to_split(p, B, sizes, Wc, dtype, dev)
     acts = {'cls': [], 'reg': []}
     for tower in ('cls', 'reg'):
-        cur = pin
+        cur = p if split_bwd else pin
         for t in range(4):
             w, b = HP[f'{tower}_convs.{t}.weight'], HP[f'{tower}_convs.{t}.bias']
             _, nxt = pyramid_alloc(B, sizes, 256, dtype, dev)
+            nxs = pyramid_alloc(B, sizes, 256, dtype, dev)[1] if split_bwd else None
             ops.conv2d(cur, ops.pack_weight(w, dtype, x3=split), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
-                       shift=b, act=ACT_RELU, split=split)
-            acts[tower].append(nxt); cur = nxt
+                       shift=b, act=ACT_RELU, split=split, ysplit=nxs)
+            acts[tower].append(nxs if split_bwd else nxt); cur = nxt
+        if split_bwd:
+            acts[tower + '_last'] = cur        # (plain fp32 operand of retina_cls / retina_reg below; not kept for backward)
     cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
     reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
-    ops.conv2d(acts['cls'][3], ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
+    ops.conv2d(acts.pop('cls_last', acts['cls'][3]), ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
                Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
                act=ACT_SIGMOID, out_f32=True, split=split)
-    ops.conv2d(acts['reg'][3], ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
+    ops.conv2d(acts.pop('reg_last', acts['reg'][3]), ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
                Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split)
-    saved = (pin, acts, sizes, HP, num_classes, split) if train else None
+    saved = (pin, acts, sizes, HP, num_classes, split or split_bwd) if train else None
     return cls, reg, saved
 
 

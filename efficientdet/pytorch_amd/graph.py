@@ -109,7 +109,8 @@ class GraphedDetect:
     faulted on the second replay of a captured call, which had kept sort + NMS + gather outside the graph.)
 
         det = GraphedDetect(model, images)            # warm-up + capture
-        det.images.copy_(batch); results = det()      # -> [(scores[K], labels[K] int64, boxes[K,4]) per image], score-descending
+        det.images.copy_(batch); results = det()      # -> [(scores[K], labels[K] int64, boxes[K,4]) per image], score-descending;
+                                                      #    fresh tensors every call (they survive the next replay)
     """
 
     def __init__(self, model, images, warmup=2):
@@ -151,5 +152,8 @@ class GraphedDetect:
                                'captured NMS); build a new GraphedDetect')
         self.graph.replay()
         counts = self.count.tolist()                       # the one device->host sync (the reference syncs too)
-        s, l, b = self.s, self.l, self.b
+        # the graph's output buffers are rewritten by the next replay: hand out COPIES of the kept rows (one clone of the rows up to
+        # the largest count), so an evaluator that accumulates results over batches keeps what it was given -- like model.detect
+        k = max(counts) if counts else 0
+        s, l, b = self.s[:, :k].clone(), self.l[:, :k].clone(), self.b[:, :k].clone()
         return [(s[i, :n], l[i, :n], b[i, :n]) for i, n in enumerate(counts)]

@@ -58,15 +58,33 @@ def _timed(name, flops, fn, note=''):
 # Arithmetic of the MFMA kernels on fp32 STORAGE (process-wide; EfficientDet(..., f32_arith=...) sets it):
 #   'f32'    v_mfma_f32_16x16x4_f32 -- exact fp32 products (the strict parity mode)
 #   'bf16x3' operands split into bf16 hi + lo in registers, 3 bf16 MFMAs per product (~16 mantissa bits), fp32 accumulate
+# F32_ARITH is what the launches issued NOW use; F32_ARITH_BWD is what the autograd nodes recorded by the running forward will
+# switch to in their backward.  A MODEL names the pair (MODEL_ARITH): 'f32' and 'bf16x3' use one arithmetic throughout;
+# 'f32_bwd_bf16x3' computes every forward value -- the (classification, regression, anchors) triple of models/efficientdet.py:64-66,
+# the losses, every ReLU / max-pool / IoU decision the backward depends on -- with exact fp32 products, bit for bit what 'f32'
+# computes, and takes only the GRADIENT convolutions (data + weight gradients) through the three-product bf16 form: their ~1e-5
+# product error lands on gradients whose masks were decided exactly, 100x inside the 1e-3 gradient gate.
 F32_ARITH = 'f32'
+F32_ARITH_BWD = 'f32'
+MODEL_ARITH = {'f32': ('f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3'), 'f32_bwd_bf16x3': ('f32', 'bf16x3')}
 
 
-def set_f32_arith(mode):
-    global F32_ARITH
-    if mode not in ('f32', 'bf16x3'):
+def set_f32_arith(mode, bwd=None):
+    """Arithmetic of the launches from now on (and, unless `bwd` says otherwise, of the backward of nodes recorded from now on)."""
+    global F32_ARITH, F32_ARITH_BWD
+    if mode not in ('f32', 'bf16x3') or (bwd is not None and bwd not in ('f32', 'bf16x3')):
         raise ValueError("f32_arith must be 'f32' or 'bf16x3'")
     old, F32_ARITH = F32_ARITH, mode
+    F32_ARITH_BWD = mode if bwd is None else bwd
     return old
+
+
+def set_model_arith(name):
+    """A model's arithmetic by name (MODEL_ARITH): forward arithmetic now, its backward arithmetic for the nodes it records."""
+    if name not in MODEL_ARITH:
+        raise ValueError('f32_arith must be one of %s' % (sorted(MODEL_ARITH),))
+    fwd, bwd = MODEL_ARITH[name]
+    set_f32_arith(fwd, bwd)
 
 
 def _mma_dtype_code(dtype, K=None, N=None):
@@ -168,7 +186,7 @@ class ParamPrep:
     module is moved (nn.Module._apply).  A lookup miss falls back to the single launch and re-records."""
 
     def __init__(self, f32_arith='f32'):
-        self.f32_arith = f32_arith          # arithmetic of the owner's MFMA launches on fp32 storage (see set_f32_arith)
+        self.f32_arith = f32_arith          # the owner's arithmetic by name (MODEL_ARITH; see set_model_arith)
         self.jobs, self.outs, self.bn_src = {}, {}, {}
         self.table, self.dirty, self.replay = None, False, False
         self._n0 = 0                        # jobs of the first build since the last reset (bounds the table's growth)
@@ -286,7 +304,7 @@ _tls = threading.local()     # .prep: the ParamPrep of the model whose forward /
 def set_prep(p):
     _tls.prep = p
     if p is not None:
-        set_f32_arith(p.f32_arith)          # forward and (through ctx.prep) backward of a model run in ITS arithmetic
+        set_model_arith(p.f32_arith)        # the model's forward arithmetic; its nodes' backward sets theirs (ctx.arith)
 
 
 def get_prep():
@@ -347,14 +365,16 @@ def scale_pack_weight(w_oihw, gate, dtype):
 
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
            res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None,
-           w_image_stride=0):
+           w_image_stride=0, ysplit=None):
     """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
     split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
-    is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed)."""
+    is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed).
+    ysplit (exact-fp32 convs only): Maps addressed like ys that receive the output a second time in the split layout."""
     if isinstance(xs, Map):
         xs, ys = [xs], [ys]
         zs = [zs] if zs is not None else None
         res = [res] if res is not None else None
+        ysplit = [ysplit] if ysplit is not None else None
     d = L.ConvDesc()
     x0, y0 = xs[0], ys[0]
     isx, isy = x0.t.element_size(), y0.t.element_size()
@@ -373,6 +393,12 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
         for y, r in zip(ys, res):
             assert (r.addr() - br) * isy == (y.addr() - base_y) * r.t.element_size() and r.ld == y.ld and r.bstride == y.bstride
         d.res = br
+    d.y_split = None
+    if ysplit is not None:
+        bs = min(q.addr() for q in ysplit)
+        for y, q in zip(ys, ysplit):
+            assert (q.addr() - bs) == (y.addr() - base_y) and q.t.element_size() == isy and q.ld == y.ld and q.bstride == y.bstride
+        d.y_split = bs
     d.scale, d.shift, d.rowscale = (t.data_ptr() if t is not None else None for t in (scale, shift, rowscale))
     d.bc_scale, d.bc_shift = (t.data_ptr() if t is not None else None for t in (bc_scale, bc_shift))     # [B][Cout] fp32, after rowscale, before res
     d.dtype, d.out_f32 = (L.F32_SPLIT if split else _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout)), int(out_f32)

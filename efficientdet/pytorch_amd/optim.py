@@ -135,6 +135,9 @@ class ClipAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        if len(self.param_groups) != 1:         # (before anything is uploaded or counted: a refused step leaves no trace)
+            raise RuntimeError('ClipAdamW honours ONE parameter group (the reference builds one, train.py:266); got %d -- other '
+                               "groups' lr / weight_decay would be silently ignored" % len(self.param_groups))
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -169,9 +172,6 @@ class ClipAdamW(torch.optim.Optimizer):
                 t['g_last'] = ptrs
         self._step += 1
         b1, b2 = g['betas']
-        if len(self.param_groups) != 1:
-            raise RuntimeError('ClipAdamW honours ONE parameter group (the reference builds one, train.py:266); got %d -- other '
-                               "groups' lr / weight_decay would be silently ignored" % len(self.param_groups))
         if torch.cuda.is_current_stream_capturing():
             self._captured = True
             if t['hyper_last'] is None:

@@ -85,6 +85,10 @@ typedef struct {
                              * implicit-GEMM kernels only): image b reads its OWN packed weights at w + b * w_image_stride -- how the
                              * squeeze-excite gate of an MBConv block is applied without a pass over the activations:
                              * W_b = W * diag(gate_b), packed by effdet_scale_pack_weight (models/efficientnet.py:86-95) */
+  void* y_split;            /* optional (dtype EFFDET_F32, no out_f32 / res op, Cout % 32 == 0, ldy / out_off / out_bstride % 32 == 0): the
+                             * output values a second time in the EFFDET_F32_SPLIT layout, addressed like y (same ldy / out_off /
+                             * out_bstride relative to y_split).  An exact-fp32 forward leaves the operands of split-layout bf16x3
+                             * GRADIENT kernels this way: forward values untouched, no conversion pass (models/retinahead.py:109-118) */
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
 /* Per-image 1x1 weights for effdet_conv_t.w_image_stride:  out[b][n][k] = w[n][k] * gate[b][k]  in the packed layout of `dtype`
@@ -542,7 +546,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 6
+#define EFFDET_ABI_VERSION 7
 int effdet_abi_version(void);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@ def main():
         json.dump(res, open(out_path, 'w'))
     dump()
     torch.cuda.set_device(0)
-    ddp.init_process_group_from_env('nccl')
+    ddp.init_process_group_from_env('nccl', for_capture=True)      # stage 3 captures the DDP step
     assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
     res['rccl_version'] = list(torch.cuda.nccl.version())
     # ---- stage 1: a bare RCCL collective on the device

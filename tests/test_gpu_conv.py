@@ -572,3 +572,34 @@ def test_conv_per_image_weights_fold_the_se_gate(dtype, bf16x3, B, H, W, Cin, Co
             ops.conv2d(x2, wpb, y2, Cin=Cin, Cout=Cout, KH=1, KW=1, w_image_stride=stride)
     finally:
         ops.set_f32_arith(old)
+
+
+def test_conv_second_output_in_the_split_layout():
+    """effdet_conv_t.y_split: an exact-fp32 conv writes its output a second time as [32 x bf16 hi | 32 x bf16 lo] groups -- the first
+    output is untouched (bitwise the conv without it) and the second equals effdet_to_split of the first, bit for bit; grouped over
+    pyramid levels like the RetinaHead tower convs that use it ('f32_bwd_bf16x3': exact forward, split-layout gradient kernels)."""
+    from efficientdet.pytorch_amd import functional as Fn, ops
+    torch.manual_seed(3)
+    B, Cin, Cout = 2, 64, 256
+    sizes = [(16, 16), (8, 8), (4, 4)]
+    dev = 'cuda'
+    _, xs = Fn.pyramid_alloc(B, sizes, Cin, torch.float32, dev)
+    for m in xs:
+        Fn.level_tensor(m).normal_()
+    w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
+    b = torch.randn(Cout, device=dev)
+    wp = ops.pack_weight(w, torch.float32)
+    f0, y0 = Fn.pyramid_alloc(B, sizes, Cout, torch.float32, dev)
+    f1, y1 = Fn.pyramid_alloc(B, sizes, Cout, torch.float32, dev)
+    fs, ys = Fn.pyramid_alloc(B, sizes, Cout, torch.float32, dev)
+    kw = dict(Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1, shift=b, act=ops.ACT_RELU)
+    ops.conv2d(xs, wp, y0, **kw)
+    ops.conv2d(xs, wp, y1, ysplit=ys, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(f0, f1)
+    assert torch.equal(fs.view(torch.int32), ops.to_split(f0).view(torch.int32))
+    # refused where the split copy cannot be addressed like y (Cout not whole 32-channel groups) or the arithmetic is not exact fp32
+    w2 = torch.randn(48, Cin, 3, 3, device=dev)
+    _, y2 = Fn.pyramid_alloc(B, sizes, 48, torch.float32, dev); _, s2 = Fn.pyramid_alloc(B, sizes, 48, torch.float32, dev)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(xs, ops.pack_weight(w2, torch.float32), y2, Cin=Cin, Cout=48, KH=3, KW=3, pad_t=1, pad_l=1, ysplit=s2)

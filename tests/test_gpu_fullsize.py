@@ -97,19 +97,21 @@ def test_loss_and_gradients_are_batch_means_at_benchmark_size():
     assert abs(full_loss[0] - lsum[0] / B) <= 1e-4 * abs(full_loss[0]), (full_loss, lsum)
     assert abs(full_loss[1] - lsum[1] / B) <= 1e-4 * abs(full_loss[1]), (full_loss, lsum)
     assert len(full) == 274
-    gmax = max(float(v.norm()) for v in full.values())
-    worst = (0.0, None)
+    worst, bad = (0.0, None), []
     for k, v in full.items():
         d = float((v - acc[k] / B).norm()); n = float(v.norm())
         rel = d / max(n, 1e-30)
-        if rel > worst[0] and d > 1e-6 * gmax:
+        if rel > worst[0]:
             worst = (rel, k)
-        # (same abs + rel gate as the golden gradient test: ReLU / max-pool ties may fall differently in the two runs)
-        assert rel <= 2e-3 or d <= 1e-6 * gmax, (k, rel, d, gmax)
+        # ONE relative clause for every tensor, however small its norm (round 5: the absolute escape `d <= 1e-6 * largest norm` is gone,
+        # as in the golden gradient test): ReLU / max-pool ties may fall differently in the two runs, hence 2e-3 and not 1e-5
+        if rel > 2e-3:
+            bad.append((k, rel, d, n))
+    assert not bad, bad
     print('batch loss %s vs mean of per-image losses %s; worst gradient deviation %s' % (full_loss, [x / B for x in lsum], worst))
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x3', 'f32_bwd_bf16x3'])
 def test_largest_family_at_its_native_size(arith):
     """EfficientDet-D6 (B6 backbone: 45 MBConv blocks, BiFPN 384 x 8, 5-conv heads; D7 is the same network at another size) at
     its own 1408 x 1408, B = 2, train mode: the batch loss is the mean of the two per-image losses, every live gradient is the
@@ -136,18 +138,19 @@ def test_largest_family_at_its_native_size(arith):
             if p.grad is not None:
                 acc[k] += p.grad.double() / B
     assert abs(fl[0] - ls[0]) <= 1e-4 * abs(fl[0]) and abs(fl[1] - ls[1]) <= 1e-4 * abs(fl[1]), (fl, ls)
-    gmax = max(float(v.norm()) for v in full.values())
-    worst = (0.0, None)
+    worst, bad = (0.0, None), []
     # exact fp32: the golden gradient gate; bf16x3 products: B = 2 and B = 1 take other tilings (another rounding of the 2^-17 split
     # operands), so ReLU masks within 1e-5 of zero fall differently in the two runs (tests/test_gpu_model.py, profiles/r04_x3_locate.txt)
     # and every tensor upstream collects them -- measured 9.9e-3 on the stem weight (the end of the backward chain); the stated gate
     # of the deep families, doubled
-    gtol = 2e-3 if arith == 'f32' else 2e-2
+    gtol = 2e-2 if arith == 'bf16x3' else 2e-3      # ('f32_bwd_bf16x3': exact forward, no mask can flip -- the exact mode's gate)
     for k, v in full.items():
         d = float((v - acc[k]).norm()); rel = d / max(float(v.norm()), 1e-30)
-        if rel > worst[0] and d > 1e-6 * gmax:
+        if rel > worst[0]:
             worst = (rel, k)
-        assert rel <= gtol or d <= 1e-6 * gmax, (k, rel, d, gmax)
+        if rel > gtol:                      # (one relative clause, no absolute escape: see the B = 32 test above)
+            bad.append((k, rel, d, float(v.norm())))
+    assert not bad, bad
     print('D6 @1408 B=2 (%s): losses %s vs per-image mean %s; worst gradient deviation %s' % (arith, fl, ls, worst))
 
 

@@ -282,8 +282,9 @@ def test_capture_probe_port_and_arguments():
 
 
 def test_nccl_init_keeps_a_watchdog_query_error_from_killing_the_job(monkeypatch):
-    """ddp.init_process_group_from_env('nccl'): the watchdog's spurious hipErrorCapturedEvent (captured DDP step) must not be re-thrown
-    into std::terminate, and a retired watchdog must not trip the heartbeat monitor; explicit user settings win."""
+    """ddp.init_process_group_from_env('nccl', for_capture=True): the watchdog's spurious hipErrorCapturedEvent (captured DDP step) must
+    not be re-thrown into std::terminate, and a retired watchdog must not trip the heartbeat monitor; explicit user settings win.
+    Plain eager DDP (the default) keeps torch's failure detection: neither variable is touched."""
     import torch.distributed as dist
     from efficientdet.pytorch_amd import ddp
     calls = []
@@ -292,12 +293,14 @@ def test_nccl_init_keeps_a_watchdog_query_error_from_killing_the_job(monkeypatch
     for k in ('TORCH_NCCL_RETHROW_CUDA_ERRORS', 'TORCH_NCCL_ENABLE_MONITORING', 'MASTER_ADDR', 'MASTER_PORT'):
         monkeypatch.delenv(k, raising=False)
     ddp.init_process_group_from_env('nccl')
+    assert 'TORCH_NCCL_RETHROW_CUDA_ERRORS' not in os.environ and 'TORCH_NCCL_ENABLE_MONITORING' not in os.environ
+    ddp.init_process_group_from_env('nccl', for_capture=True)
     assert os.environ['TORCH_NCCL_RETHROW_CUDA_ERRORS'] == '0' and os.environ['TORCH_NCCL_ENABLE_MONITORING'] == '0'
-    assert calls == [dict(backend='nccl', init_method='env://')] and os.environ['MASTER_ADDR'] == '127.0.0.1'
+    assert calls == [dict(backend='nccl', init_method='env://')] * 2 and os.environ['MASTER_ADDR'] == '127.0.0.1'
     monkeypatch.setenv('TORCH_NCCL_RETHROW_CUDA_ERRORS', '1')
-    ddp.init_process_group_from_env('nccl')
+    ddp.init_process_group_from_env('nccl', for_capture=True)
     assert os.environ['TORCH_NCCL_RETHROW_CUDA_ERRORS'] == '1'
     for k in ('TORCH_NCCL_RETHROW_CUDA_ERRORS', 'TORCH_NCCL_ENABLE_MONITORING'):
         monkeypatch.delenv(k, raising=False)
-    ddp.init_process_group_from_env('gloo')
+    ddp.init_process_group_from_env('gloo', for_capture=True)
     assert 'TORCH_NCCL_RETHROW_CUDA_ERRORS' not in os.environ
