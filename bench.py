@@ -227,52 +227,29 @@ class DdpSelfCheckFailed(RuntimeError):
     pass
 
 
-def ddp_graph_self_check(model, opt, graphed, step, on_stream, dev, world):
-    """A captured DDP step must BE the eager DDP step.  From ONE saved state (parameters, Adam moments + step counters, the drop_connect
-    counter -- all restored in place, so the graph's pointers stay valid): one eager step -> parameters P_e; restore; one replay -> P_g.
-    Both see the same batch and the same Bernoulli masks, so P_g must equal P_e up to the summation order RCCL may choose: the difference
-    must stay within 1e-3 of the step's own update, on every rank (the captured-hooks race this guards against -- gradient buckets read
-    half-written -- moves parameters by a large part of the update or makes them non-finite), AND after the replay every rank must hold the
-    same parameters (checksum MIN == MAX over ranks).  Raises DdpSelfCheckFailed; the supervisor then re-runs the leg eagerly."""
+def graph_self_check(graphed, dev, world, use_dist=True):
+    """A captured step must BE the eager step (N = 1: the plain step; N > 1: the DDP step with its all-reduces): graph.replay_vs_eager
+    runs one eager step and one replay from the same restored state (same batch, same Bernoulli masks) and compares the parameters they
+    produce.  Gate: the difference within 1e-3 of the step's own update on every rank (a gradient that does not reach the optimizer --
+    buckets read half-written, a workspace not reset inside the graph -- moves it by 10-20 % of the update), finite, and after the replay
+    every rank holds the same parameters (checksum MIN == MAX over ranks).  Raises DdpSelfCheckFailed; under DDP the supervisor then
+    re-runs the leg eagerly, at N = 1 the leg times eager launches."""
     import torch
     import torch.distributed as dist
-    ps = [p for p in model.parameters() if p.requires_grad]
-    t = opt._table
-    dc = [v for k, v in model._dc.items() if isinstance(k, tuple) and k[0] == 'step_dev']
-
-    def flat():
-        return torch.cat([p.detach().reshape(-1) for p in ps])
-    torch.cuda.synchronize()
-    p0, m0, v0, s0 = flat().clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), t['steps'].clone()
-    dc0 = [d.clone() for d in dc]
-
-    def restore():
-        with torch.no_grad():
-            o = 0
-            for p in ps:
-                n = p.numel(); p.copy_(p0[o:o + n].view_as(p)); o += n
-            opt.exp_avg.copy_(m0); opt.exp_avg_sq.copy_(v0); t['steps'].copy_(s0)
-            for d, d0 in zip(dc, dc0):
-                d.copy_(d0)
-        torch.cuda.synchronize()
-    with on_stream():
-        step()
-    torch.cuda.synchronize()
-    pe = flat().clone()
-    restore()
-    graphed()
-    torch.cuda.synchronize()
-    pg = flat().clone()
-    upd, diff = float((pe - p0).norm()), float((pg - pe).norm())
-    stat = torch.tensor([diff / max(upd, 1e-30), 0.0 if bool(torch.isfinite(pg).all()) else 1.0], device=dev, dtype=torch.float64)
-    dist.all_reduce(stat, op=dist.ReduceOp.MAX)
-    cs = pg.double().sum().reshape(1)
+    from efficientdet.pytorch_amd.graph import replay_vs_eager
+    r = replay_vs_eager(graphed)
+    ps = graphed.optimizer._table['params']
+    cs = torch.cat([p.detach().reshape(-1) for p in ps]).double().sum().reshape(1)
+    stat = torch.tensor([r['replay_vs_eager'], 0.0 if r['finite'] else 1.0, r['eager_vs_eager'], r['replay_vs_replay']], device=dev, dtype=torch.float64)
     lo, hi = cs.clone(), cs.clone()
-    dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-    note = {'replay_vs_eager_rel_to_update': float(stat[0].item()), 'update_norm_rank0': upd, 'ranks_hold_equal_parameters': bool((lo == hi).item()),
-            'finite': float(stat[1].item()) == 0.0, 'world': world}
-    if not (note['finite'] and note['ranks_hold_equal_parameters'] and note['replay_vs_eager_rel_to_update'] <= 1e-3 and upd > 0.0):
-        raise DdpSelfCheckFailed('captured DDP step != eager DDP step: %s' % json.dumps(note))
+    if use_dist:
+        dist.all_reduce(stat, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    note = {'replay_vs_eager_rel_to_update': float(stat[0].item()), 'eager_vs_eager': float(stat[2].item()), 'replay_vs_replay': float(stat[3].item()),
+            'update_norm_rank0': r['update_norm'], 'losses_replay_rank0': r['losses_replay'], 'losses_eager_rank0': r['losses_eager'],
+            'ranks_hold_equal_parameters': bool((lo == hi).item()), 'finite': float(stat[1].item()) == 0.0, 'world': world}
+    if not (note['finite'] and note['ranks_hold_equal_parameters'] and note['replay_vs_eager_rel_to_update'] <= 1e-3 and r['update_norm'] > 0.0):
+        raise DdpSelfCheckFailed('captured step != eager step: %s' % json.dumps(note))
     return note
 
 
@@ -342,8 +319,15 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
                 raise
             sys.stderr.write('hipGraph capture failed (%s: %s); timing eager launches\n' % (type(e).__name__, e))
             graphed = None
-        if use_ddp and graphed is not None:
-            self_check = ddp_graph_self_check(model, opt, graphed, step, on_stream, dev, world)
+        if graphed is not None and not a.torch_optim:
+            # the number below is only worth reporting if a replay IS a step: checked against an eager step from the same state, every leg
+            try:
+                self_check = graph_self_check(graphed, dev, world, use_dist=use_ddp)
+            except DdpSelfCheckFailed as e:
+                if use_ddp:
+                    raise
+                sys.stderr.write('%s; timing eager launches\n' % e)
+                graphed, self_check = None, {'failed': str(e)}
     sync_all()
     t0 = time.perf_counter()
     if graphed is not None:
@@ -484,7 +468,8 @@ def result_line(a, world, leg, cfg, ddp_note=None):
                    'ddp_graph': ddp_note,
                    'arithmetic': MODE_NOTE[a.dtype],
                    'final_loss': round(leg['final_loss'], 4),
-                   'launch': 'hipGraph replay (one graph launch per step)' if leg['graphed'] else 'eager launches'},
+                   'launch': 'hipGraph replay (one graph launch per step)' if leg['graphed'] else 'eager launches',
+                   'graph_self_check': leg.get('self_check')},
         'algorithmic_tflops_per_gpu': round(TRAIN_GFLOP_PER_IMG * a.batch / leg['ms_per_step'], 2) if d0_512 else None,
         # host time to ISSUE one step, per rank (wall time per step is ms_per_step): host ~= wall means the launch path, not the GPU, is the bound
         'host_ms_per_step': leg['host_ms'],

@@ -324,6 +324,18 @@ __global__ void loss_bwd_reg_kernel(const LossK p) {
   }
 }
 
+// stat[] starts every pass at zero (num_pos is an integer atomic count).  A KERNEL, not hipMemsetAsync: captured into a hipGraph the
+// memset node did not hold -- replays of the captured train step ran the assign pass on whatever the recycled workspace contained
+// (num_pos ~ 1e9 from a float bit pattern: losses and every gradient scaled by ~1e-7; found in round 5 by comparing one replay with one
+// eager step from the same state).  Kernel nodes only, like the NMS (postprocess.hip).
+__global__ __launch_bounds__(256) void loss_zero_stat_kernel(float* __restrict__ stat, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) stat[i] = 0.f;
+}
+inline void zero_stat(const LossK& k, int B, hipStream_t st) {
+  hipLaunchKernelGGL(loss_zero_stat_kernel, dim3((unsigned)((B * SS + 255) / 256)), dim3(256), 0, st, k.stat, B * SS);
+}
+
 inline int grid_for(long long n) { long long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -356,7 +368,8 @@ extern "C" int effdet_focal_loss_fwd(const float* cls, const float* reg, const f
   k.B = B; k.nc = num_classes; k.N = N; k.A = A;
   carve_loss(k, workspace, B, A);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(k.stat, 0, (size_t)B * SS * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+  zero_stat(k, B, st);
+  EFFDET_CHECK_LAUNCH();
   hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)k.na, B), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   const long long groups = (A * num_classes + 3) / 4;
@@ -421,7 +434,8 @@ extern "C" int effdet_focal_loss_fwd_grad(const float* cls, const float* reg, co
   k.dcls = dcls_pix; k.dld = dld; k.B = B; k.nc = num_classes; k.N = N; k.A = A;
   carve_loss(k, workspace, B, A);
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(k.stat, 0, (size_t)B * SS * 4, st) != hipSuccess) return EFFDET_ELAUNCH;
+  zero_stat(k, B, st);
+  EFFDET_CHECK_LAUNCH();
   hipLaunchKernelGGL(loss_assign_kernel, dim3((unsigned)k.na, B), dim3(256), 0, st, k);
   EFFDET_CHECK_LAUNCH();
   const long long groups = (A / 9) * dld / 4;

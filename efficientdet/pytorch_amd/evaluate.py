@@ -36,10 +36,12 @@ def finalize(s, l, b, count, scales, score_threshold=0.05, max_detections=None, 
                          dtype=torch.float32, device=s.device).contiguous()
     out, oc = ops.finalize_dets(s, l, b, count, sc, score_threshold, max_detections, xywh)
     # counts first (a few bytes), then ONLY the filled rows: the uncapped COCO default makes `out` [B, A, 6] -- 1.18 MB per D0 image,
-    # 4.7 MB per D4 image, nearly all of it rows past the count -- and the host array is padded back to the documented shape
+    # 4.7 MB per D4 image, nearly all of it padding rows past the count (zeros with label -1, as the kernel writes them) -- which the
+    # host array reproduces without transferring them
     counts = oc.cpu().numpy()
     k = int(counts.max()) if counts.size else 0
     host = np.zeros((out.shape[0], max_detections, 6), dtype=np.float32)
+    host[:, :, 5] = -1.0
     if k:
         host[:, :k] = out[:, :k].cpu().numpy()
     return host, counts

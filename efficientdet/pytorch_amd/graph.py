@@ -56,6 +56,7 @@ class GraphedTrainStep:
         # ONE side stream for the warm-up AND the capture; a DDP module built by ddp.wrap_for_capture brings the stream its
         # AccumulateGrad nodes / bucket hooks already live on
         side = getattr(model, '_effdet_capture_stream', None) or torch.cuda.Stream()
+        self.stream = side                      # eager steps of this model belong on it too (its AccumulateGrad nodes live there)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # warm-up on the side stream: records the ParamPrep table, sizes the zero pool, and
             for _ in range(max(1, warmup)):     # (re)creates the AccumulateGrad nodes off the legacy default stream, which a
@@ -100,6 +101,57 @@ class GraphedTrainStep:
 
     def _hyper_sig(self):
         return [sorted((k, repr(v)) for k, v in g.items() if k != 'params') for g in self.optimizer.param_groups]
+
+
+def replay_vs_eager(graphed, eager_step=None):
+    """Is a replay of `graphed` (a GraphedTrainStep over optim.ClipAdamW) the eager step?  From ONE saved state -- parameters, Adam
+    moments + per-tensor step counters, the drop_connect counter, all restored IN PLACE so the graph's pointers stay valid -- run the eager
+    step (default: graphed._step on the capture stream) and the replay, each twice, on the graph's static batch, and compare the
+    parameters they produce.  The path has no float atomics, so eager == eager and replay == replay bit for bit (which also proves the
+    restore complete), and replay vs eager differs at most by what a collective's summation order may change under DDP.
+    -> {'replay_vs_eager', 'eager_vs_eager', 'replay_vs_replay'} (norm of the parameter difference / norm of the step's own update),
+       'update_norm', 'finite', 'losses_replay', 'losses_eager'.   Leaves the model one replayed step past the state it found.
+    (Round 5: this is the check that found the captured step training on ~1e-7 of its gradients -- a hipMemsetAsync node inside the loss
+    did not hold in the graph -- while every 'losses track, parameters within AdamW's sign noise' test stayed green.)"""
+    opt = graphed.optimizer
+    model = graphed.model
+    while isinstance(model, (torch.nn.DataParallel, torch.nn.parallel.DistributedDataParallel)):
+        model = model.module
+    if not hasattr(opt, 'exp_avg') or getattr(opt, '_table', None) is None:
+        raise RuntimeError('replay_vs_eager needs optim.ClipAdamW (its state lives in arenas that can be restored in place)')
+    ps = [p for p in opt._table['params']]
+    t = opt._table
+    dc = [v for k, v in getattr(model, '_dc', {}).items() if isinstance(k, tuple) and k[0] == 'step_dev']
+
+    def flat():
+        return torch.cat([p.detach().reshape(-1).float() for p in ps]).clone()
+    torch.cuda.synchronize()
+    p0, m0, v0, s0 = flat(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), t['steps'].clone()
+    dc0 = [d.clone() for d in dc]
+    side = graphed.stream
+
+    def run(replay):
+        with torch.no_grad():
+            o = 0
+            for p in ps:
+                n = p.numel(); p.copy_(p0[o:o + n].view_as(p)); o += n
+            opt.exp_avg.copy_(m0); opt.exp_avg_sq.copy_(v0); t['steps'].copy_(s0)
+            for d, d0 in zip(dc, dc0):
+                d.copy_(d0)
+        torch.cuda.synchronize()
+        if replay:
+            cl, rl = graphed()
+        else:
+            with torch.cuda.stream(side):
+                cl, rl = (graphed._step if eager_step is None else eager_step)()
+        torch.cuda.synchronize()
+        return flat(), (float(cl.detach().reshape(-1)[0]), float(rl.detach().reshape(-1)[0]))
+    pe, le = run(False); pe2, _ = run(False)
+    pg, lg = run(True); pg2, _ = run(True)
+    upd = float((pe - p0).norm())
+    rel = lambda a, b: float((a - b).norm()) / max(upd, 1e-30)
+    return {'replay_vs_eager': rel(pg, pe), 'eager_vs_eager': rel(pe2, pe), 'replay_vs_replay': rel(pg2, pg), 'update_norm': upd,
+            'finite': bool(torch.isfinite(pg).all()), 'losses_replay': lg, 'losses_eager': le}
 
 
 class GraphedDetect:

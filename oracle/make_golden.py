@@ -302,6 +302,10 @@ CASES = {
     'd0_512_dets_separated': lambda E: case_dets_separated(E, 'd0_512_dets_separated', 'efficientdet-d0', 80, 2, 512, gain=0.5, seed=2),
     # ... and with ~100 kept boxes per image (complete lists compared as sets: near-tied neighbours may swap places)
     'd0_512_dets_dense': lambda E: case_dets_dense(E, 'd0_512_dets_dense', 'efficientdet-d0', 80, 2, 512),
+    # configs[4]'s geometry end to end (round 5): D4 @1024, 80 classes -- the real reference's COMPLETE lists (196 416 anchors per image in,
+    # scores / labels / boxes in NMS order out), gated in both parity modes like d0_512_dets_separated
+    'd4_1024_dets_separated': lambda E: case_dets_separated(E, 'd4_1024_dets_separated', 'efficientdet-d4', 80, 2, 1024, gain=0.5, seed=3),
+    'd4_1024_dets_dense': lambda E: case_dets_dense(E, 'd4_1024_dets_dense', 'efficientdet-d4', 80, 1, 1024),
     'd0_128_dropconnect': lambda E: case_train_dropconnect(E, 'd0_128_dropconnect', 'efficientdet-d0', 20, 4, 128),
 }
 

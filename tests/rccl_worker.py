@@ -98,6 +98,10 @@ def main():
     d = (flat(me) - flat(mg)).abs()
     res.update(graph_losses=lg, eager_tail_losses=le[WARM:], graph_param_diff_mean=float(d.mean()), graph_param_diff_max=float(d.max()),
                graph_finite=bool(torch.isfinite(flat(mg)).all()), lr=lr, steps=WARM + REPLAYS)
+    # ONE replay vs ONE eager DDP step from the same restored state (graph.replay_vs_eager): the strict form of 'replays track eager'
+    from efficientdet.pytorch_amd.graph import replay_vs_eager
+    res['replay_vs_eager'] = replay_vs_eager(g)
+    res['stage'] = 'checked'; dump()
     # a second batch through the static input buffers, one more replay: still a real step
     g.images.copy_(img.flip(0)); g.annotations.copy_(ann.flip(0))
     cl, rl = g(); torch.cuda.synchronize()

@@ -143,12 +143,20 @@ def test_largest_family_at_its_native_size(arith):
     # operands), so ReLU masks within 1e-5 of zero fall differently in the two runs (tests/test_gpu_model.py, profiles/r04_x3_locate.txt)
     # and every tensor upstream collects them -- measured 9.9e-3 on the stem weight (the end of the backward chain); the stated gate
     # of the deep families, doubled
-    gtol = 2e-2 if arith == 'bf16x3' else 2e-3      # ('f32_bwd_bf16x3': exact forward, no mask can flip -- the exact mode's gate)
+    # ('f32_bwd_bf16x3': exact forward, no mask can flip -- the exact mode's gates.)  ONE relative clause per tensor, no absolute escape
+    # (round 5).  What the escape had hidden, measured: exact fp32 is within 2e-3 on every tensor except the LAST of the 45-block backward
+    # chain, the stem weight at 6.1e-3 (d = 0.048 on a norm of 7.89; the same value in both exact-forward modes) -- a sum over 1408 x 1408
+    # pixels with heavy cancellation into which the few ReLU / max-pool ties that fall differently between the B = 2 and B = 1 launches
+    # (other tilings, other summation orders) are carried; tests/test_gpu_model.py::test_non_square_input_vs_oracle measures the same
+    # effect on the reference arithmetic itself (its own stem gradient moves by 1.25e-2 under a 1.2e-6 input scaling).  Stated gate for
+    # the stem tensors: 1e-2.
+    gtol = 2e-2 if arith == 'bf16x3' else 2e-3
+    stem_tol = 2e-2 if arith == 'bf16x3' else 1e-2
     for k, v in full.items():
         d = float((v - acc[k]).norm()); rel = d / max(float(v.norm()), 1e-30)
         if rel > worst[0]:
             worst = (rel, k)
-        if rel > gtol:                      # (one relative clause, no absolute escape: see the B = 32 test above)
+        if rel > (stem_tol if k.startswith(('backbone._conv_stem', 'backbone._bn0')) else gtol):
             bad.append((k, rel, d, float(v.norm())))
     assert not bad, bad
     print('D6 @1408 B=2 (%s): losses %s vs per-image mean %s; worst gradient deviation %s' % (arith, fl, ls, worst))

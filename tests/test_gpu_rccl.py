@@ -37,7 +37,7 @@ def rccl_run(tmp_path_factory):
 
 def test_rccl_collective_and_eager_ddp_equal_the_bare_module(rccl_run):
     r, res = rccl_run
-    assert res['stage'] in ('eager', 'capture', 'captured', 'done'), (res, r.stderr[-3000:])
+    assert res['stage'] in ('eager', 'capture', 'captured', 'checked', 'done'), (res, r.stderr[-3000:])
     assert res['allreduce_ok'] and res['rccl_version'][0] >= 2
     assert res['finite'] and res['prep_replay']
     assert res['eager_losses_ddp'] == res['eager_losses_plain'], res          # same kernels, same masks: identical floats
@@ -56,6 +56,9 @@ def test_ddp_step_with_rccl_all_reduce_captured_as_hipgraph(rccl_run):
     # parameters after 14 steps: eager vs 11 warm-ups + 3 replays (the gate of test_graphed_train_step_tracks_eager: AdamW sign noise)
     assert res['graph_param_diff_mean'] < 0.5 * res['lr'] and res['graph_param_diff_max'] <= res['steps'] * 2 * res['lr'] + 1e-6, res
     assert np.isfinite(res['graph_second_batch_loss']) and res['graph_second_batch_loss'] != lg[-1]
+    # the strict form: one replay == one eager DDP step from the same state (parameters compared against the step's own update)
+    rv = res['replay_vs_eager']
+    assert rv['finite'] and rv['eager_vs_eager'] == 0.0 and rv['replay_vs_replay'] == 0.0 and rv['replay_vs_eager'] <= 1e-6, rv
 
 
 def test_capture_probe_answers_in_child_processes():

@@ -80,7 +80,7 @@ def test_nms_and_detections(golden_dir, case):
         np.testing.assert_allclose(s.numpy()[:16], g[f'det{b}_scores'][:16], rtol=1e-4)
 
 
-@pytest.mark.parametrize('case', ['d0_128_dets_separated', 'd0_512_dets_separated'])       # last: BASELINE configs[1] geometry
+@pytest.mark.parametrize('case', ['d0_128_dets_separated', 'd0_512_dets_separated', 'd4_1024_dets_separated'])       # BASELINE configs[1] and configs[4] geometries
 def test_complete_detection_lists_when_scores_are_separated(golden_dir, case):
     """Oracle == the real reference on every score / label / box of a case with well-separated candidate scores."""
     g = _load(golden_dir, case)
@@ -97,11 +97,12 @@ def test_complete_detection_lists_when_scores_are_separated(golden_dir, case):
         np.testing.assert_allclose(bx.numpy(), g[f'det{b}_boxes'], rtol=1e-4, atol=1e-3)
 
 
-def test_complete_detection_lists_dense(golden_dir):
-    """Oracle == the real reference on the COMPLETE lists of a configs[1]-geometry case that keeps ~100 boxes per image (compared as
-    sets: neighbouring scores are closer than conv rounding, so two near-tied boxes may swap places but not drop out)."""
+@pytest.mark.parametrize('case', ['d0_512_dets_dense', 'd4_1024_dets_dense'])
+def test_complete_detection_lists_dense(golden_dir, case):
+    """Oracle == the real reference on the COMPLETE lists of a configs[1]- / configs[4]-geometry case that keeps ~100 boxes per image
+    (compared as sets: neighbouring scores are closer than conv rounding, so two near-tied boxes may swap places but not drop out)."""
     from tests.gpu_util import unmatched_detections
-    g = _load(golden_dir, 'd0_512_dets_dense')
+    g = _load(golden_dir, case)
     net, nc = str(g['network']), int(g['num_classes'])
     sd = O.golden_state_dict(g)
     sd['bbox_head.retina_cls.weight'] = sd['bbox_head.retina_cls.weight'] * float(g['gain'])
