@@ -96,7 +96,7 @@ def parse(argv=None):
     ap.add_argument('--ddp-single', action='store_true',
                     help='N = 1 through the N > 1 code path: supervisor + child leg, world_size-1 RCCL process group, ddp.wrap, bucketed all-reduce, '
                          'captured DDP step with its self-check (what a box with one GPU can validate of the multi-GPU path)')
-    ap.add_argument('--leg-timeout', type=float, default=900.0, help='N > 1: seconds the child processes of one attempt get before it is abandoned')
+    ap.add_argument('--leg-timeout', type=float, default=360.0, help='N > 1: seconds the child processes of one attempt get before it is abandoned')
     ap.add_argument('--infer-reps', type=int, default=20, help='timed repetitions of every inference leg')
     ap.add_argument('--torch-optim', action='store_true', help='stock clip_grad_norm_ + torch.optim.AdamW(fused) instead of the HIP ClipAdamW')
     ap.add_argument('--_leg', dest='leg', default=None, choices=['graph', 'eager', 'dry'], help=argparse.SUPPRESS)   # internal: this process IS one rank of a DDP leg
@@ -387,7 +387,7 @@ def inference_roofline(model, img, dtype_name):
     ops.PROFILE = ops.LaunchProfile()
     try:
         with torch.no_grad():
-            model.forward_raw(img)
+            model.detect(img)              # forward + decode + NMS + gather, eager, every launch timed
         torch.cuda.synchronize()
         summ = ops.PROFILE.summary()
         mf = {k: v for k, v in summ.items() if k.startswith('conv_')}
@@ -592,6 +592,8 @@ def run_attempt(a, path, attempt, rank, world, local, base_port, store, dry):
     env = {k: v for k, v in os.environ.items() if not k.startswith(('TORCHELASTIC_', 'GROUP_', 'ROLE_', 'LOCAL_WORLD'))}
     env.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), EFFDET_BENCH_DRY_PATH=path)
+    if path == 'graph':
+        env.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')       # torch's recipe for DDP inside a captured graph (the capture leg only)
     argv = [x for x in sys.argv[1:] if x != '--ddp-single']
     cmd = [sys.executable, os.path.abspath(__file__)] + argv + ['--_leg', 'dry' if dry else path]
     t0 = time.time()

@@ -926,8 +926,11 @@ def decode_score(anc, reg, cls, img_h, img_w):
     boxes = torch.empty((B, A, 4), dtype=torch.float32, device=cls.device)
     score = torch.empty((B, A), dtype=torch.float32, device=cls.device)
     label = torch.empty((B, A), dtype=torch.int32, device=cls.device)
-    L.check(L.lib().effdet_decode_score(L.ptr(anc), L.ptr(reg), L.ptr(cls), L.ptr(boxes), L.ptr(score), L.ptr(label), B,
-                                        C.c_longlong(A), nc, C.c_float(img_w), C.c_float(img_h), L.stream_ptr()), 'effdet_decode_score')
+    # algorithmic bytes: probabilities + box deltas read once, boxes / score / label written once (anchors: one [A,4] table for the batch)
+    nbytes = 4 * (B * A * (nc + 4) + A * 4 + B * A * 6)
+    _timed('decode_score_kernel', nbytes, lambda: L.check(L.lib().effdet_decode_score(
+        L.ptr(anc), L.ptr(reg), L.ptr(cls), L.ptr(boxes), L.ptr(score), L.ptr(label), B, C.c_longlong(A), nc, C.c_float(img_w), C.c_float(img_h),
+        L.stream_ptr()), 'effdet_decode_score'), 'BYTES B%d A%d nc%d' % (B, A, nc))
     return boxes, score, label
 
 
@@ -938,8 +941,12 @@ def nms(boxes, score, threshold, iou_threshold):
     ws = torch.empty(nbytes, dtype=torch.uint8, device=score.device)
     idx = torch.empty((B, A), dtype=torch.int32, device=score.device)
     count = torch.empty((B,), dtype=torch.int32, device=score.device)
-    L.check(L.lib().effdet_nms(L.ptr(boxes), L.ptr(score), C.c_float(threshold), C.c_float(iou_threshold), L.ptr(idx), L.ptr(count),
-                               L.ptr(ws), C.c_longlong(nbytes), B, C.c_longlong(A), L.stream_ptr()), 'effdet_nms')
+    # algorithmic bytes of the whole NMS call (sort + greedy rounds = ~90 launches): every candidate's box + score read once, its index
+    # written once -- the O(K^2) suppression work is latency / ALU, not bytes, so the GB/s of this entry says how far from a streaming
+    # pass the greedy algorithm is, not how well a kernel streams
+    _timed('nms (radix sort + cross / matrix / resolve rounds)', 4 * B * A * 6, lambda: L.check(L.lib().effdet_nms(
+        L.ptr(boxes), L.ptr(score), C.c_float(threshold), C.c_float(iou_threshold), L.ptr(idx), L.ptr(count),
+        L.ptr(ws), C.c_longlong(nbytes), B, C.c_longlong(A), L.stream_ptr()), 'effdet_nms'), 'BYTES B%d A%d' % (B, A))
     return idx, count
 
 

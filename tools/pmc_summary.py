@@ -59,12 +59,13 @@ def short(name):
     if m:
         return 'conv_wgrad_f32dma_kernel<%s%s>' % (m.group(1), ',bf16x3' if m.group(2) == '1' else '')
     m = re.search(r'(conv_wgrad\w*_kernel<[^>(]*>|dw_\w+_kernel|unpack_wgrad\w*_kernel|wgrad_\w+_kernel|loss_\w+_kernel|se_\w+_kernel|'
-                  r'channel_scale_kernel|fuse_\w+_kernel|opt_\w+_kernel|act_bwd_kernel|prepare_params_kernel|nms_\w+_kernel|decode_score_kernel)', name)
+                  r'channel_scale_kernel|fuse_\w+_kernel|opt_\w+_kernel|act_bwd_kernel|prepare_params_kernel|nms_\w+_kernel|decode_score_kernel|conv_pw_f32_kernel<\d+>|sort_\w+_kernel|radix_\w+_kernel|gather_dets_kernel|to_split_kernel)', name)
     return m.group(1).replace('unsigned short', 'bf16').replace('float', 'f32') if m else None
 
 
 def main():
     out_path, dtype, fdir, wdir, sdir = sys.argv[1:6]
+    command = sys.argv[6] if len(sys.argv) > 6 else 'python bench.py --dtype %s --steps 2 --warmup 1 (train leg only)' % dtype
     fetch, write = per_launch(fdir, {'FETCH_SIZE'}), per_launch(wdir, {'WRITE_SIZE'})
     sq = per_launch(sdir, {'SQ_VALU_MFMA_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES'})
     out = {}
@@ -104,8 +105,8 @@ def main():
         kernels[s] = r
     res = {'dtype': dtype,
            'source': 'rocprofv3 --pmc FETCH_SIZE | --pmc WRITE_SIZE | --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (three separate passes) -- '
-                     'python bench.py --dtype %s --steps 2 --warmup 1 (train leg only); KiB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md; '
-                     'mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)' % dtype,
+                     '%s; KiB -> bytes; FETCH_SIZE doubled per MI355X_MICROARCH.md; '
+                     'mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)' % command,
            'kernels': kernels}
     json.dump(res, open(out_path, 'w'), indent=1)
     for k in ('conv_igemm_kernel<bf16,128>', 'conv_igemm_kernel<f32,128>', 'conv_wgrad_tr_kernel<8>', 'conv_igemm_kernel<split,128,bf16x3>', 'conv_wgrad_split_kernel'):
