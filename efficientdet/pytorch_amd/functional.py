@@ -380,6 +380,45 @@ def head_out_maps(buf, B, sizes, per_anchor):
     return maps
 
 
+# The two towers of the RetinaHead are independent chains of equal launches.  A 256 -> 256 tower conv is 2728 tiles on 512 workgroup slots =
+# 5.33 rounds: the last round runs a third full, i.e. ~11 % of every launch is a draining tail (PMC: MFMA busy 0.82 = 0.89 of quantisation x
+# 0.92 in the loop).  On two streams (one graph branch each under capture) the regression tower's workgroups fill the classification
+# tower's tail and vice versa.  Fork / join discipline instead of record_stream: the side stream starts behind everything the main stream
+# has enqueued, and the main stream waits for it before anything the side stream touched can be freed or reused.
+HEAD_TWO_STREAMS = os.environ.get('EFFDET_HEAD_TWO_STREAMS', '0') == '1'
+_side_streams = {}
+
+
+class _Fork:
+    """with _Fork(device, on) as f: ...main-stream work...; with f.side(): ...side-stream work...   (joined at exit; on=False: one stream)"""
+
+    def __init__(self, device, on):
+        self.on = on
+        if on:
+            key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device)
+            self.main, self.s = torch.cuda.current_stream(device), _side_streams[key]
+
+    def __enter__(self):
+        if self.on:
+            self.s.wait_stream(self.main)
+        return self
+
+    def side(self):
+        import contextlib
+        return torch.cuda.stream(self.s) if self.on else contextlib.nullcontext()
+
+    def join(self):
+        if self.on:
+            self.main.wait_stream(self.s)
+            self.on = False
+
+    def __exit__(self, et, ev, tb):
+        self.join()
+        return False
+
+
 HEAD_SPLIT = os.environ.get('EFFDET_HEAD_SPLIT', '1') == '1'     # A/B switch: split-layout head activations in the bf16x3 arithmetic
 _split_ok = {}
 
@@ -427,7 +466,10 @@ def head_fwd(p, HP, num_classes, dtype, train):
     if split or split_bwd:    # the pyramid once in the split layout: operand of both towers' first conv and of their weight gradients
         pin = _pyramid_to_split(p, B, sizes, Wc, dtype, dev)
     acts = {'cls': [], 'reg': []}
-    for tower in ('cls', 'reg'):
+    cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
+    reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
+
+    def tower_fwd(tower):
         cur = p if split_bwd else pin
         for t in range(4):
             w, b = HP[f'{tower}_convs.{t}.weight'], HP[f'{tower}_convs.{t}.bias']
@@ -435,16 +477,18 @@ def head_fwd(p, HP, num_classes, dtype, train):
             nxs = pyramid_alloc(B, sizes, 256, dtype, dev)[1] if split_bwd else None
             ops.conv2d(cur, ops.pack_weight(w, dtype, x3=split), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
                        shift=b, act=ACT_RELU, split=split, ysplit=nxs)
-            acts[tower].append(nxs if split_bwd else nxt); cur = nxt
-        if split_bwd:
-            acts[tower + '_last'] = cur        # (plain fp32 operand of retina_cls / retina_reg below; not kept for backward)
-    cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
-    reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
-    ops.conv2d(acts.pop('cls_last', acts['cls'][3]), ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
-               Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
-               act=ACT_SIGMOID, out_f32=True, split=split)
-    ops.conv2d(acts.pop('reg_last', acts['reg'][3]), ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
-               Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split)
+            acts[tower].append(nxs if split_bwd else nxt); cur = nxt       # (split_bwd: `cur` stays plain fp32 and is not kept for backward)
+        if tower == 'cls':
+            ops.conv2d(cur, ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
+                       Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
+                       act=ACT_SIGMOID, out_f32=True, split=split)
+        else:
+            ops.conv2d(cur, ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
+                       Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split)
+    with _Fork(dev, HEAD_TWO_STREAMS and ops.PROFILE is None) as fk:
+        with fk.side():
+            tower_fwd('reg')
+        tower_fwd('cls')
     saved = (pin, acts, sizes, HP, num_classes, split or split_bwd) if train else None
     return cls, reg, saved
 
@@ -471,9 +515,10 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     g = {}
-    dp_maps = None
     apix = sum(h * w for (h, w) in sizes)
-    for tower, dout, per, pix_ld in (('cls', dcls_logit, nc, dcls_ld), ('reg', dreg, 4, dreg_ld)):
+    last = {}
+
+    def tower_bwd(tower, dout, per, pix_ld):
         fin = f'retina_{tower}'
         wf = HP[fin + '.weight']
         Cf = wf.shape[0]
@@ -517,11 +562,24 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
                 ops.conv2d(dz, wd, nz, Cin=256, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, res=acts[tower][t - 1],
                            res_mode=RES_RELU_MASK, split=split)
                 dz = nz
-            else:                                       # back to plain fp32 for the neck (out_f32 in the split form)
-                if dp_maps is None:
-                    _, dp_maps = pyramid_alloc(B, sizes, Wc, dtype, dev)
-                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, split=split, out_f32=split)
-                else:                                   # second tower: accumulate onto the first one's gradient
-                    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, res=dp_maps,
-                               res_mode=RES_ADD, split=split, out_f32=split)
+            else:
+                last[tower] = (dz, wd)                  # 256 -> Wc back to the neck: after the join (the towers' sum)
+
+    # (the two towers on two streams, see HEAD_TWO_STREAMS: the deferred unpack jobs of both leave in the node's ONE tail launch, on the
+    #  main stream, after the join -- hence no early flush in between)
+    two = HEAD_TWO_STREAMS and ops.PROFILE is None
+    ops.hold_tail_flush(two)
+    try:
+        with _Fork(dev, two) as fk:
+            with fk.side():
+                tower_bwd('reg', dreg, 4, dreg_ld)
+            tower_bwd('cls', dcls_logit, nc, dcls_ld)
+    finally:
+        ops.hold_tail_flush(False)
+    # back to plain fp32 for the neck (out_f32 in the split form): the first tower writes, the second accumulates onto it
+    _, dp_maps = pyramid_alloc(B, sizes, Wc, dtype, dev)
+    dz, wd = last['cls']
+    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, split=split, out_f32=split)
+    dz, wd = last['reg']
+    ops.conv2d(dz, wd, dp_maps, Cin=256, Cout=Wc, KH=3, KW=3, pad_t=1, pad_l=1, res=dp_maps, res_mode=RES_ADD, split=split, out_f32=split)
     return dp_maps, g

@@ -498,7 +498,7 @@ class _TailBatch:
         # the deferred jobs pin their split-K slab workspaces (tens of MB per head conv): bound the lifetime, not only the launch
         # size -- past the byte budget the jobs recorded so far leave now and their inputs go back to the allocator
         self.bytes += sum(x.numel() * x.element_size() for x in tensors if isinstance(x, torch.Tensor))
-        if self.bytes > TAIL_KEEP_BYTES:
+        if self.bytes > TAIL_KEEP_BYTES and not getattr(_tls, 'hold_tail', False):
             self.flush()
 
     def flush(self):
@@ -511,6 +511,12 @@ class _TailBatch:
 UNPACK_BATCHED = os.environ.get('EFFDET_UNPACK_BATCH', '1') != '0'      # A/B switch: 0 = every tail job is its own launch
 TAIL_KEEP_BYTES = int(os.environ.get('EFFDET_TAIL_KEEP_MB', '2048')) << 20  # flush early once the deferred jobs pin this much workspace (256 MB split the
 # D0 head's ten unpacks over three launches: 515 -> 704 us of tail time per step; the chains of few jobs do not fill the GPU)
+
+
+def hold_tail_flush(on):
+    """While on, the open tail batch of this thread never flushes early (its jobs were recorded under more than one stream: they may only
+    be launched by the owner of the batch, after the streams have joined)."""
+    _tls.hold_tail = bool(on)
 
 
 def _cur_batch():

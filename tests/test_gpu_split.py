@@ -244,3 +244,34 @@ def test_model_with_split_head_matches_plain_head(S):
     for k in b[2]:
         d = float((a[2][k].double() - b[2][k].double()).norm()); n = float(b[2][k].double().norm())
         assert d <= 2e-3 * n + 1e-12, (k, d, n)
+
+
+def test_head_towers_on_two_streams_compute_the_same_bits():
+    """functional.HEAD_TWO_STREAMS (A/B knob, off: measured 37.95 vs 37.62 ms per D0 B = 32 step -- the other tower's workgroups do not fill a
+    launch's draining tail): the regression tower forked onto a side stream and joined before the towers' sum must give the same losses
+    and the same gradients, bit for bit, in the headline arithmetic."""
+    from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, functional as Fn
+    from oracle import effdet_oracle as O
+    net, nc = 'efficientdet-d0', 8
+    c = EFFICIENTDET[net]
+    sd = O.make_state_dict(net, nc, seed=3)
+    img, ann = O.synthetic_batch(2, 512, seed=2, num_classes=nc)
+    img, ann = img.cuda(), ann.cuda()
+    outs = []
+    old = Fn.HEAD_TWO_STREAMS
+    try:
+        for two in (False, True):
+            Fn.HEAD_TWO_STREAMS = two
+            m = EfficientDet(nc, network=net, W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'], compute_dtype=torch.float32,
+                             f32_arith='f32_bwd_bf16x3')
+            m.load_state_dict(sd); m.backbone.drop_connect_rate = 0.0
+            m = m.cuda(); m.train(); m.is_training = True; m.freeze_bn()
+            cl, rl = m([img, ann])
+            (cl.mean() + rl.mean()).backward()
+            torch.cuda.synchronize()
+            outs.append((cl.detach().clone(), rl.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        Fn.HEAD_TWO_STREAMS = old
+    a, b = outs
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[2].keys() == b[2].keys() and all(torch.equal(a[2][k], b[2][k]) for k in a[2])
