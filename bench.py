@@ -219,6 +219,8 @@ def roofline_of(summ, dtype_name, batch, size):
             'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': (src + ' (rocprofv3 PMC, per launch)') if src else None,
             'launches_per_step': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
             'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+            # operands read once + outputs written once, averaged over the symbol's launches: what `traffic` (PMC) is to be compared with
+            'algorithmic_bytes_per_launch': round(d.get('bytes', 0.0) / d['launches']),
             'all_kernels': _kernel_rows(mf, dtype_name),
             'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)}
                             for k, v in hbm.items()}}
@@ -409,6 +411,7 @@ def inference_roofline(model, img, dtype_name):
                 'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': src,
                 'launches_per_forward': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
+                'algorithmic_bytes_per_launch': round(d.get('bytes', 0.0) / d['launches']),
                 'dominant_by_shape': ops.PROFILE.by_shape(name, top=3),
                 'all_kernels': _kernel_rows(mf, dtype_name),
                 'hbm_kernels': {k: {'launches': v['launches'], 'ms': round(v['ms'], 3), 'GBps': round(v['flops'] / (v['ms'] * 1e-3) / 1e9, 1)}

@@ -24,9 +24,9 @@ class LaunchProfile:
     def summary(self):
         torch.cuda.synchronize()
         out = {}
-        for name, flops, e0, e1, _ in self.records:
-            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
-            d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1)
+        for name, flops, e0, e1, _, nbytes in self.records:
+            d = out.setdefault(name, {'launches': 0, 'flops': 0.0, 'ms': 0.0, 'bytes': 0.0})
+            d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1); d['bytes'] += nbytes
         return out
 
     def by_shape(self, name, top=4):
@@ -34,7 +34,7 @@ class LaunchProfile:
         HBM-bound backbone ones; this shows them apart)."""
         torch.cuda.synchronize()
         agg = {}
-        for n, flops, e0, e1, note in self.records:
+        for n, flops, e0, e1, note, _ in self.records:
             if n == name:
                 d = agg.setdefault(note, {'launches': 0, 'flops': 0.0, 'ms': 0.0})
                 d['launches'] += 1; d['flops'] += flops; d['ms'] += e0.elapsed_time(e1)
@@ -46,12 +46,14 @@ class LaunchProfile:
 PROFILE = None     # set to a LaunchProfile() to time every conv launch
 
 
-def _timed(name, flops, fn, note=''):
+def _timed(name, flops, fn, note='', nbytes=0.0):
+    """flops: algorithmic FLOPs of an MFMA launch (for the byte-counted kernels, whose notes start with 'BYTES': their algorithmic bytes);
+    nbytes: algorithmic bytes of an MFMA launch (operands read once + outputs written once), next to the PMC traffic in the roofline."""
     if PROFILE is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); r = fn(); e1.record()
-    PROFILE.records.append((name, flops, e0, e1, note))
+    PROFILE.records.append((name, flops, e0, e1, note, nbytes))
     return r
 
 
@@ -409,9 +411,12 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
     d.w_image_stride = int(w_image_stride)       # bytes; image b reads its own packed weights (scale_pack_weight)
     _segs(d, xs, ys, base_x, base_y, isx, isy)
     flops = 2.0 * KH * KW * Cin * Cout * sum(y.B * y.H * y.W for y in ys)
+    # algorithmic bytes: the input map, the packed weights, every output stream (y, the pre-activation copy, the split copy), the residual
+    nbytes = isx * Cin * sum(x.B * x.H * x.W for x in xs) + wp.numel() * wp.element_size() + \
+        (4 if out_f32 else isy) * Cout * sum(y.B * y.H * y.W for y in ys) * (1 + (zs is not None) + (ysplit is not None) + (res is not None))
     _timed(_igemm_symbol(x0.dtype, d) if PROFILE is not None else '', flops,
            lambda: L.check(L.lib().effdet_conv2d(C.byref(d), L.stream_ptr()), 'effdet_conv2d'),
-           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)))
+           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(y.B * y.H * y.W for y in ys)), nbytes=float(nbytes))
 
 
 def _wgrad_desc(xs, dzs, dw, dbias, Cin, Cout, KH, KW, stride, pad_t, pad_l, want_bias, split, image_splits):
@@ -463,7 +468,9 @@ def conv2d_wgrad(xs, dzs, dw=None, dbias=None, *, Cin, Cout, KH, KW, stride=1, p
              ('conv_wgrad_f32dma_kernel<4,bf16x3>' if d.dtype == L.F32_BF16X3 else 'conv_wgrad_f32dma_kernel<8>'))), flops,
            lambda: L.check(L.lib().effdet_conv2d_wgrad(C.byref(d), L.ptr(ws), C.c_longlong(nbytes), L.stream_ptr()),
                            'effdet_conv2d_wgrad'),
-           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)))
+           'k%d s%d Cin%d Cout%d M%d' % (KH, stride, Cin, Cout, sum(z.B * z.H * z.W for z in dzs)),
+           nbytes=float(x0.t.element_size() * Cin * sum(x.B * x.H * x.W for x in xs) +
+                        dzs[0].t.element_size() * Cout * sum(z.B * z.H * z.W for z in dzs) + 4.0 * splits * (n + Cout)))
     slabs = ws[:splits * n].view(splits, Cout, KH * KW, Cin)
     parts = ws[splits * n:].view(splits, Cout) if d.dbias else None
     if group:

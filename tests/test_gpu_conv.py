@@ -579,6 +579,7 @@ def test_conv_second_output_in_the_split_layout():
     output is untouched (bitwise the conv without it) and the second equals effdet_to_split of the first, bit for bit; grouped over
     pyramid levels like the RetinaHead tower convs that use it ('f32_bwd_bf16x3': exact forward, split-layout gradient kernels)."""
     from efficientdet.pytorch_amd import functional as Fn, ops
+    ops.set_f32_arith('f32')          # (the process-wide arithmetic is whatever the last model's backward left: this test is about exact fp32)
     torch.manual_seed(3)
     B, Cin, Cout = 2, 64, 256
     sizes = [(16, 16), (8, 8), (4, 4)]
