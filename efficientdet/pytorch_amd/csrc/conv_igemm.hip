@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   int kq = kc, tap = 0, cc = kc;
   while (cc >= p.cpt) { cc -= p.cpt; ++tap; }
   int kh = tap / p.KW, kw = tap - kh * p.KW;
-  int tapi = tap;                // (tap index of the channel-group-major walk, SPLIT == 2 only)
+  int tapi = tap;                // (tap index of the channel-group-major walk: kord == 1)
   unsigned xcur[XROWS];          // current byte offset per row, or EFFDET_OOB when the tap falls outside the image
   auto retap = [&]() {
 #pragma unroll
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
         dma16_async(rw, ws_a + (unsigned)(buf * WLD + (wrow0 + RSTEP * j) * 8) * 16u, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     }
     // advance the cursor by one K-step (8 chunks)
-    if constexpr (SPLIT == 2) {
+    if constexpr (SPLIT != 1) {
       if (p.kord == 1) {
         // channel-group-major walk (cpt % 8 == 0): the 9 taps of one 32-channel group back to back, then the next group.  With
         // 4-byte elements the tap-major walk re-reads a pixel's 128-byte line 8 K-steps (kw) / 24 K-steps (kh) apart -- the lines
@@ -1338,6 +1338,12 @@ extern "C" int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream) {
     case 10 + 4230: return launch_pers<4, 2, 3>(k, st);
     case 10000 + 442: return launch_pers<4, 4, 2, 1>(k, st);
     default: break;
+  }
+  if (id < 8) {
+    // K walk of the plain 128-pixel-tile kernels: tap-major, or (exact fp32, 3x3, whole 32-channel groups; env EFFDET_F32_KORD, A/B)
+    // channel-group-major like the split-layout convs -- same products, another summation order, fewer L2 -> fabric re-fetches
+    static const int f32_kord = getenv("EFFDET_F32_KORD") ? atoi(getenv("EFFDET_F32_KORD")) : 0;
+    k.kord = (id < 4 && f32_kord && p->dtype == EFFDET_F32 && p->KH * p->KW > 1 && k.cpt % 8 == 0 && p->Cin >= f32_kord) ? 1 : 0;
   }
   if (id >= 4 && id < 8) return dispatch<float, 1>(k, st);
   if (id == 20) {
