@@ -97,7 +97,7 @@ def parse(argv=None):
     ap.add_argument('--ddp-single', action='store_true',
                     help='N = 1 through the N > 1 code path: supervisor + child leg, world_size-1 RCCL process group, ddp.wrap, bucketed all-reduce, '
                          'captured DDP step with its self-check (what a box with one GPU can validate of the multi-GPU path)')
-    ap.add_argument('--leg-timeout', type=float, default=360.0, help='N > 1: seconds the child processes of one attempt get before it is abandoned')
+    ap.add_argument('--leg-timeout', type=float, default=240.0, help='N > 1: seconds the child processes of one attempt get before it is abandoned')
     ap.add_argument('--infer-reps', type=int, default=20, help='timed repetitions of every inference leg')
     ap.add_argument('--torch-optim', action='store_true', help='stock clip_grad_norm_ + torch.optim.AdamW(fused) instead of the HIP ClipAdamW')
     ap.add_argument('--_leg', dest='leg', default=None, choices=['graph', 'eager', 'dry'], help=argparse.SUPPRESS)   # internal: this process IS one rank of a DDP leg
