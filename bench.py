@@ -564,8 +564,8 @@ def leg_main(a):
     from efficientdet.pytorch_amd import ddp
     ndev = torch.cuda.device_count()
     backend = os.environ.get('EFFDET_BENCH_BACKEND', 'nccl')                             # 'nccl' IS RCCL on ROCm
-    if local >= ndev:      # debug only (EFFDET_BENCH_BACKEND=gloo): several ranks sharing one GPU to exercise the N>1 control flow
-        if backend != 'gloo' or ndev == 0:
+    if local >= ndev:      # debug only (EFFDET_BENCH_BACKEND=gloo, or EFFDET_BENCH_SHARE_GPU=1 with RCCL): several ranks sharing one GPU to exercise the N>1 path
+        if (backend != 'gloo' and os.environ.get('EFFDET_BENCH_SHARE_GPU') != '1') or ndev == 0:
             sys.stderr.write('rank %d has no GPU of its own (%d visible)\n' % (local, ndev))
             return 2
         local %= ndev

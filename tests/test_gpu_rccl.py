@@ -73,3 +73,37 @@ def test_capture_probe_answers_in_child_processes():
     # a rank whose peers never show up must come back with a verdict, not hang the job: world_size 2 with nobody at rank 1
     ok, note = ddp.rccl_graph_probe(0, timeout=20, rank=0, world_size=2, port=_free_port())
     assert not ok and 'timed out' in note, note
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_rccl_ranks_real_or_refused_never_hung(tmp_path):
+    """`python bench.py --gpus 2` through the self-launch + supervisor + child legs with the REAL RCCL backend.
+    On a box with >= 2 GPUs this is the multi-rank run itself: one JSON line, n_gpus 2, and -- when the captured DDP step was the path --
+    its replay-vs-eager self-check on both ranks.  On a 1-GPU box (EFFDET_BENCH_SHARE_GPU=1: both ranks on device 0) RCCL refuses the
+    communicator ("Duplicate GPU detected"): both attempts must then fail FAST with the failure reported and a non-zero exit code -- no
+    hang, no number."""
+    import time
+    import torch
+    two = torch.cuda.device_count() >= 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='4')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'MASTER_ADDR'):
+        env.pop(k, None)
+    if not two:
+        env['EFFDET_BENCH_SHARE_GPU'] = '1'
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--batch', '4', '--steps', '3', '--warmup', '1', '--no-roofline'],
+                       capture_output=True, text=True, timeout=1100, env=env, cwd=ROOT)
+    dt = time.time() - t0
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    if two:
+        assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+        out = lines[0]
+        assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['global_batch'] == 8
+        note = out['config']['ddp_graph']
+        if note['captured']:
+            sc = note['self_check']
+            assert sc['finite'] and sc['ranks_hold_equal_parameters'] and sc['replay_vs_eager_rel_to_update'] <= 1e-3, sc
+    else:
+        assert r.returncode != 0 and not lines, (r.returncode, r.stdout[-500:])
+        assert 'every attempt failed' in r.stderr and 'attempt 2' in r.stderr
+        assert dt < 200, dt
