@@ -648,19 +648,34 @@ def run_attempt(a, path, attempt, rank, world, local, base_port, store, dry):
     return ok, result, why
 
 
+class Agreement:
+    """What the supervising ranks need from each other -- a verdict per attempt (MIN over ranks), an abort key, a final barrier -- on the
+    launcher's own key-value store (env:// rendezvous: under torch.distributed.run the agent hosts it, started by hand rank 0 does).  No
+    process group: nothing of a collective library prints to stdout next to the ONE JSON line, and there is no communicator to tear down."""
+
+    def __init__(self, rank, world, timeout_s):
+        import datetime
+        from torch.distributed import rendezvous
+        self.store, _, _ = next(rendezvous('env://', rank=rank, world_size=world))
+        self.store.set_timeout(datetime.timedelta(seconds=timeout_s))
+        self.rank, self.world = rank, world
+
+    def gather(self, tag, value):
+        """-> the values every rank gave for `tag` (blocks until all have)."""
+        self.store.set('effdet_%s_%d' % (tag, self.rank), str(int(value)))
+        keys = ['effdet_%s_%d' % (tag, r) for r in range(self.world)]
+        self.store.wait(keys)
+        return [int(self.store.get(k)) for k in keys]
+
+
 def supervisor_main(a, rank, world, local):
     """A rank as the launcher started it: never touches the GPU.  Runs its share of each attempt in a child process, agrees with the
-    other supervisors (gloo, CPU tensors) on whether the attempt worked EVERYWHERE, and moves on to the next path if it did not."""
-    import torch
-    import torch.distributed as dist
+    other supervisors (over the launcher's store) on whether the attempt worked EVERYWHERE, and moves on to the next path if it did not."""
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', str(free_port()))
     base_port = int(os.environ['MASTER_PORT'])
-    dist.init_process_group('gloo', init_method='env://', rank=rank, world_size=world)
-    try:
-        store = dist.distributed_c10d._get_default_store()
-    except Exception:
-        store = None
+    ag = Agreement(rank, world, a.leg_timeout + 180.0)
+    store = ag.store
     dry = os.environ.get('EFFDET_BENCH_DRYRUN') == '1'
     backend = os.environ.get('EFFDET_BENCH_BACKEND', 'nccl')
     eager_only = a.no_ddp_graph or a.no_graph or a.torch_optim or (backend != 'nccl' and not dry)
@@ -669,9 +684,7 @@ def supervisor_main(a, rank, world, local):
     for attempt, path in enumerate(plan):
         t0 = time.time()
         ok, mine, why = run_attempt(a, path, attempt, rank, world, local, base_port, store, dry)
-        flag = torch.tensor([1 if ok else 0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)                # every rank agrees on the verdict of the attempt
-        all_ok = bool(int(flag.item()))
+        all_ok = min(ag.gather('ok%d' % attempt, 1 if ok else 0)) == 1       # every rank agrees on the verdict of the attempt
         history.append({'attempt': attempt + 1, 'path': PATH_NAME[path], 'ok_on_every_rank': all_ok, 'rank0_note': why,
                         'seconds': round(time.time() - t0, 1)})
         if all_ok:
@@ -689,11 +702,7 @@ def supervisor_main(a, rank, world, local):
             note = {'captured': bool(result['graphed']), 'attempts': history, 'self_check': result.get('self_check'),
                     'supervised': 'each rank ran its leg in a child process; a failed attempt is re-run on the next path in fresh processes'}
             print(json.dumps(result_line(a, world, result, EFFICIENTDET[a.network], note)), flush=True)
-    fin = torch.tensor([rc])
-    dist.all_reduce(fin, op=dist.ReduceOp.MAX)
-    dist.barrier()
-    dist.destroy_process_group()
-    return int(fin.item())
+    return max(ag.gather('done', rc))                             # (also the final barrier: nobody leaves before rank 0 has printed)
 
 
 def self_launch(a):
