@@ -1165,7 +1165,10 @@ int dispatch(ConvK& k, hipStream_t st) {
     if ((SPLIT ? deep_env >= 2 : deep_env >= 1) && (long long)k.mtiles * k.ntiles <= 256 && k.Kc >= 6 * 8) {
       // a handful of 128-wide tiles with a long K loop (the project convs of the 8x8 / 4x4 stages: 16 x 2 tiles, 36 K-steps) are bound
       // by the MFMA work of their few CUs (0.66 us per K-step on 32 of 256 CUs): narrower tiles spread the same work over 4x the CUs
-      static const int narrow = getenv("EFFDET_IGEMM_NARROW") ? atoi(getenv("EFFDET_IGEMM_NARROW")) : 64;     // A/B switch: max 128/64-wide tiles (0 = off); 27.91 -> 27.61 ms on the D0 step, 128 / 256 and shorter K loops measured the same
+      // A/B switch: up to how many 128/64-wide tiles (0 = off).  Round 3: 64 took the D0 step from 27.91 to 27.61 ms, 128 / 256 measured the
+      // same THERE.  Round 5: 128 -- the 224 -> 224 BiFPN convs of D4 at M = 8192 (64 x 2 wide tiles on 256 CUs, 63 K-steps each) go from
+      // 1.78 to 1.05 ms per forward (49.8 -> 84.9 TFLOP/s, 12 launches); configs[4] forward 4.758 -> 4.627 ms/img, D0 train / inference +-0
+      static const int narrow = getenv("EFFDET_IGEMM_NARROW") ? atoi(getenv("EFFDET_IGEMM_NARROW")) : 128;
       static const int narrow_k = getenv("EFFDET_IGEMM_NARROW_K") ? atoi(getenv("EFFDET_IGEMM_NARROW_K")) : 16;
       if (narrow && bn >= 64 && (long long)k.mtiles * k.ntiles <= narrow && k.Kc >= narrow_k * 8) {
         k.ntiles = (k.Cout + 31) / 32;
