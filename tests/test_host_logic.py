@@ -144,6 +144,35 @@ def test_bf16x3_rule_and_enum_values_match_header():
         ops.set_f32_arith('fp8')
 
 
+def test_model_arithmetic_names_a_forward_backward_pair():
+    """ops.MODEL_ARITH: a model's `f32_arith` names the arithmetic of the launches issued in its forward (ops.F32_ARITH) and the one its
+    autograd nodes switch to in backward (ops.F32_ARITH_BWD).  'f32_bwd_bf16x3' (the bench headline) = exact forward, bf16x3 gradients;
+    a ParamPrep carries the NAME, so set_prep() restores the forward half and the nodes' ctx.arith the backward half."""
+    import pytest
+    from efficientdet.pytorch_amd import ops, EfficientDet
+    try:
+        assert ops.MODEL_ARITH == {'f32': ('f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3'), 'f32_bwd_bf16x3': ('f32', 'bf16x3')}
+        ops.set_model_arith('f32_bwd_bf16x3')
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('f32', 'bf16x3')
+        ops.set_f32_arith(ops.F32_ARITH_BWD)                     # what a node's backward does with its ctx.arith
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('bf16x3', 'bf16x3')
+        ops.set_prep(ops.ParamPrep('f32_bwd_bf16x3'))            # the next forward of the model: back to the exact half
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('f32', 'bf16x3')
+        ops.set_prep(ops.ParamPrep('bf16x3'))
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('bf16x3', 'bf16x3')
+        with pytest.raises(ValueError):
+            ops.set_model_arith('bf16x6')
+        with pytest.raises(ValueError):
+            EfficientDet(4, W_bifpn=64, D_bifpn=2, f32_arith='fp8')
+        m = EfficientDet(4, W_bifpn=64, D_bifpn=2, f32_arith='f32_bwd_bf16x3')
+        assert m.f32_arith == 'f32_bwd_bf16x3'
+        import copy
+        assert copy.deepcopy(m).f32_arith == 'f32_bwd_bf16x3'
+    finally:
+        ops.set_prep(None)
+        ops.set_f32_arith('f32')
+
+
 def _wgrad_desc(dtype, B, cin, cout, sizes, k=1, stride=1, pad=0, ldx=None, lddz=None, image_splits=0, want_bias=True, separate=False):
     """effdet_wgrad_t over fake device pointers (planning entry points do no device work).  separate: every level in its own
     'allocation' (offsets from a common base, 4 KiB apart beyond the tensor), as the grouped BiFPN launch passes them."""
