@@ -11,8 +11,9 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
-ABI_VERSION = 7                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
+ABI_VERSION = 8                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
+F32_HSPLIT = 4                                     # the f16x3 forward arithmetic: [32 x f16 hi | 32 x f16 lo * 2^11] activations, three-piece f16 weights
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
 TUNE_IGEMM_BIG, TUNE_IGEMM_BIG_MIN_M, TUNE_SPLIT_PERS, TUNE_IGEMM_KORD, TUNE_SPLIT_KORD = 0, 1, 2, 3, 4
@@ -90,7 +91,7 @@ SYMBOLS = [
     'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',
     'effdet_clip_adamw_step', 'effdet_opt_chunk',
     'effdet_drop_connect_scales', 'effdet_philox4x32_10', 'effdet_preprocess_batch', 'effdet_finalize_dets', 'effdet_head_out_bwd',
-    'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_to_split', 'effdet_version', 'effdet_abi_version',
+    'effdet_nhwc_to_nchw_f32', 'effdet_nchw_f32_to_nhwc', 'effdet_pad_rows', 'effdet_to_split', 'effdet_to_split2', 'effdet_version', 'effdet_abi_version',
 ]
 
 

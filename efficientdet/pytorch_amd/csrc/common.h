@@ -89,6 +89,42 @@ __device__ __forceinline__ f32x4 load4(const split_t* p) {
                __uint_as_float(hi.y << 16) + __uint_as_float(lo.y << 16), __uint_as_float(hi.y & 0xffff0000u) + __uint_as_float(lo.y & 0xffff0000u)};
 }
 
+// EFFDET_F32_HSPLIT element ("H-split": the operand layout of the f16x3 arithmetic).  Same geometry as split_t -- 4 bytes per
+// element, every 128-byte group of a row = 32 channels -- but the two halves are IEEE fp16: [32 x f16 hi | 32 x f16 lo'] with
+//   hi  = RNE_f16(v)                          (denormals kept: gfx950's fp16 MFMA honours them, profiles/r06_f16x3_denormal_probe.txt)
+//   lo' = RNE_f16((v - hi) * 2^11)            (the remainder is exact in fp32; the 2^11 keeps it in fp16's NORMAL range)
+// so v = hi + lo' * 2^-11 + O(2^-22 |v|) for 2^-14 <= |v| < 65504: 22 significand bits; below 2^-14 the absolute error is <= 2^-36.
+// |v| >= 65520 overflows hi to inf and every product it enters is inf / NaN -- loud, not silent.
+// (-DEFFDET_HSPLIT_FLUSH forces a denormal hi to zero -- the value then rides in lo' alone, 11 bits: the A/B of the probe.)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint32_t pack2h(float a, float b) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+__device__ __forceinline__ float h2f(uint32_t bits16) { return (float)__builtin_bit_cast(_Float16, (uint16_t)bits16); }
+// two packed fp16: halves in the denormal range -> signed zero
+__device__ __forceinline__ uint32_t flush2h(uint32_t h) {
+#ifdef EFFDET_HSPLIT_FLUSH
+  if ((h & 0x00007c00u) == 0u) h &= 0xffff8000u;
+  if ((h & 0x7c000000u) == 0u) h &= 0x8000ffffu;
+#endif
+  return h;
+}
+// 4 consecutive channels -> (hi pairs, scaled-lo pairs)
+__device__ __forceinline__ void hsplit4(const f32x4& v, uint2& hi, uint2& lo) {
+  hi.x = flush2h(pack2h(v[0], v[1])); hi.y = flush2h(pack2h(v[2], v[3]));
+  lo.x = pack2h((v[0] - h2f(hi.x & 0xffffu)) * 2048.f, (v[1] - h2f(hi.x >> 16)) * 2048.f);
+  lo.y = pack2h((v[2] - h2f(hi.y & 0xffffu)) * 2048.f, (v[3] - h2f(hi.y >> 16)) * 2048.f);
+}
+struct hsplit_t { uint32_t bits; };
+__device__ __forceinline__ void store4(hsplit_t* p, f32x4 v) {
+  const unsigned long long a = (unsigned long long)p;
+  char* grp = (char*)(a & ~127ull) + ((a & 127ull) >> 1);
+  uint2 hi, lo;
+  hsplit4(v, hi, lo);
+  *(uint2*)grp = hi; *(uint2*)(grp + 64) = lo;
+}
+
 // 16-byte chunk <-> CE floats (CE = 4 or 8)
 template <typename T> struct Chunk;
 template <> struct Chunk<float> {

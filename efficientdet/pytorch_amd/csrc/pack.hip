@@ -32,6 +32,52 @@ __device__ __forceinline__ void store_x3(void* out, long long i, long long K, fl
   o[0] = hi; o[32] = lo;
 }
 
+// EFFDET_F32_HSPLIT weight rows (the f16x3 forward convs, conv_igemm.hip SPLIT = 3): one workgroup = 256 consecutive packed indices
+// [slice * 256, +256) of the [rows][K] matrix (K % 32 == 0, K >= 256: a slice touches at most two rows).  Row n is stored as
+// w[n] * S_n, S_n = 2^(14 - floor(log2 max|w[n]|)), in 192-byte groups of 32 k: [32 x f16 hi | 32 x f16 lo | 32 x f16 hi * 2^-11]
+// (hi = RNE_f16, lo = RNE_f16 of the exact remainder; hi * 2^-11 is the exact operand of the activation's scaled lo half), and
+// 1 / S_n goes to the float array behind the rows.  The row maximum is recomputed by every slice of the row (<= K / 256 + 1 readers of
+// a few KiB that sit in L2) so that the pack stays ONE launch with no ordering between workgroups.
+__device__ __forceinline__ void pack_h3_slice(const float* __restrict__ w, void* __restrict__ out, long long slice, int Cout, int Cin, int KH, int KW,
+                                              int Kpad, const float* __restrict__ scale, const float* __restrict__ gamma,
+                                              const float* __restrict__ var, float eps) {
+  const long long K = (long long)KH * KW * Kpad, total = (long long)Cout * K;
+  const long long i0 = slice * 256, i = i0 + threadIdx.x;
+  const long long ra = i0 / K, rb_ = (i0 + 255 < total ? i0 + 255 : total - 1) / K;
+  __shared__ float red[2][4];
+  float S[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const long long r = q == 0 ? ra : rb_;
+    float m = 0.f;
+    for (long long k = threadIdx.x; k < K; k += 256) m = fmaxf(m, fabsf(pack_elem(w, r * K + k, 0, Cout, Cin, KH, KW, Kpad, scale, gamma, var, eps)));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = m;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const float m = fmaxf(fmaxf(red[q][0], red[q][1]), fmaxf(red[q][2], red[q][3]));
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;            // floor(log2 m) for normal m
+    int sh = 14 - e; sh = sh > 100 ? 100 : (sh < -100 ? -100 : sh);
+    S[q] = (m > 0.f && m < 3.0e38f) ? __uint_as_float((unsigned)(sh + 127) << 23) : 1.0f;
+  }
+  if (i >= total) return;
+  const long long row = i / K, k = i - row * K;
+  const float s = row == ra ? S[0] : S[1];
+  const float v = pack_elem(w, i, 0, Cout, Cin, KH, KW, Kpad, scale, gamma, var, eps) * s;
+  const uint32_t hi = pack2h(v, 0.f) & 0xffffu;
+  const float hf = h2f(hi);
+  const uint32_t lo = pack2h(v - hf, 0.f) & 0xffffu, h2 = pack2h(hf * (1.0f / 2048.0f), 0.f) & 0xffffu;
+  uint16_t* o = (uint16_t*)out + row * 3 * K + (k >> 5) * 96 + (k & 31);
+  o[0] = (uint16_t)hi; o[32] = (uint16_t)lo; o[64] = (uint16_t)h2;
+  if (k == 0) ((float*)((char*)out + total * 6))[row] = 1.0f / s;
+}
+__global__ __launch_bounds__(256) void pack_w_h3_kernel(const float* __restrict__ w, const float* __restrict__ scale, void* __restrict__ out,
+                                                        int Cout, int Cin, int KH, int KW, int Cin_pad) {
+  pack_h3_slice(w, out, blockIdx.x, Cout, Cin, KH, KW, Cin_pad, scale, nullptr, nullptr, 0.f);
+}
+
 // mode 0: out[co][tap][ci]            = w[co][ci][kh][kw] * scale[co]
 // mode 1: out[ci][tap flipped][co]    = w[co][ci][KH-1-kh][KW-1-kw] * scale[co]   (data-gradient operand)
 template <typename T, bool X3 = false>
@@ -69,6 +115,10 @@ __global__ __launch_bounds__(256) void prepare_params_kernel(const effdet_prep_j
   const int j = block_job[blockIdx.x];
   const effdet_prep_job_t jb = jobs[j];
   const long long i = (long long)(blockIdx.x - block_first[j]) * 256 + threadIdx.x;
+  if (jb.kind == EFFDET_PREP_PACK0 && jb.dtype == EFFDET_F32_HSPLIT) {          // (workgroup-uniform branch: the slice reduces cooperatively)
+    pack_h3_slice(jb.a, jb.out, blockIdx.x - block_first[j], jb.n0, jb.n1, jb.n2, jb.n3, jb.n4, nullptr, jb.b, jb.c, jb.eps);
+    return;
+  }
   if (jb.kind == EFFDET_PREP_PACK0 || jb.kind == EFFDET_PREP_PACK1) {
     const int mode = jb.kind == EFFDET_PREP_PACK1;
     const long long total = (long long)(mode == 0 ? jb.n0 : jb.n1) * jb.n4 * jb.n2 * jb.n3;
@@ -153,6 +203,15 @@ __global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, 
   }
 }
 
+// plain fp32 -> split (bf16 halves) and / or H-split (f16 hi + scaled lo), 4 elements per thread
+__global__ void to_split2_kernel(const float* __restrict__ src, split_t* __restrict__ ds, hsplit_t* __restrict__ dh, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const f32x4 v = *(const f32x4*)(src + i * 4);
+    if (ds) store4(ds + i * 4, v);
+    if (dh) store4(dh + i * 4, v);
+  }
+}
+
 // plain fp32 -> split layout, 4 elements per thread (same element index on both sides; the group position follows from the address)
 __global__ void to_split_kernel(const float* __restrict__ src, split_t* __restrict__ dst, long long n4) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
@@ -187,6 +246,11 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
   else if (dtype == EFFDET_F32_BF16X3) {
     if (((long long)Cin_pad * KH * KW) % 32) return EFFDET_EUNSUPPORTED;
     hipLaunchKernelGGL((pack_w_kernel<float, true>), dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
+  } else if (dtype == EFFDET_F32_HSPLIT) {
+    // f16x3 forward operand: three f16 pieces per value of the row-scaled weights + the row scales (see pack_h3_slice)
+    const long long K = (long long)Cin_pad * KH * KW;
+    if (mode != 0 || K % 32 || K < 256) return EFFDET_EUNSUPPORTED;
+    hipLaunchKernelGGL(pack_w_h3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, scale, out, Cout, Cin, KH, KW, Cin_pad);
   } else return EFFDET_EINVAL;
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
@@ -326,6 +390,15 @@ extern "C" int effdet_to_split(const float* src, void* dst, long long n, effdet_
   return EFFDET_OK;
 }
 
+extern "C" int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, effdet_stream_t stream) {
+  if (!src || (!dst_split && !dst_hsplit) || n < 4 || (n & 3) || ((unsigned long long)src & 15ull) || ((unsigned long long)dst_split & 127ull) ||
+      ((unsigned long long)dst_hsplit & 127ull) || (const void*)src == dst_split || (const void*)src == dst_hsplit || dst_split == dst_hsplit) return EFFDET_EINVAL;
+  long long g = (n / 4 + 255) / 256; if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(to_split2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst_split, (hsplit_t*)dst_hsplit, n / 4);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
 extern "C" int effdet_scale_pack_weight(const float* w, const float* gate, void* out, int dtype, int B, int Cout, int Cin, effdet_stream_t stream) {
   if (!w || !gate || !out || B < 1 || Cout < 1 || Cin < 1) return EFFDET_EINVAL;
   if (dtype == EFFDET_F32_BF16X3 && (Cin % 32)) return EFFDET_EUNSUPPORTED;
@@ -340,5 +413,5 @@ extern "C" int effdet_scale_pack_weight(const float* w, const float* gate, void*
   return EFFDET_OK;
 }
 
-extern "C" const char* effdet_version(void) { return "effdet-hip gfx950 0.4"; }
+extern "C" const char* effdet_version(void) { return "effdet-hip gfx950 0.5"; }
 extern "C" int effdet_abi_version(void) { return EFFDET_ABI_VERSION; }

@@ -164,7 +164,11 @@ class _StemFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
+        with ops.backward_scope(ctx.prep, ctx.arith):      # this model's parameter arena + BACKWARD arithmetic; the arithmetic found at entry is put back at exit
+            return _StemFn._bwd(ctx, dy)
+
+    @staticmethod
+    def _bwd(ctx, dy):
         fused = bool(ctx.link and ctx.link.pop('dz_done', False))
         dw, dg, db = Fn.stem_bwd(ctx.saved, Map.of(dy.contiguous()), dy_is_dz=fused)
         ctx.saved = None
@@ -205,7 +209,11 @@ class _MBConvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
+        with ops.backward_scope(ctx.prep, ctx.arith):      # this model's parameter arena + BACKWARD arithmetic; the arithmetic found at entry is put back at exit
+            return _MBConvFn._bwd(ctx, dy)
+
+    @staticmethod
+    def _bwd(ctx, dy):
         with ops.unpack_batch():                                   # the node's weight-gradient unpacks leave as one launch
             dx, g = Fn.mbconv_bwd(ctx.saved, Map.of(dy.contiguous()))
         if ctx.saved['blk'].expand == 1 and ctx.saved['blk'].skip:
@@ -241,7 +249,11 @@ class _NeckFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *douts):
-        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
+        with ops.backward_scope(ctx.prep, ctx.arith):      # this model's parameter arena + BACKWARD arithmetic; the arithmetic found at entry is put back at exit
+            return _NeckFn._bwd(ctx, *douts)
+
+    @staticmethod
+    def _bwd(ctx, *douts):
         feats, lw, saved_mods, dtype, nlev, stack = ctx.saved
         d = [Map.of(t.contiguous()) for t in douts]
         mod_grads = []
@@ -277,7 +289,11 @@ class _HeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dcls, dreg):
-        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
+        with ops.backward_scope(ctx.prep, ctx.arith):      # this model's parameter arena + BACKWARD arithmetic; the arithmetic found at entry is put back at exit
+            return _HeadFn._bwd(ctx, dcls, dreg)
+
+    @staticmethod
+    def _bwd(ctx, dcls, dreg):
         saved, cls, dtype = ctx.saved
         dlogit, dr = ops.head_out_bwd(dcls.contiguous().float(), cls, dreg.contiguous().float(), dtype)
         with ops.unpack_batch():
@@ -313,7 +329,11 @@ class _HeadLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gcls, greg):
-        ops.set_prep(ctx.prep); ops.set_f32_arith(ctx.arith)       # this model's parameter arena + BACKWARD arithmetic, whatever ran in between
+        with ops.backward_scope(ctx.prep, ctx.arith):      # this model's parameter arena + BACKWARD arithmetic; the arithmetic found at entry is put back at exit
+            return _HeadLossFn._bwd(ctx, gcls, greg)
+
+    @staticmethod
+    def _bwd(ctx, gcls, greg):
         saved, cls, reg, anchors, annots, ws, dtype, dpix, dld = ctx.saved
         gscale = torch.cat([gcls.reshape(1), greg.reshape(1)]).float().contiguous()
         if dpix is not None:

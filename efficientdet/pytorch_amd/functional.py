@@ -437,14 +437,25 @@ def head_uses_split(B, sizes, Wc, dtype, arith=None):
     return _split_ok[key]
 
 
-def _pyramid_to_split(src_maps, B, sizes, C_, dtype, dev):
-    """A pyramid activation (plain fp32, one tensor per level) -> a fresh flat level-major buffer holding it in the split layout."""
-    _, dst = pyramid_alloc(B, sizes, C_, dtype, dev)
-    for s_, d_ in zip(src_maps, dst):
+def _pyramid_to_split(src_maps, B, sizes, C_, dtype, dev, bf=True, h=False):
+    """A pyramid activation (plain fp32, one tensor per level) -> fresh flat level-major buffers holding it in the split layout (bf) and /
+    or the H-split layout of the f16x3 forward convs (h), written by ONE pass per level.  -> (split maps or None, H-split maps or None)"""
+    dst = pyramid_alloc(B, sizes, C_, dtype, dev)[1] if bf else None
+    dsth = pyramid_alloc(B, sizes, C_, dtype, dev)[1] if h else None
+    for i, s_ in enumerate(src_maps):
         n = s_.B * s_.H * s_.W * s_.C
-        ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(s_.tensor()), ops.C.c_void_p(d_.addr()), ops.C.c_longlong(n), ops.L.stream_ptr()),
-                    'effdet_to_split')
-    return dst
+        if h:
+            ops.L.check(ops.L.lib().effdet_to_split2(ops.L.ptr(s_.tensor()), ops.C.c_void_p(dst[i].addr() if bf else None),
+                                                     ops.C.c_void_p(dsth[i].addr()), ops.C.c_longlong(n), ops.L.stream_ptr()), 'effdet_to_split2')
+        else:
+            ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(s_.tensor()), ops.C.c_void_p(dst[i].addr()), ops.C.c_longlong(n), ops.L.stream_ptr()),
+                        'effdet_to_split')
+    return dst, dsth
+
+
+def head_uses_f16x3(Wc, dtype):
+    """The f16x3 forward head (ops.F32_ARITH_HEAD): fp32 storage, exact-fp32 arithmetic around it, whole 32-channel groups."""
+    return HEAD_SPLIT and dtype == torch.float32 and ops.F32_ARITH == 'f32' and ops.F32_ARITH_HEAD == 'f16x3' and Wc % 32 == 0
 
 
 def head_fwd(p, HP, num_classes, dtype, train):
@@ -462,29 +473,35 @@ def head_fwd(p, HP, num_classes, dtype, train):
     A = sum(h * w for (h, w) in sizes) * 9
     split = head_uses_split(B, sizes, Wc, dtype)
     split_bwd = (not split) and train and ops.F32_ARITH_BWD == 'bf16x3' and head_uses_split(B, sizes, Wc, dtype, 'bf16x3')
-    pin = p
-    if split or split_bwd:    # the pyramid once in the split layout: operand of both towers' first conv and of their weight gradients
-        pin = _pyramid_to_split(p, B, sizes, Wc, dtype, dev)
+    # f16x3 forward (fp32-equivalent three-product fp16 form): every conv below reads H-split operands and writes H-split outputs; the
+    # backward is the split-layout bf16x3 one (split_bwd: its operands / masks ride along as `ysplit`).  Training geometries the split
+    # gradient kernels cannot take keep the exact-fp32 head.
+    hs = (not split) and head_uses_f16x3(Wc, dtype) and (split_bwd or not train)
+    pin, pin_h = p, None
+    if split or split_bwd or hs:    # the pyramid once in the split layout(s): operand of both towers' first conv and of their weight gradients
+        pin, pin_h = _pyramid_to_split(p, B, sizes, Wc, dtype, dev, bf=split or split_bwd, h=hs)
+        if pin is None:
+            pin = p
     acts = {'cls': [], 'reg': []}
     cls = torch.empty((B, A, num_classes), dtype=torch.float32, device=dev)
     reg = torch.empty((B, A, 4), dtype=torch.float32, device=dev)
 
     def tower_fwd(tower):
-        cur = p if split_bwd else pin
+        cur = pin_h if hs else (p if split_bwd else pin)
         for t in range(4):
             w, b = HP[f'{tower}_convs.{t}.weight'], HP[f'{tower}_convs.{t}.bias']
             _, nxt = pyramid_alloc(B, sizes, 256, dtype, dev)
             nxs = pyramid_alloc(B, sizes, 256, dtype, dev)[1] if split_bwd else None
-            ops.conv2d(cur, ops.pack_weight(w, dtype, x3=split), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
-                       shift=b, act=ACT_RELU, split=split, ysplit=nxs)
-            acts[tower].append(nxs if split_bwd else nxt); cur = nxt       # (split_bwd: `cur` stays plain fp32 and is not kept for backward)
+            ops.conv2d(cur, ops.pack_weight(w, dtype, x3=split, h3=hs), nxt, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
+                       shift=b, act=ACT_RELU, split=split, ysplit=nxs, hsplit=hs)
+            acts[tower].append(nxs if split_bwd else nxt); cur = nxt       # (split_bwd: `cur` stays plain fp32 / H-split and is not kept for backward)
         if tower == 'cls':
-            ops.conv2d(cur, ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split), head_out_maps(cls, B, sizes, num_classes),
+            ops.conv2d(cur, ops.pack_weight(HP['retina_cls.weight'], dtype, x3=split, h3=hs), head_out_maps(cls, B, sizes, num_classes),
                        Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
-                       act=ACT_SIGMOID, out_f32=True, split=split)
+                       act=ACT_SIGMOID, out_f32=True, split=split, hsplit=hs)
         else:
-            ops.conv2d(cur, ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split), head_out_maps(reg, B, sizes, 4),
-                       Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split)
+            ops.conv2d(cur, ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split, h3=hs), head_out_maps(reg, B, sizes, 4),
+                       Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split, hsplit=hs)
     with _Fork(dev, HEAD_TWO_STREAMS and ops.PROFILE is None) as fk:
         with fk.side():
             tower_fwd('reg')

@@ -97,6 +97,12 @@ class GraphedTrainStep:
                                'captured kernels; use optim.ClipAdamW or re-capture the step' % type(self.optimizer).__name__)
         self.graph.replay()
         ops.bump_param_generation()             # the replay rewrote the parameters through raw pointers (no Tensor._version bump)
+        # the replay's memcpy node re-installed the GRAPH's gradient-pointer table on the device: an eager ClipAdamW.step() that follows
+        # must upload its own pointers again even when p.grad sits at the addresses of the last eager step (the usual case after
+        # zero_grad(set_to_none=True)) -- otherwise its kernels would read the graph pool's gradients
+        tbl = getattr(self.optimizer, '_table', None)
+        if tbl is not None:
+            tbl['g_last'] = None
         return self.losses
 
     def _hyper_sig(self):

@@ -66,9 +66,16 @@ def _timed(name, flops, fn, note='', nbytes=0.0):
 # the losses, every ReLU / max-pool / IoU decision the backward depends on -- with exact fp32 products, bit for bit what 'f32'
 # computes, and takes only the GRADIENT convolutions (data + weight gradients) through the three-product bf16 form: their ~1e-5
 # product error lands on gradients whose masks were decided exactly, 100x inside the 1e-3 gradient gate.
+# F32_ARITH_HEAD: arithmetic of the RetinaHead's FORWARD convs when F32_ARITH is 'f32' -- 'f32' (exact), or 'f16x3': operands as
+# fp16 hi + scaled fp16 lo (22 significand bits), 3 fp16 MFMAs per product into one fp32 accumulator.  Per product ~2^-22 relative --
+# below the rounding noise of the fp32 accumulation itself (measured: outputs within 1.2x of the exact mode's distance to a float64
+# head) -- at the fp16 matrix rate: "fp32-equivalent", not bit-identical to the exact mode.
+# 'f32_hf16x3_bwd_bf16x3' = that forward head + exact fp32 everywhere else in the forward + bf16x3 gradient convs.
 F32_ARITH = 'f32'
 F32_ARITH_BWD = 'f32'
-MODEL_ARITH = {'f32': ('f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3'), 'f32_bwd_bf16x3': ('f32', 'bf16x3')}
+F32_ARITH_HEAD = 'f32'
+MODEL_ARITH = {'f32': ('f32', 'f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3', 'f32'), 'f32_bwd_bf16x3': ('f32', 'bf16x3', 'f32'),
+               'f32_hf16x3_bwd_bf16x3': ('f32', 'bf16x3', 'f16x3')}
 
 
 def set_f32_arith(mode, bwd=None):
@@ -85,8 +92,29 @@ def set_model_arith(name):
     """A model's arithmetic by name (MODEL_ARITH): forward arithmetic now, its backward arithmetic for the nodes it records."""
     if name not in MODEL_ARITH:
         raise ValueError('f32_arith must be one of %s' % (sorted(MODEL_ARITH),))
-    fwd, bwd = MODEL_ARITH[name]
+    global F32_ARITH_HEAD
+    fwd, bwd, head = MODEL_ARITH[name]
     set_f32_arith(fwd, bwd)
+    F32_ARITH_HEAD = head
+
+
+class backward_scope:
+    """with backward_scope(ctx.prep, ctx.arith): the body of an autograd node's backward -- this model's parameter arena and its BACKWARD
+    arithmetic for the launches inside, and the arithmetic found at entry put back at exit, so that direct ops.conv2d / functional.* calls
+    issued between a backward and the next model forward do not silently inherit the gradient arithmetic."""
+
+    def __init__(self, prep, arith):
+        self.prep, self.arith = prep, arith
+
+    def __enter__(self):
+        self.old = (F32_ARITH, F32_ARITH_BWD, F32_ARITH_HEAD)
+        set_prep(self.prep); set_f32_arith(self.arith)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global F32_ARITH, F32_ARITH_BWD, F32_ARITH_HEAD
+        F32_ARITH, F32_ARITH_BWD, F32_ARITH_HEAD = self.old
+        return False
 
 
 def _mma_dtype_code(dtype, K=None, N=None):
@@ -104,6 +132,8 @@ def _mma_dtype_code(dtype, K=None, N=None):
 def _igemm_symbol(dtype, desc):
     """Kernel symbol the library will launch for this descriptor (profiling attribution only)."""
     kid = int(L.lib().effdet_conv2d_kernel(C.byref(desc)))
+    if kid in (30, 31):
+        return 'conv_igemm_kernel<hsplit,%d,f16x3>' % (128, 64)[kid - 30]
     if kid >= 10000:
         return 'conv_igemm_pers_kernel<split,bf16x3>'
     if kid == 20:
@@ -257,10 +287,11 @@ class ParamPrep:
     def lookup(self, key):
         return self.outs.get(key) if self.replay else None
 
-    def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0, code=None):
+    def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0, code=None, work=None):
+        """work: number of 1-per-thread work items of the job when it is not the number of output elements (the three-piece f16 pack)."""
         if key not in self.jobs:
             self.jobs[key] = (kind, srcs, dims, dtype, shape, eps, L.dtype_code(dtype) if code is None else code,
-                              tuple(t.data_ptr() if t is not None else 0 for t in srcs))
+                              tuple(t.data_ptr() if t is not None else 0 for t in srcs), work)
             self.dirty = True
 
     def _build(self):
@@ -287,7 +318,7 @@ class ParamPrep:
             j.a, j.b, j.c, j.d = ptrs[:4]
             j.out, j.kind, j.dtype, j.eps = out.data_ptr(), kind, code, eps
             j.n0, j.n1, j.n2, j.n3, j.n4 = (list(dims) + [0] * 5)[:5]
-            blocks = (n + 255) // 256
+            blocks = ((self.jobs[k][8] or n) + 255) // 256
             block_first.append(nb); block_job += [i] * blocks; nb += blocks
             self.outs[k] = out
             if kind == PREP_BNFOLD:
@@ -325,9 +356,11 @@ def zeros(shape, device):
     return t.view(shape)
 
 
-def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
+def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False, h3=False):
     """OIHW fp32 -> packed [Cout][taps][Cin_pad] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1).
-    x3=True: always the pre-split bf16x3 operand layout (the convs on split-layout activations need it whatever the size)."""
+    x3=True: always the pre-split bf16x3 operand layout (the convs on split-layout activations need it whatever the size).
+    h3=True (mode 0, fp32 storage): the f16x3 forward operand (EFFDET_F32_HSPLIT) -- a flat fp32-typed buffer holding Cout rows of
+    row-scaled three-piece f16 groups followed by the Cout row scales 1 / S_n (conv2d(..., hsplit=True) finds them there)."""
     Cout, Cin, KH, KW = w_oihw.shape
     w = w_oihw.detach()
     assert w.dtype == torch.float32 and w.is_contiguous()
@@ -335,6 +368,11 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
         cin_pad = Cin if mode == 0 else Cout
     shape = (Cout, KH * KW, cin_pad) if mode == 0 else (Cin, KH * KW, cin_pad)
     code = L.F32_BF16X3 if x3 else _mma_dtype_code(dtype, KH * KW * cin_pad, shape[0])
+    work = None
+    if h3:
+        assert mode == 0 and dtype == torch.float32 and not x3
+        work = Cout * KH * KW * cin_pad
+        code, shape = L.F32_HSPLIT, (work * 3 // 2 + Cout,)
     PREP = get_prep()
     if PREP is not None:
         bn = PREP.bn_src.get(scale.data_ptr()) if scale is not None else None
@@ -344,7 +382,7 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False):
             if hit is not None:
                 return hit
             PREP.record(key, PREP_PACK1 if mode else PREP_PACK0, (w_oihw, bn[0] if bn else None, bn[1] if bn else None),
-                        (Cout, Cin, KH, KW, cin_pad), dtype, shape, bn[2] if bn else 0.0, code)
+                        (Cout, Cin, KH, KW, cin_pad), dtype, shape, bn[2] if bn else 0.0, code, work)
     out = torch.empty(shape, dtype=dtype, device=w.device)
     L.check(L.lib().effdet_pack_conv_weight(L.ptr(w), L.ptr(scale), L.ptr(out), code, mode,
                                             Cout, Cin, KH, KW, cin_pad, L.stream_ptr()), 'effdet_pack_conv_weight')
@@ -367,11 +405,13 @@ def scale_pack_weight(w_oihw, gate, dtype):
 
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
            res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None,
-           w_image_stride=0, ysplit=None):
+           w_image_stride=0, ysplit=None, hsplit=False):
     """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
     split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
     is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed).
-    ysplit (exact-fp32 convs only): Maps addressed like ys that receive the output a second time in the split layout."""
+    ysplit (exact-fp32 and f16x3 convs only): Maps addressed like ys that receive the output a second time in the split layout.
+    hsplit=True (EFFDET_F32_HSPLIT, the f16x3 forward arithmetic): xs hold the H-split layout ([32 x f16 hi | 32 x f16 lo * 2^11] per 32
+    channels), wp = pack_weight(..., h3=True); ys are written H-split too unless out_f32; no scale / res / rowscale."""
     if isinstance(xs, Map):
         xs, ys = [xs], [ys]
         zs = [zs] if zs is not None else None
@@ -403,7 +443,8 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
         d.y_split = bs
     d.scale, d.shift, d.rowscale = (t.data_ptr() if t is not None else None for t in (scale, shift, rowscale))
     d.bc_scale, d.bc_shift = (t.data_ptr() if t is not None else None for t in (bc_scale, bc_shift))     # [B][Cout] fp32, after rowscale, before res
-    d.dtype, d.out_f32 = (L.F32_SPLIT if split else _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout)), int(out_f32)
+    assert not (hsplit and (split or scale is not None))
+    d.dtype, d.out_f32 = (L.F32_HSPLIT if hsplit else (L.F32_SPLIT if split else _mma_dtype_code(x0.dtype, KH * KW * Cin, Cout))), int(out_f32)
     d.B, d.Cin, d.Cout, d.KH, d.KW = x0.B, Cin, Cout, KH, KW
     d.stride, d.pad_t, d.pad_l = stride, pad_t, pad_l
     d.ldx, d.ldy = x0.ld, y0.ld

@@ -39,7 +39,21 @@ enum { EFFDET_F32 = 0, EFFDET_BF16 = 1,
         * no splitting work in the loop.  Channel counts and row pitches are multiples of 32, rows 128-byte aligned.
         * effdet_conv2d: x split; w packed with EFFDET_F32_BF16X3; y split (Cout % 32 == 0; res, if any, is the EFFDET_RES_RELU_MASK
         * activation in the same layout) or, with out_f32, plain fp32 (res, if any, EFFDET_RES_ADD in plain fp32); no z. */
-       EFFDET_F32_SPLIT = 3 };
+       EFFDET_F32_SPLIT = 3,
+       /* effdet_conv2d / effdet_pack_conv_weight / EFFDET_PREP_PACK0 / effdet_to_split2 only: the "f16x3" arithmetic of the FORWARD
+        * RetinaHead (models/retinahead.py:109-129) -- fp32-equivalent products at the fp16 matrix rate.  Activations in the H-SPLIT
+        * layout: 4 bytes per element and the group geometry of EFFDET_F32_SPLIT, but the halves are IEEE fp16:
+        * [32 x f16 hi | 32 x f16 lo'], hi = RNE_f16(v) (fp16 denormals included: the matrix pipe honours them), lo' = RNE_f16((v - hi) * 2^11),
+        * i.e. v = hi + lo' * 2^-11 with 22 significand bits for 2^-14 <= |v| < 65504, absolute error <= 2^-36 below (|v| >= 65520 overflows
+        * to inf: loud).
+        * Weights packed by effdet_pack_conv_weight(dtype = EFFDET_F32_HSPLIT, mode 0): per output channel n the row w[n] * S_n (S_n = the
+        * power of two that puts max |w[n]| into [2^14, 2^15)) as 192-byte groups of 32 k: [32 x f16 hi | 32 x f16 lo | 32 x f16 hi * 2^-11],
+        * followed by Cout floats 1 / S_n; 6 * Cout * K + 4 * Cout bytes, K = KH * KW * Cin_pad, K % 32 == 0, K >= 256.
+        * effdet_conv2d: y = act(conv / S_n + shift[n]) from 3 x v_mfma_f32_16x16x32_f16 per K-step (hi*hi + lo*hi + (hi 2^-11)*(lo' 2^11)),
+        * fp32 accumulate: per product ~2^-22 relative, below the rounding noise of an fp32 accumulation.  scale / rowscale / bc_* / res / z
+        * / w_image_stride must be unset; y is H-split (Cout % 32 == 0) or, with out_f32, plain fp32; y_split (optional, y H-split) receives
+        * the values once more in the bf16 EFFDET_F32_SPLIT layout (operands / ReLU masks of the bf16x3 gradient kernels). */
+       EFFDET_F32_HSPLIT = 4 };
 enum { EFFDET_ACT_NONE = 0, EFFDET_ACT_RELU = 1, EFFDET_ACT_SWISH = 2, EFFDET_ACT_SIGMOID = 3 };
 /* what the `res` tensor of a conv does in the epilogue */
 enum { EFFDET_RES_NONE = 0, EFFDET_RES_ADD = 1, EFFDET_RES_RELU_MASK = 2, EFFDET_RES_SWISH_GRAD = 3 };
@@ -494,6 +508,10 @@ int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, lo
 /* plain fp32 -> split layout (EFFDET_F32_SPLIT), elementwise over n elements (n % 4 == 0; rows are whole 32-channel groups and
  * both buffers 128-byte aligned, so element i of src lands in the group of element i of dst).  Out of place. */
 int effdet_to_split(const float* src, void* dst, long long n, effdet_stream_t stream);
+/* The same pass writing up to two layouts of the same values: dst_split (EFFDET_F32_SPLIT, bf16 halves; may be NULL) and dst_hsplit
+ * (EFFDET_F32_HSPLIT, fp16 hi + scaled lo; may be NULL) -- the BiFPN pyramid entering the RetinaHead once as the operand of the f16x3
+ * forward convs and once as the operand of the bf16x3 weight gradients (models/retinahead.py:109-113).  Same requirements as above. */
+int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, effdet_stream_t stream);
 
 /* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
 int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);
@@ -546,7 +564,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 7
+#define EFFDET_ABI_VERSION 8
 int effdet_abi_version(void);
 
 #ifdef __cplusplus

@@ -121,8 +121,8 @@ def test_packed_images_feed_the_model_like_nchw():
     c1, r1, a1 = m.forward_raw(img)
     c2, r2, a2 = m.forward_raw(packed)
     assert torch.equal(a1, a2)
-    # (two passes differ by the fp32 atomic summation order of the SE pooling, ~1e-6 of scale)
-    assert_close_scale(c2.cpu(), c1.cpu(), 2e-5, 'cls'); assert_close_scale(r2.cpu(), r1.cpu(), 2e-5, 'reg')
+    # (the same kernels on the same values -- the path has no float atomics: bitwise equal)
+    assert torch.equal(c2, c1) and torch.equal(r2, r1)
     mb = _model('efficientdet-d0', 6, torch.bfloat16, is_training=False)
     with pytest.raises(RuntimeError):
         mb.forward_raw(packed)                               # fp32 pack into a bf16 model: refused, not reinterpreted
@@ -326,7 +326,7 @@ def test_graphed_train_step_tracks_eager():
     assert float(d.mean()) < 0.5 * lr and float(d.max()) <= 6 * 2 * lr + 1e-6, (float(d.mean()), float(d.max()))
 
 
-@pytest.mark.parametrize('arith', ['f32', 'f32_bwd_bf16x3', 'bf16x3'])
+@pytest.mark.parametrize('arith', ['f32', 'f32_bwd_bf16x3', 'f32_hf16x3_bwd_bf16x3', 'bf16x3'])
 @pytest.mark.parametrize('geom', [(4, 128, 20), (2, 256, 8)])
 def test_a_graph_replay_is_the_eager_step(arith, geom):
     """graph.replay_vs_eager: ONE eager step and ONE replay from the same restored state (parameters, Adam moments + counters, drop_connect
@@ -358,6 +358,39 @@ def test_a_graph_replay_is_the_eager_step(arith, geom):
     assert r['replay_vs_eager'] <= 1e-6, r                                          # the same kernels on the same values
     for a, b in zip(r['losses_replay'], r['losses_eager']):
         assert abs(a - b) <= 1e-6 * abs(b), r
+
+
+def test_eager_step_right_after_a_replay_reads_its_own_gradients():
+    """Order eager, replay, eager (bench.py's fall-back after a failed self-check; a second replay_vs_eager): the replay's memcpy node
+    re-installs the GRAPH's gradient-pointer table on the device, and after zero_grad(set_to_none=True) the eager gradients come back at
+    the addresses of the last eager step -- ClipAdamW must upload its pointers again instead of trusting its cache.  Twin run: the same
+    three steps with the middle one eager must give the same parameters bit for bit."""
+    from efficientdet.pytorch_amd.graph import GraphedTrainStep
+    from efficientdet.pytorch_amd.optim import ClipAdamW
+    from efficientdet.pytorch_amd import ddp
+    img, ann = O.synthetic_batch(2, 128, seed=6, num_classes=8)
+    img, ann = img.cuda(), ann.cuda()
+    res = {}
+    for mode in ('eager', 'mixed'):
+        m = _model('efficientdet-d0', 8, torch.float32, f32_arith='f32_bwd_bf16x3')
+        m.train(); m.is_training = True; m.freeze_bn(); m.backbone.drop_connect_rate = 0.0
+        ddp.freeze_dead_parameters(m)
+        opt = ClipAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-3, max_norm=0.1)
+
+        def eager():
+            opt.zero_grad(set_to_none=True)
+            cl, rl = m([img, ann]); (cl.mean() + rl.mean()).backward(); opt.step()
+        eager(); eager()
+        if mode == 'mixed':
+            g = GraphedTrainStep(m, opt, img, ann, warmup=1)      # (1 warm-up step inside) ...
+            g()                                                   # ... + one replay
+        else:
+            eager(); eager()
+        eager(); eager()                                          # eager steps right behind the replay
+        torch.cuda.synchronize()
+        res[mode] = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+    assert bool(torch.isfinite(res['mixed']).all())
+    assert torch.equal(res['eager'], res['mixed']), float((res['eager'] - res['mixed']).abs().max())
 
 
 def test_graphed_detect_matches_eager():
@@ -415,8 +448,8 @@ def test_inference_skips_param_prep_only_while_weights_are_unchanged():
 
 
 def test_interleaved_models_keep_their_own_f32_arithmetic():
-    """f32_arith is process-wide state inside ops; every forward sets it and every backward node restores the value its
-    forward ran with -- so two models with different arithmetic can interleave forward and backward passes (batched
+    """f32_arith is process-wide state inside ops; every forward sets it, every backward node runs under the value its forward
+    recorded and puts back what it found (ops.backward_scope) -- so two models with different arithmetic can interleave forward and backward passes (batched
     parameter prep on or off).  Checked on the kernels actually launched (the launch profile names them)."""
     from efficientdet.pytorch_amd import ops
     img, ann = O.synthetic_batch(2, 128, seed=13, num_classes=8)
@@ -442,7 +475,7 @@ def test_interleaved_models_keep_their_own_f32_arithmetic():
             la = ma([img, ann]); lb = mb([img, ann])                 # forward A, forward B: the global is now 'f32' ...
             assert ops.F32_ARITH == 'f32'
             ka = profiled(lambda: (la[0].mean() + la[1].mean()).backward())      # ... backward A must still run bf16x3 kernels
-            assert ops.F32_ARITH == 'bf16x3'
+            assert ops.F32_ARITH == 'f32'                                        # ... and hand the arithmetic it found back (ops.backward_scope)
             kb = profiled(lambda: (lb[0].mean() + lb[1].mean()).backward())
             assert ops.F32_ARITH == 'f32'
             assert sum('bf16x3' in k for k in ka) >= 30, ka          # head / BiFPN data gradients + every DMA-eligible weight gradient

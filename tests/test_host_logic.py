@@ -116,6 +116,10 @@ def test_conv_kernel_selection_rule():
     assert kid(L.F32_BF16X3, 32, 64, 32) == 6
     assert kid(L.F32_BF16X3, 32, 36, 256) == -3                       # K = 324: EFFDET_EUNSUPPORTED (the caller's rule never asks)
     assert kid(L.F32_BF16X3, 32, 256, 16) == 7                        # works; the Python rule just never asks (HBM-bound)
+    # the f16x3 forward form (H-split activations, three-piece f16 weights): its own kernel, 128- or 64-channel block tile
+    assert kid(L.F32_HSPLIT, 32, 256, 256) == 30 and kid(L.F32_HSPLIT, 32, 64, 256) == 30 and kid(L.F32_HSPLIT, 32, 256, 64) == 31
+    assert kid(L.F32_HSPLIT, 32, 256, 36) == -3                        # H-split output rows are whole 32-channel groups (retina_reg: out_f32)
+    assert kid(L.F32_HSPLIT, 32, 256, 256, res_mode=L.RES_RELU_MASK) == -3     # forward convs only: no residual op
 
 
 def test_bf16x3_rule_and_enum_values_match_header():
@@ -125,8 +129,9 @@ def test_bf16x3_rule_and_enum_values_match_header():
     from efficientdet.pytorch_amd import _lib as L, ops
     h = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'effdet_hip.h')).read()
     h = re.sub(r'/\*.*?\*/', '', h, flags=re.S)
-    vals = {k: int(v) for k, v in re.findall(r'(EFFDET_(?:F32|BF16|F32_BF16X3))\s*=\s*(\d+)', h)}
-    assert vals == {'EFFDET_F32': L.F32, 'EFFDET_BF16': L.BF16, 'EFFDET_F32_BF16X3': L.F32_BF16X3}
+    vals = {k: int(v) for k, v in re.findall(r'(EFFDET_(?:F32|BF16|F32_BF16X3|F32_SPLIT|F32_HSPLIT))\s*=\s*(\d+)', h)}
+    assert vals == {'EFFDET_F32': L.F32, 'EFFDET_BF16': L.BF16, 'EFFDET_F32_BF16X3': L.F32_BF16X3, 'EFFDET_F32_SPLIT': L.F32_SPLIT,
+                    'EFFDET_F32_HSPLIT': L.F32_HSPLIT}
     old = ops.set_f32_arith('bf16x3')
     try:
         f, b = torch.float32, torch.bfloat16
@@ -151,9 +156,15 @@ def test_model_arithmetic_names_a_forward_backward_pair():
     import pytest
     from efficientdet.pytorch_amd import ops, EfficientDet
     try:
-        assert ops.MODEL_ARITH == {'f32': ('f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3'), 'f32_bwd_bf16x3': ('f32', 'bf16x3')}
+        assert ops.MODEL_ARITH == {'f32': ('f32', 'f32', 'f32'), 'bf16x3': ('bf16x3', 'bf16x3', 'f32'), 'f32_bwd_bf16x3': ('f32', 'bf16x3', 'f32'),
+                                   'f32_hf16x3_bwd_bf16x3': ('f32', 'bf16x3', 'f16x3')}
+        ops.set_model_arith('f32_hf16x3_bwd_bf16x3')             # round 6 headline: + the RetinaHead's forward convs in the f16x3 form
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD, ops.F32_ARITH_HEAD) == ('f32', 'bf16x3', 'f16x3')
         ops.set_model_arith('f32_bwd_bf16x3')
-        assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('f32', 'bf16x3')
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD, ops.F32_ARITH_HEAD) == ('f32', 'bf16x3', 'f32')
+        with ops.backward_scope(None, 'bf16x3'):                 # an autograd node's backward: its arithmetic inside, the caller's back at exit
+            assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('bf16x3', 'bf16x3')
+        assert (ops.F32_ARITH, ops.F32_ARITH_BWD, ops.F32_ARITH_HEAD) == ('f32', 'bf16x3', 'f32')
         ops.set_f32_arith(ops.F32_ARITH_BWD)                     # what a node's backward does with its ctx.arith
         assert (ops.F32_ARITH, ops.F32_ARITH_BWD) == ('bf16x3', 'bf16x3')
         ops.set_prep(ops.ParamPrep('f32_bwd_bf16x3'))            # the next forward of the model: back to the exact half
