@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.p
 MAX_SEG = 5
 ABI_VERSION = 8                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
-F32_HSPLIT = 4                                     # the f16x3 forward arithmetic: [32 x f16 hi | 32 x f16 lo * 2^11] activations, three-piece f16 weights
+F32_HSPLIT = 4                                     # the f16x3 forward arithmetic: [32 x f16 hi | 32 x f16 lo * 2^11] activations, row-scaled f16 hi | lo weights
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
 RES_NONE, RES_ADD, RES_RELU_MASK, RES_SWISH_GRAD = 0, 1, 2, 3
 TUNE_IGEMM_BIG, TUNE_IGEMM_BIG_MIN_M, TUNE_SPLIT_PERS, TUNE_IGEMM_KORD, TUNE_SPLIT_KORD = 0, 1, 2, 3, 4

@@ -92,15 +92,16 @@ template <> struct Mma<float> {
 // loop has no splitting VALU at all; the byte geometry of the DMA staging is unchanged.
 // SPLIT = 3 (EFFDET_F32_HSPLIT, "f16x3"): the fp32-EQUIVALENT three-product form for the forward RetinaHead.  Activations arrive in the
 // H-split layout ([32 x f16 hi | 32 x f16 lo * 2^11] per 32 channels: 22 significand bits, the scaled lo never leaves fp16's normal
-// range), weights as THREE f16 pieces per 32-channel group (192 bytes per row and group: hi | lo | hi * 2^-11) of the row-scaled value
-// w * S_n, S_n = the power of two that puts the row's largest |w| into [2^14, 2^15) (so neither the unscaled weight lo nor hi * 2^-11
-// leaves the normal range for weights within 2^-17 of the row maximum).  A K-step is
-//     acc += Wh * Xh  +  Wl * Xh  +  (Wh * 2^-11) * (Xl * 2^11)          (3 x v_mfma_f32_16x16x32_f16, ONE fp32 accumulator)
-// and the epilogue's per-channel scale is 1 / S_n (stored behind the packed rows).  Per product the error is ~2^-22 (operand
-// truncation + the dropped lo * lo term) against the 2^-24 roundings of every fp32 accumulation -- measured on the head's shapes it is
-// lost in the accumulation noise -- at 3/8 of the matrix-pipe passes of the exact form and at the bf16 rate.
-// The third weight piece has its own LDS tile [BN rows][4 chunks] (slot = chunk ^ ((row >> 2) & 3): conflict-free 16-lane groups),
-// staged by one extra DMA instruction per wave and K-step.
+// range), weights as [32 x f16 hi | 32 x f16 lo] groups of the row-scaled value w * S_n, S_n = the power of two that puts the row's
+// largest |w| into [2^14, 2^15) (so the UNscaled weight lo stays a normal fp16 number for weights within 2^-17 of the row maximum):
+// byte for byte the geometry of SPLIT = 2, so staging, K walk and fragment reads are that kernel's.  A K-step is
+//     acc  += Wh * Xh  +  Wl * Xh            acc2 += Wh * (Xl * 2^11)            (3 x v_mfma_f32_16x16x32_f16, fp32 accumulate)
+// and the tile's value is (acc + acc2 * 2^-11) / S_n (1 / S_n: the epilogue's per-channel scale, stored behind the packed rows).  The
+// second accumulator costs 32 VGPRs (128 in all: still 4 waves / SIMD, two workgroups per CU) and nothing in the loop; a first version
+// with ONE accumulator and a third weight piece Wh * 2^-11 (own LDS tile, + 4 fragment reads and a DMA instruction per K-step)
+// measured 314 TFLOP/s on the 256 -> 256 tower conv.  Per product the error is ~2^-22 (operand truncation + the dropped lo * lo term)
+// against the 2^-24 roundings of every fp32 accumulation -- on the head's shapes it is lost in the accumulation noise (DESIGN.md
+// section 2) -- at 3/8 of the matrix-pipe passes of the exact form and at the bf16 rate.
 // NS: LDS stages of the K loop.  2 is right when two workgroups share a CU (the other one's MFMAs cover this one's DMA latency);
 // launches too small for that (<= 1 tile per CU: BiFPN convs on the coarse levels, the late backbone 1x1 convs) run ONE
 // workgroup per CU and were bound by the DMA round trip (1.27 us per K-step for 0.35 us of MFMA work): NS = 4 keeps three
@@ -114,7 +115,7 @@ template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2
 __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
   static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
   static_assert(!M32 || SPLIT == 2, "the 32x32x16 form is built for the split layout");
-  static_assert(SPLIT != 3 || (NS == 2 && NWAVES * 16 == BN), "f16x3: two stages, one third-piece DMA instruction per wave");
+  static_assert(SPLIT != 3 || NS == 2, "f16x3: two stages");
   static_assert(NS == 2 || !M32, "deep staging is not built for the 32x32 tile loop");
   constexpr int CE = Elem<T>::CE;
   constexpr int NTHREADS = NWAVES * 64;
@@ -130,8 +131,6 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   extern __shared__ __attribute__((aligned(16))) uint4 smem[];
   uint4* xs = smem;                // [NS][BM*8]
   uint4* ws = smem + NS * XLD;     // [NS][BN*8]
-  constexpr int W2LD = BN * 4;     // SPLIT == 3: the third weight piece, [NS][BN*4]
-  uint4* ws2 = ws + NS * WLD;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -177,15 +176,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   for (int j = 0; j < WROWS; ++j) {
     const int r = r0 + RSTEP * j, n = n_base + r;
     wok[j] = (r < BN) && (n < p.Cout);
-    woff[j] = SPLIT == 3 ? (unsigned)((long long)(wok[j] ? n : 0) * (p.Kc >> 3) * 192) + (unsigned)kc * 16u      // 192-byte groups: + (kq >> 3) * 192 per K-step
-                         : (unsigned)((long long)(wok[j] ? n : 0) * p.Kc * 16);
+    woff[j] = (unsigned)((long long)(wok[j] ? n : 0) * p.Kc * 16);
   }
-  // SPLIT == 3: this lane's 16 bytes of the third weight piece -- tile row wave*16 + lane/4, LDS slot lane & 3 <- source chunk slot ^ ((row >> 2) & 3)
-  const int wv_u = __builtin_amdgcn_readfirstlane(wave);
-  const int w2r = wv_u * 16 + (lane >> 2);
-  const bool w2ok = SPLIT == 3 && (n_base + w2r < p.Cout);
-  const unsigned w2off = (unsigned)((long long)(w2ok ? n_base + w2r : 0) * (p.Kc >> 3) * 192) + 128u + (unsigned)(((lane & 3) ^ ((w2r >> 2) & 3)) * 16);
-  const unsigned ws2_a = lds_addr(ws2);
   // K cursor of this thread's source chunk: chunk index kq = tap*cpt + cc.  The per-row byte offset / halo test is
   // recomputed only when the TAP changes; inside a tap (cpt > 8, e.g. 4 K-steps per tap at Cin = 256) a K-step just
   // advances every offset by 8 chunks = 128 B.  (PMC: ~3 address VALU per MFMA before this.)
@@ -212,11 +204,8 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
 #pragma unroll
     for (int j = 0; j < WROWS; ++j) {
       if (wrow0 + RSTEP * j < BN)     // wave-uniform: the whole 8-row piece is inside the weight tile
-        dma16_async(rw, ws_a + (unsigned)(buf * WLD + (wrow0 + RSTEP * j) * 8) * 16u,
-                    (kok && wok[j]) ? woff[j] + (SPLIT == 3 ? (unsigned)(kq >> 3) * 192u : (unsigned)kq * 16u) : EFFDET_OOB);
+        dma16_async(rw, ws_a + (unsigned)(buf * WLD + (wrow0 + RSTEP * j) * 8) * 16u, (kok && wok[j]) ? woff[j] + (unsigned)kq * 16u : EFFDET_OOB);
     }
-    if constexpr (SPLIT == 3)
-      dma16_async(rw, ws2_a + (unsigned)(buf * W2LD) * 16u + (unsigned)wv_u * 1024u, (kok && w2ok) ? w2off + (unsigned)(kq >> 3) * 192u : EFFDET_OOB);
     // advance the cursor by one K-step (8 chunks)
     if constexpr (SPLIT != 1) {
       if (p.kord == 1) {
@@ -337,7 +326,14 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
   } else if constexpr (SPLIT) {
     // one slice per K-step: lane (row, lq) takes chunks lq and 4 + lq = 8 floats -> one 16x16x32 operand (any k <-> lane
     // assignment works as long as both operands share it); one barrier per K-step as below.
-    struct Frags { uint4 wh[NT], wl[NT], xh[MT], xl[MT], w2[SPLIT == 3 ? NT : 1]; };
+    struct Frags { uint4 wh[NT], wl[NT], xh[MT], xl[MT]; };
+    f32x4 acc2[SPLIT == 3 ? NT : 1][SPLIT == 3 ? MT : 1];      // f16x3: the (hi, scaled lo') cross term, folded into acc as acc2 * 2^-11 after the loop
+    if constexpr (SPLIT == 3) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc2[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     auto split8 = [](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
       const unsigned v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
       unsigned h[4], l[4];
@@ -352,19 +348,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
     auto loadsp = [&](int buf, Frags& f) {
       // weights arrive pre-split (pack.hip, store_x3): chunk lq = hi, chunk 4 + lq = lo of k = 8*lq .. 8*lq+7 -- so the
       // activation side takes the same k: chunks 2*lq, 2*lq + 1 (both conflict-free under the (row>>1)&7 swizzle)
-      if constexpr (SPLIT == 3) {
-        // in the order the three terms consume them: (Wh, Xh), Wl, (W2, Xl)
-#pragma unroll
-        for (int a = 0; a < NT; ++a) f.wh[a] = ws[buf * WLD + (wn0 + a * 16 + l15) * 8 + (lq ^ lsw)];
-#pragma unroll
-        for (int b = 0; b < MT; ++b) f.xh[b] = xs[buf * XLD + (wm0 + b * 16 + l15) * 8 + (lq ^ lsw)];
-#pragma unroll
-        for (int a = 0; a < NT; ++a) f.wl[a] = ws[buf * WLD + (wn0 + a * 16 + l15) * 8 + ((4 + lq) ^ lsw)];
-#pragma unroll
-        for (int b = 0; b < MT; ++b) f.xl[b] = xs[buf * XLD + (wm0 + b * 16 + l15) * 8 + ((4 + lq) ^ lsw)];
-#pragma unroll
-        for (int a = 0; a < NT; ++a) f.w2[a] = ws2[buf * W2LD + (wn0 + a * 16 + l15) * 4 + (lq ^ ((l15 >> 2) & 3))];
-      } else if constexpr (SPLIT == 2) {
+      if constexpr (SPLIT >= 2) {
         // both operands pre-split: the hi fragments first, so that the hi*hi MFMAs can start while the lo fragments are in flight
 #pragma unroll
         for (int a = 0; a < NT; ++a) f.wh[a] = ws[buf * WLD + (wn0 + a * 16 + l15) * 8 + (lq ^ lsw)];
@@ -396,7 +380,7 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
         for (int a = 0; a < NT; ++a)
 #pragma unroll
           for (int b = 0; b < MT; ++b) {
-            if constexpr (SPLIT == 3) MmaH::run(t == 0 ? f.wh[a] : (t == 1 ? f.wl[a] : f.w2[a]), t == 2 ? f.xl[b] : f.xh[b], acc[a][b]);
+            if constexpr (SPLIT == 3) MmaH::run(t == 2 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], t == 1 ? acc2[a][b] : acc[a][b]);
             else if constexpr (SPLIT == 2) Mma<bf16_t>::run(t == 2 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
             else Mma<bf16_t>::run(t == 0 ? f.wl[a] : f.wh[a], t == 1 ? f.xl[b] : f.xh[b], acc[a][b]);
           }
@@ -421,6 +405,12 @@ __global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) 
         __syncthreads();                   // ... for everyone, and every wave has read tile kt out of buffer c
         if (issued < nk) { stage(c); ++issued; }
       }
+    }
+    if constexpr (SPLIT == 3) {
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] += acc2[a][b] * (1.0f / 2048.0f);
     }
   } else {
     uint4 wfA[NT], xfA[MT], wfB[NT], xfB[MT];
@@ -1205,7 +1195,7 @@ static int big_variant() {
 
 template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2, int M32 = 0>
 int launch(const ConvK& k, hipStream_t st) {
-  const size_t lds = (size_t)NS * (BM + BN) * 8 * sizeof(uint4) + (SPLIT == 3 ? (size_t)NS * BN * 4 * sizeof(uint4) : 0);   // NS-stage operand tiles
+  const size_t lds = (size_t)NS * (BM + BN) * 8 * sizeof(uint4);                    // NS-stage operand tiles
   const int grid = k.mtiles * k.ntiles;
   if (lds > 48 * 1024) EFFDET_SET_MAX_LDS((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS, M32>), lds);
   hipLaunchKernelGGL((conv_igemm_kernel<T, BN, WAVES_N, NWAVES, SPLIT, NS, M32>), dim3(grid), dim3(NWAVES * 64), lds, st, k);
@@ -1337,7 +1327,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     if (e >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
     k.seg[s].x_bytes = (unsigned)e;
   }
-  const long long wb = hfmt ? (long long)p->Cout * (k.Kc >> 3) * 192 : (long long)p->Cout * k.Kc * 16;
+  const long long wb = (long long)p->Cout * k.Kc * 16;
   if (wb >= 0xFFFF0000LL) return EFFDET_EUNSUPPORTED;
   k.w_bytes = (unsigned)wb;
   if (hfmt) {

@@ -34,10 +34,11 @@ __device__ __forceinline__ void store_x3(void* out, long long i, long long K, fl
 
 // EFFDET_F32_HSPLIT weight rows (the f16x3 forward convs, conv_igemm.hip SPLIT = 3): one workgroup = 256 consecutive packed indices
 // [slice * 256, +256) of the [rows][K] matrix (K % 32 == 0, K >= 256: a slice touches at most two rows).  Row n is stored as
-// w[n] * S_n, S_n = 2^(14 - floor(log2 max|w[n]|)), in 192-byte groups of 32 k: [32 x f16 hi | 32 x f16 lo | 32 x f16 hi * 2^-11]
-// (hi = RNE_f16, lo = RNE_f16 of the exact remainder; hi * 2^-11 is the exact operand of the activation's scaled lo half), and
-// 1 / S_n goes to the float array behind the rows.  The row maximum is recomputed by every slice of the row (<= K / 256 + 1 readers of
-// a few KiB that sit in L2) so that the pack stays ONE launch with no ordering between workgroups.
+// w[n] * S_n, S_n = 2^(14 - floor(log2 max|w[n]|)), in the 128-byte groups of the bf16x3 pack but with fp16 halves:
+// [32 x f16 hi | 32 x f16 lo] (hi = RNE_f16, lo = RNE_f16 of the exact remainder -- a normal fp16 number for every weight within 2^-17
+// of the row maximum, thanks to the row scale), and 1 / S_n goes to the float array behind the rows.  The row maximum is recomputed by
+// every slice of the row (<= K / 256 + 1 readers of a few KiB that sit in L2) so that the pack stays ONE launch with no ordering between
+// workgroups.
 __device__ __forceinline__ void pack_h3_slice(const float* __restrict__ w, void* __restrict__ out, long long slice, int Cout, int Cin, int KH, int KW,
                                               int Kpad, const float* __restrict__ scale, const float* __restrict__ gamma,
                                               const float* __restrict__ var, float eps) {
@@ -68,10 +69,10 @@ __device__ __forceinline__ void pack_h3_slice(const float* __restrict__ w, void*
   const float v = pack_elem(w, i, 0, Cout, Cin, KH, KW, Kpad, scale, gamma, var, eps) * s;
   const uint32_t hi = pack2h(v, 0.f) & 0xffffu;
   const float hf = h2f(hi);
-  const uint32_t lo = pack2h(v - hf, 0.f) & 0xffffu, h2 = pack2h(hf * (1.0f / 2048.0f), 0.f) & 0xffffu;
-  uint16_t* o = (uint16_t*)out + row * 3 * K + (k >> 5) * 96 + (k & 31);
-  o[0] = (uint16_t)hi; o[32] = (uint16_t)lo; o[64] = (uint16_t)h2;
-  if (k == 0) ((float*)((char*)out + total * 6))[row] = 1.0f / s;
+  const uint32_t lo = pack2h(v - hf, 0.f) & 0xffffu;
+  uint16_t* o = (uint16_t*)out + row * 2 * K + (k >> 5) * 64 + (k & 31);
+  o[0] = (uint16_t)hi; o[32] = (uint16_t)lo;
+  if (k == 0) ((float*)((char*)out + total * 4))[row] = 1.0f / s;
 }
 __global__ __launch_bounds__(256) void pack_w_h3_kernel(const float* __restrict__ w, const float* __restrict__ scale, void* __restrict__ out,
                                                         int Cout, int Cin, int KH, int KW, int Cin_pad) {
@@ -247,7 +248,7 @@ extern "C" int effdet_pack_conv_weight(const float* w, const float* scale, void*
     if (((long long)Cin_pad * KH * KW) % 32) return EFFDET_EUNSUPPORTED;
     hipLaunchKernelGGL((pack_w_kernel<float, true>), dim3(grid_for(n)), dim3(256), 0, st, w, scale, (float*)out, mode, Cout, Cin, KH, KW, Cin_pad);
   } else if (dtype == EFFDET_F32_HSPLIT) {
-    // f16x3 forward operand: three f16 pieces per value of the row-scaled weights + the row scales (see pack_h3_slice)
+    // f16x3 forward operand: f16 hi | lo pairs of the row-scaled weights + the row scales (see pack_h3_slice)
     const long long K = (long long)Cin_pad * KH * KW;
     if (mode != 0 || K % 32 || K < 256) return EFFDET_EUNSUPPORTED;
     hipLaunchKernelGGL(pack_w_h3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, scale, out, Cout, Cin, KH, KW, Cin_pad);

@@ -288,7 +288,7 @@ class ParamPrep:
         return self.outs.get(key) if self.replay else None
 
     def record(self, key, kind, srcs, dims, dtype, shape, eps=0.0, code=None, work=None):
-        """work: number of 1-per-thread work items of the job when it is not the number of output elements (the three-piece f16 pack)."""
+        """work: number of 1-per-thread work items of the job when it is not the number of output elements (the f16x3 pack: rows + row scales)."""
         if key not in self.jobs:
             self.jobs[key] = (kind, srcs, dims, dtype, shape, eps, L.dtype_code(dtype) if code is None else code,
                               tuple(t.data_ptr() if t is not None else 0 for t in srcs), work)
@@ -360,7 +360,7 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False, h3=Fa
     """OIHW fp32 -> packed [Cout][taps][Cin_pad] (mode 0) or data-gradient operand [Cin][taps'][Cout] (mode 1).
     x3=True: always the pre-split bf16x3 operand layout (the convs on split-layout activations need it whatever the size).
     h3=True (mode 0, fp32 storage): the f16x3 forward operand (EFFDET_F32_HSPLIT) -- a flat fp32-typed buffer holding Cout rows of
-    row-scaled three-piece f16 groups followed by the Cout row scales 1 / S_n (conv2d(..., hsplit=True) finds them there)."""
+    row-scaled [32 x f16 hi | 32 x f16 lo] groups followed by the Cout row scales 1 / S_n (conv2d(..., hsplit=True) finds them there)."""
     Cout, Cin, KH, KW = w_oihw.shape
     w = w_oihw.detach()
     assert w.dtype == torch.float32 and w.is_contiguous()
@@ -372,7 +372,7 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False, h3=Fa
     if h3:
         assert mode == 0 and dtype == torch.float32 and not x3
         work = Cout * KH * KW * cin_pad
-        code, shape = L.F32_HSPLIT, (work * 3 // 2 + Cout,)
+        code, shape = L.F32_HSPLIT, (work + Cout,)
     PREP = get_prep()
     if PREP is not None:
         bn = PREP.bn_src.get(scale.data_ptr()) if scale is not None else None

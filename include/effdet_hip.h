@@ -47,10 +47,11 @@ enum { EFFDET_F32 = 0, EFFDET_BF16 = 1,
         * i.e. v = hi + lo' * 2^-11 with 22 significand bits for 2^-14 <= |v| < 65504, absolute error <= 2^-36 below (|v| >= 65520 overflows
         * to inf: loud).
         * Weights packed by effdet_pack_conv_weight(dtype = EFFDET_F32_HSPLIT, mode 0): per output channel n the row w[n] * S_n (S_n = the
-        * power of two that puts max |w[n]| into [2^14, 2^15)) as 192-byte groups of 32 k: [32 x f16 hi | 32 x f16 lo | 32 x f16 hi * 2^-11],
-        * followed by Cout floats 1 / S_n; 6 * Cout * K + 4 * Cout bytes, K = KH * KW * Cin_pad, K % 32 == 0, K >= 256.
-        * effdet_conv2d: y = act(conv / S_n + shift[n]) from 3 x v_mfma_f32_16x16x32_f16 per K-step (hi*hi + lo*hi + (hi 2^-11)*(lo' 2^11)),
-        * fp32 accumulate: per product ~2^-22 relative, below the rounding noise of an fp32 accumulation.  scale / rowscale / bc_* / res / z
+        * power of two that puts max |w[n]| into [2^14, 2^15)) as 128-byte groups of 32 k: [32 x f16 hi | 32 x f16 lo] (lo unscaled: the row
+        * scale keeps it normal), followed by Cout floats 1 / S_n; 4 * Cout * K + 4 * Cout bytes, K = KH * KW * Cin_pad, K % 32 == 0, K >= 256.
+        * effdet_conv2d: y = act(conv / S_n + shift[n]) from 3 x v_mfma_f32_16x16x32_f16 per K-step (hi*hi + lo*hi into one fp32
+        * accumulator, hi*lo' into a second one that enters as * 2^-11): per product ~2^-22 relative, below the rounding noise of an fp32
+        * accumulation.  scale / rowscale / bc_* / res / z
         * / w_image_stride must be unset; y is H-split (Cout % 32 == 0) or, with out_f32, plain fp32; y_split (optional, y H-split) receives
         * the values once more in the bf16 EFFDET_F32_SPLIT layout (operands / ReLU masks of the bf16x3 gradient kernels). */
        EFFDET_F32_HSPLIT = 4 };
