@@ -1,6 +1,6 @@
 """configs[1] / configs[4]: eval forward + decode + on-device NMS on random-init weights (every anchor a candidate: the NMS worst case).
 Prints the forward alone, eager detect, the ONE-graph detect (graph.GraphedDetect) and the post-processing alone (decode + NMS + gather).
-    python tools/infer_bench.py [--network efficientdet-d0 --batch 32 --size 512 --reps 10 --dtype f32_bf16x3|f32|bf16]"""
+    python tools/infer_bench.py [--network efficientdet-d0 --batch 32 --size 512 --reps 10 --dtype f32_hf16x3|f32_bf16x3|f32|bf16]"""
 import argparse
 import os
 import sys
@@ -21,7 +21,7 @@ cfg = EFFICIENTDET[a.network]
 torch.manual_seed(0)
 m = EfficientDet(80, network=a.network, W_bifpn=cfg['W_bifpn'], D_bifpn=cfg['D_bifpn'], D_class=cfg['D_class'], is_training=False,
                  compute_dtype=torch.bfloat16 if a.dtype == 'bf16' else torch.float32,
-                 f32_arith='bf16x3' if a.dtype == 'f32_bf16x3' else 'f32').cuda().eval()
+                 f32_arith={'f32_bf16x3': 'bf16x3', 'f32_hf16x3': 'f32_hf16x3_bwd_bf16x3'}.get(a.dtype, 'f32')).cuda().eval()
 img = torch.randn(a.batch, 3, a.size, a.size, device='cuda')
 
 
