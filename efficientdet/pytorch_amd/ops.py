@@ -371,8 +371,8 @@ def pack_weight(w_oihw, dtype, mode=0, scale=None, cin_pad=None, x3=False, h3=Fa
     work = None
     if h3:
         assert mode == 0 and dtype == torch.float32 and not x3
-        work = Cout * KH * KW * cin_pad
-        code, shape = L.F32_HSPLIT, (work + Cout,)
+        work = Cout * 256                                   # one 256-thread workgroup per output row (it derives the row's scale)
+        code, shape = L.F32_HSPLIT, (Cout * KH * KW * cin_pad + Cout,)
     PREP = get_prep()
     if PREP is not None:
         bn = PREP.bn_src.get(scale.data_ptr()) if scale is not None else None

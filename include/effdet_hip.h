@@ -244,11 +244,12 @@ int effdet_backward_tail(const effdet_tail_job_t* jobs, int njobs, effdet_stream
  *   EFFDET_PREP_BNFOLD           effdet_bn_fold      (a gamma, b beta, c mean, d var -> out = scale|shift|invstd, 3*n0)
  *   EFFDET_PREP_DWPACK           effdet_dw_pack_weight (a: [C][1][k][k] -> out [k*k][C] fp32;  n0 = C, n2 = k*k)
  * jobs / block_job / block_first are DEVICE arrays: workgroup i handles elements [256*(i - block_first[j]), +256) of job
- * j = block_job[i].  The table is built once per model (parameter storage is stable) and replayed every step. */
+ * j = block_job[i] -- except a PACK0 job with dtype EFFDET_F32_HSPLIT, which takes ONE WORKGROUP PER OUTPUT ROW (n0 workgroups: the row's
+ * scale is a reduction over the row).  The table is built once per model (parameter storage is stable) and replayed every step. */
 enum { EFFDET_PREP_PACK0 = 0, EFFDET_PREP_PACK1 = 1, EFFDET_PREP_BNFOLD = 2, EFFDET_PREP_DWPACK = 3 };
 typedef struct {
   const float* a; const float* b; const float* c; const float* d; void* out;
-  int kind, dtype;         /* dtype of `out` for the PACK jobs (EFFDET_F32 / EFFDET_BF16) */
+  int kind, dtype;         /* dtype of `out` for the PACK jobs (EFFDET_F32 / EFFDET_BF16 / EFFDET_F32_BF16X3 / EFFDET_F32_HSPLIT) */
   int n0, n1, n2, n3, n4;  /* PACK: Cout, Cin, KH, KW, Kpad;  BNFOLD: C;  DWPACK: C, -, k*k */
   float eps;
 } effdet_prep_job_t;

@@ -104,7 +104,7 @@ def finalize_reference(scores, labels, boxes, scale, score_threshold=0.05, max_d
     """eval.py:104-117 for one image: -> image_detections [n, 6] = boxes/scale, score, label."""
     scores = np.asarray(scores, dtype=np.float32).copy(); labels = np.asarray(labels).copy()
     boxes = np.asarray(boxes, dtype=np.float32).copy()
-    boxes /= scale
+    boxes /= float(scale)        # (the reference's scale is a PYTHON float, datasets/augmentation.py:100-104: the division runs in float32)
     indices = np.where(scores > score_threshold)[0]
     if indices.shape[0] == 0:
         return np.zeros((0, 6), dtype=np.float32)
@@ -117,7 +117,7 @@ def finalize_reference(scores, labels, boxes, scale, score_threshold=0.05, max_d
 def coco_results_reference(scores, labels, boxes, scale, image_id, threshold=0.05, label_to_coco_label=lambda c: c):
     """eval.py:279-306 for one image (scores descending)."""
     boxes = np.asarray(boxes, dtype=np.float32).copy()
-    boxes /= scale
+    boxes /= float(scale)
     res = []
     if boxes.shape[0] > 0:
         boxes[:, 2] -= boxes[:, 0]; boxes[:, 3] -= boxes[:, 1]

@@ -110,6 +110,57 @@ def test_device_collater_vs_reference_chain(dtype):
         np.testing.assert_allclose(got[5, :3], want, rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_device_collater_vs_the_reference_source_golden(golden_dir, dtype):
+    """The same launch against tests/golden/pipeline_chain.npz -- the chain executed from the reference's own source text
+    (datasets/augmentation.py:69-150; cv2.resize alone is the restated rule): images within fp32 rounding of the float64 host arithmetic,
+    annotation rows and scales to fp32 rounding, the Augmenter's flip decisions injected."""
+    import types
+    from efficientdet.pytorch_amd.data import DeviceCollater
+    from efficientdet.pytorch_amd import ops
+    g = np.load(os.path.join(golden_dir, 'pipeline_chain.npz'), allow_pickle=False)
+    n, S = int(g['n']), int(g['S'])
+    samples = [{'img': g[f'img{i}'], 'annot': g[f'annot{i}']} for i in range(n)]
+    col = DeviceCollater(common_size=S, dtype=dtype, flip_x=0.5, seed=0)
+    col.rng = types.SimpleNamespace(rand=lambda B: np.where(g['flips'], 0.0, 1.0))          # the reference run's own draws
+    packed, ann, scale = col(samples)
+    got = ops.nhwc_to_nchw(packed.map).cpu().numpy()
+    ref = g['out_imgs']
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    assert got.shape[0] == n and np.abs(got[:, :3] - ref).max() <= tol * max(1.0, np.abs(ref).max()), np.abs(got[:, :3] - ref).max()
+    assert np.all(got[:, 3:] == 0)
+    np.testing.assert_allclose(scale.cpu().numpy(), g['out_scales'], rtol=1e-6)
+    np.testing.assert_allclose(ann.cpu().numpy(), g['out_annots'], rtol=1e-5, atol=1e-4)
+
+
+def test_eval_consumer_vs_the_reference_source_golden(golden_dir):
+    """evaluate.finalize / all_detections_rows / coco_results against tests/golden/eval_consumer.npz -- eval.py:76-136 and :260-338
+    executed from the reference's own source text on replayed detection lists: every row bit for bit (same fp32 divisions)."""
+    from efficientdet.pytorch_amd import evaluate as EV
+    g = np.load(os.path.join(golden_dir, 'eval_consumer.npz'), allow_pickle=False)
+    NC, thr, mx = int(g['num_classes']), float(g['score_threshold']), int(g['max_detections'])
+    B = len(g['scales'])
+    A = max(len(g[f'in{i}_scores']) for i in range(B))
+    s = torch.zeros(B, A); l = torch.zeros(B, A, dtype=torch.int64); b = torch.zeros(B, A, 4); cnt = torch.zeros(B, dtype=torch.int32)
+    for i in range(B):
+        k = len(g[f'in{i}_scores']); cnt[i] = k
+        s[i, :k] = torch.from_numpy(g[f'in{i}_scores']); l[i, :k] = torch.from_numpy(g[f'in{i}_labels']); b[i, :k] = torch.from_numpy(g[f'in{i}_boxes'])
+    scales = [float(v) for v in g['scales']]                                    # python floats, as the reference's Resizer returns them
+    dets, counts = EV.finalize(s.cuda(), l.cuda(), b.cuda(), cnt.cuda(), scales, score_threshold=thr, max_detections=mx)
+    rows = EV.all_detections_rows(dets, counts, NC)
+    for i in range(B):
+        for c in range(NC):
+            want = g[f'det{i}_class{c}']
+            assert rows[i][c].shape == want.shape and np.array_equal(np.asarray(rows[i][c], dtype=np.float64), want), (i, c)
+    dx, cx = EV.finalize(s.cuda(), l.cuda(), b.cuda(), cnt.cuda(), scales, score_threshold=thr, xywh=True)
+    a_, b_ = int(g['coco_label_a']), int(g['coco_label_b'])
+    res = EV.coco_results(dx, cx, image_ids=[int(v) for v in g['image_ids']], label_to_coco_label=lambda c: a_ + b_ * c)
+    assert len(res) == len(g['coco_score']) > 100
+    assert [r['image_id'] for r in res] == g['coco_image_id'].tolist() and [r['category_id'] for r in res] == g['coco_category_id'].tolist()
+    assert np.array_equal(np.array([r['score'] for r in res]), g['coco_score'])
+    assert np.array_equal(np.array([r['bbox'] for r in res], dtype=np.float64), g['coco_bbox'])
+
+
 def test_packed_images_feed_the_model_like_nchw():
     """model(PackedImages) == model(NCHW tensor holding the same values): the stem reads the packed batch directly."""
     from efficientdet.pytorch_amd import ops, PackedImages

@@ -92,6 +92,43 @@ def test_finalize_oracle_formats():
     assert len(r) == 3 and r[0]['bbox'] == [0.0, 0.5, 1.0, 1.0] and r[2]['category_id'] == 1 and r[0]['image_id'] == 7
 
 
+def test_pipeline_oracle_is_pinned_on_the_reference_source_chain(golden_dir):
+    """tests/golden/pipeline_chain.npz: Normalizer -> Augmenter -> Resizer -> collater executed FROM THE REFERENCE'S SOURCE TEXT
+    (oracle/make_golden.py::case_pipeline_chain; only cv2.resize is a stub = the restated INTER_LINEAR rule, which therefore stays
+    "parity unpinned").  The oracle's chain must reproduce it bit for bit: normalisation in float64, flip + box mirror, the int()
+    truncated resize geometry, zero canvas, annotation scale, -1 padding to the longest list, NCHW."""
+    g = np.load(os.path.join(golden_dir, 'pipeline_chain.npz'), allow_pickle=False)
+    n, S = int(g['n']), int(g['S'])
+    samples = [{'img': g[f'img{i}'], 'annot': g[f'annot{i}']} for i in range(n)]
+    imgs, ann, scales = PO.collate_reference(samples, S, g['flips'])
+    assert imgs.shape == g['out_imgs'].shape and np.array_equal(imgs, g['out_imgs'])
+    assert ann.shape == g['out_annots'].shape and np.array_equal(ann, g['out_annots'])
+    assert np.array_equal(scales, g['out_scales'])
+    assert g['flips'].any() and not g['flips'].all() and (g['out_annots'][2] == -1).all()        # both branches, an empty annotation list
+
+
+def test_eval_oracle_is_pinned_on_the_reference_source_loops(golden_dir):
+    """tests/golden/eval_consumer.npz: eval.py:76-136 `_get_detections` and eval.py:260-338 `evaluate_coco` executed from the reference's
+    source text on replayed detection lists (an image above the top-100 cut, one with nothing above the threshold, an empty one, a short
+    one).  finalize_reference / coco_results_reference must reproduce every row."""
+    g = np.load(os.path.join(golden_dir, 'eval_consumer.npz'), allow_pickle=False)
+    NC, thr, mx = int(g['num_classes']), float(g['score_threshold']), int(g['max_detections'])
+    rows = []
+    for i, scale in enumerate(g['scales']):
+        s, l, b = g[f'in{i}_scores'], g[f'in{i}_labels'], g[f'in{i}_boxes']
+        d = PO.finalize_reference(s, l, b, scale, thr, mx)
+        for c in range(NC):
+            want = g[f'det{i}_class{c}']
+            got = d[d[:, -1] == c, :-1] if len(d) else np.zeros((0, 5))
+            assert got.shape == want.shape and np.array_equal(got.astype(np.float64), want), (i, c)
+        rows += PO.coco_results_reference(s, l, b, scale, int(g['image_ids'][i]), thr,
+                                          lambda c: int(g['coco_label_a']) + int(g['coco_label_b']) * c)
+    assert len(rows) == len(g['coco_score']) > 100
+    assert [r['image_id'] for r in rows] == g['coco_image_id'].tolist() and [r['category_id'] for r in rows] == g['coco_category_id'].tolist()
+    assert np.array_equal(np.array([r['score'] for r in rows]), g['coco_score'])
+    assert np.array_equal(np.array([r['bbox'] for r in rows], dtype=np.float64), g['coco_bbox'])
+
+
 def test_checkpoint_roundtrip_prefix_and_pretrained(tmp_path):
     from efficientdet.pytorch_amd import EfficientDet, checkpoint as ck
     m = EfficientDet(4, network='efficientdet-d0', W_bifpn=64, D_bifpn=2)
