@@ -86,7 +86,7 @@ SYMBOLS = [
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
     'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_mbconv_expand_dw_fwd', 'effdet_mbconv_expand_dw_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
-    'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_bwd',
+    'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_fwd2', 'effdet_bifpn_fuse_bwd',
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
     'effdet_gather_dets', 'effdet_loss_workspace_bytes', 'effdet_focal_loss_fwd', 'effdet_focal_loss_bwd', 'effdet_focal_loss_bwd_pix', 'effdet_focal_loss_fwd_grad', 'effdet_focal_loss_bwd_reg',
     'effdet_clip_adamw_step', 'effdet_opt_chunk',

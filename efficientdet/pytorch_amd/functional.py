@@ -23,6 +23,10 @@ EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training:
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage: expand conv inside the depthwise kernel
 FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').split(','))     # block input widths that take it (A/B)
+# f16x3 BiFPN convs from this much work per launch (output pixels x C^2; x 18 = FLOPs): below ~2 GFLOP the launch is a handful of tiles behind a
+# DMA round trip and the exact kernel's deep-staged narrow tiles win (measured, D4 B = 8 @1024, 224 -> 224: M = 8192 87 -> 63 us, M = 2048
+# 56 -> 61, M = 512 55 -> 61; D0 B = 32 @512, 64 -> 64: M = 131072 97 -> 59, M = 32768 35 -> 27, M = 8192 22 -> 27)
+BIFPN_F16X3_MIN_WORK = float(os.environ.get('EFFDET_BIFPN_F16X3_MIN_WORK', '1.2e8'))
 GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
 # ... in training too (fp32 storage, fused SE backward): built, tested, and OFF -- the depthwise forward must then store its Swish
 # output next to the pre-activation, which costs what channel_scale's pass did: 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on)
@@ -261,9 +265,15 @@ def lateral_bwd(feats, weights, douts, dtype):
     return dfs, dws, dbs
 
 
-def _conv3_fwd(x, w, b, dtype):
-    y = Map.new(x.B, x.H, x.W, w.shape[0], dtype, x.t.device)
-    ops.conv2d(x, ops.pack_weight(w, dtype), y, Cin=w.shape[1], Cout=w.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, shift=b)
+def _conv3_fwd(x, w, b, dtype, xh=None):
+    """xh: the same input in the H-split layout -> the conv runs in the f16x3 arithmetic (plain fp32 output)."""
+    src = x if xh is None else xh
+    y = Map.new(src.B, src.H, src.W, w.shape[0], dtype, src.t.device)
+    if xh is not None:
+        ops.conv2d(xh, ops.pack_weight(w, dtype, h3=True), y, Cin=w.shape[1], Cout=w.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, shift=b,
+                   hsplit=True, out_f32=True)
+    else:
+        ops.conv2d(x, ops.pack_weight(w, dtype), y, Cin=w.shape[1], Cout=w.shape[0], KH=3, KW=3, pad_t=1, pad_l=1, shift=b)
     return y
 
 
@@ -277,19 +287,27 @@ def bifpn_module_fwd(p, w1, w2, cw, cb, dtype, train):
     nodes = []            # (mode, col, wsel, a_name, b_name, c_name, out_name, fused Map)
     names = {('in', l): t_in[l] for l in range(L_)}
     c = 0
+    # f16x3 (ops.F32_ARITH_HEAD, the headline mode): the node's 3x3 conv reads the fused map in the H-split layout, which the fusion kernel
+    # writes itself (inference: instead of the plain map; training: next to it -- the conv's weight gradient reads the plain one)
+    hs = head_uses_f16x3(cw[0].shape[0], dtype) and cw[0].shape[1] == cw[0].shape[0]
+
+    def fuse(a, b, cc, w, col, mode):
+        if not hs or a.B * a.H * a.W * a.C * a.C < BIFPN_F16X3_MIN_WORK:
+            return ops.bifpn_fuse_fwd(a, b, cc, w, col, mode), None
+        return ops.bifpn_fuse_fwd(a, b, cc, w, col, mode, plain=train, hsplit=True)
     for i in range(L_ - 1, 0, -1):                                  # top-down, bifpn.py:188-192
         a_n = ('in', i - 1); b_n = ('in', i) if i == L_ - 1 else ('td', i)
-        f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], None, w1, i - 1, 0)
-        out_n = ('td', i - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+        f, fh = fuse(names[a_n], names[b_n], None, w1, i - 1, 0)
+        out_n = ('td', i - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype, fh)
         nodes.append((0, i - 1, 1, a_n, b_n, None, out_n, f, c)); c += 1
     for i in range(0, L_ - 2):                                      # bottom-up, bifpn.py:194-198
         a_n = ('td', i + 1); b_n = ('td', 0) if i == 0 else ('bu', i); c_n = ('in', i + 1)
-        f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], names[c_n], w2, i, 1)
-        out_n = ('bu', i + 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+        f, fh = fuse(names[a_n], names[b_n], names[c_n], w2, i, 1)
+        out_n = ('bu', i + 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype, fh)
         nodes.append((1, i, 2, a_n, b_n, c_n, out_n, f, c)); c += 1
     a_n = ('in', L_ - 1); b_n = ('bu', L_ - 2)                      # top node, bifpn.py:200-202
-    f = ops.bifpn_fuse_fwd(names[a_n], names[b_n], None, w1, L_ - 1, 2)
-    out_n = ('top', L_ - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype)
+    f, fh = fuse(names[a_n], names[b_n], None, w1, L_ - 1, 2)
+    out_n = ('top', L_ - 1); names[out_n] = _conv3_fwd(f, cw[c], cb[c], dtype, fh)
     nodes.append((2, L_ - 1, 1, a_n, b_n, None, out_n, f, c))
     out_names = [('td', 0)] + [('bu', l) for l in range(1, L_ - 1)] + [out_n]
     outs = [names[n] for n in out_names]

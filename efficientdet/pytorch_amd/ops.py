@@ -931,13 +931,15 @@ def colsum(t2d, out):
 
 
 # ----------------------------------------------------------------------------- BiFPN fusion
-def bifpn_fuse_fwd(a, b, c, wraw, col, mode):
-    out = Map.new(a.B, a.H, a.W, a.C, a.dtype, a.t.device)
+def bifpn_fuse_fwd(a, b, c, wraw, col, mode, plain=True, hsplit=False):
+    """-> the fused map (plain Map), or with hsplit=True the pair (plain Map or None, H-split Map): the operand of an f16x3 conv."""
+    out = Map.new(a.B, a.H, a.W, a.C, a.dtype, a.t.device) if plain else None
+    outh = Map.new(a.B, a.H, a.W, a.C, a.dtype, a.t.device) if hsplit else None
     wr, wc = wraw.shape
-    L.check(L.lib().effdet_bifpn_fuse_fwd(L.ptr(a.tensor()), L.ptr(b.tensor()), L.ptr(c.tensor() if c is not None else None),
-                                          L.ptr(out.t), L.ptr(wraw.detach()), wr, wc, col, mode, L.dtype_code(a.dtype),
-                                          a.B, a.H, a.W, a.C, L.stream_ptr()), 'effdet_bifpn_fuse_fwd')
-    return out
+    L.check(L.lib().effdet_bifpn_fuse_fwd2(L.ptr(a.tensor()), L.ptr(b.tensor()), L.ptr(c.tensor() if c is not None else None),
+                                           L.ptr(out.t if plain else None), L.ptr(outh.t if hsplit else None), L.ptr(wraw.detach()), wr, wc, col, mode,
+                                           L.dtype_code(a.dtype), a.B, a.H, a.W, a.C, L.stream_ptr()), 'effdet_bifpn_fuse_fwd2')
+    return (out, outh) if hsplit else out
 
 
 FUSE_COL_FLOATS = 4 + 3 * 2048     # EFFDET_FUSE_COL_FLOATS (include/effdet_hip.h): per weight column, [count | per-workgroup partial triples]

@@ -390,6 +390,12 @@ int effdet_colsum(const void* x, float* out, int dtype, long long rows, int C, i
 int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out, const float* wraw,
                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                           effdet_stream_t stream);
+/* The same node writing the fused map in up to two forms: `out` (plain, may be NULL) and `out_hsplit` (EFFDET_F32_HSPLIT, may be NULL;
+ * fp32 only, C % 32 == 0, 128-byte aligned) -- the operand of the node's 3x3 conv (models/bifpn.py:189-202, ConvModule) when it runs in
+ * the f16x3 arithmetic; training keeps the plain form as well (operand of the conv's weight gradient). */
+int effdet_bifpn_fuse_fwd2(const void* a, const void* b, const void* c, void* out, void* out_hsplit, const float* wraw,
+                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
+                           effdet_stream_t stream);
 /* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and the partial sums of
  * d loss / d n_r (grad wrt the ONCE-normalised weights), one row per workgroup and NO float atomics:
  *   dn[col * EFFDET_FUSE_COL_FLOATS]                    = number of workgroups of this node's launch
