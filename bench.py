@@ -222,7 +222,12 @@ def roofline_of(summ, dtype_name, batch, size):
         except Exception:
             pass
     return {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-            'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': (src + ' (rocprofv3 PMC, per launch)') if src else None,
+            'traffic': traffic, 'mfma_busy_frac': util,
+            # traffic / mfma_busy_frac: NOT observed in this run (PMC counters cannot be read from inside the process) -- copied from the
+            # committed rocprofv3 --pmc passes of this same command
+            'traffic_source': ('committed profile ' + src + ' (rocprofv3 PMC, per launch)') if src else None,
+            # every MFMA launch of the step at the dense peak of ITS arithmetic: the time the step's matrix work alone would take
+            'step_floor_ms': round(sum(v['flops'] / (kernel_peak(k, dtype_name) * 1e12) for k, v in mf.items()) * 1e3, 3),
             'launches_per_step': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
             'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
             # operands read once + outputs written once, averaged over the symbol's launches: what `traffic` (PMC) is to be compared with
@@ -371,6 +376,8 @@ def train_leg(a, dtype_name, steps, warmup, rank, world, local, dev, want_roofli
             summ = ops.PROFILE.summary()
             roof = roofline_of(summ, dtype_name, a.batch, a.size)
             # the dominant symbol's launches by shape: its MFMA-bound head shapes apart from the HBM-bound backbone ones
+            # step-level roofline: the blended MFMA floor (each kernel's algorithmic FLOPs at the dense peak of its arithmetic) / the timed step
+            roof['step_frac'] = round(roof['step_floor_ms'] / (dt / steps * 1e3), 4)
             roof['dominant_by_shape'] = ops.PROFILE.by_shape(roof['kernel'])
             roof['other_mfma_by_shape'] = {k: ops.PROFILE.by_shape(k, top=3) for k, v in summ.items()
                                            if k.startswith('conv_') and k != roof['kernel'] and v['ms'] >= 1.0}
@@ -414,7 +421,7 @@ def inference_roofline(model, img, dtype_name):
                 except Exception:
                     pass
         roof = {'bound': 'mfma', 'kernel': name, 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': src,
+                'traffic': traffic, 'mfma_busy_frac': util, 'traffic_source': ('committed profile ' + src) if src else None,
                 'launches_per_forward': d['launches'], 'avg_launch_ms': round(d['ms'] / d['launches'], 4),
                 'flops_per_launch': round(d['flops'] / d['launches'] / 1e9, 3),
                 'algorithmic_bytes_per_launch': round(d.get('bytes', 0.0) / d['launches']),

@@ -124,7 +124,14 @@ def check(status, what):
         raise RuntimeError('%s failed: %s (%d)' % (what, _ERR.get(status, 'unknown'), status))
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device (every launch asks: the raw-handle query is ~0.3 us, the
+    torch.cuda.current_stream() object ~9 us -- 1.2 ms of host time per eager D0 train step)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -112,7 +112,9 @@ template <> struct Mma<float> {
 // shape was the obvious try: it measured 342-360 against 370-390 (same LDS fragment bytes per MAC, longer dependent chains per
 // accumulator): the loop is bound by LDS port + latency hiding at this tile size, not by MFMA issue.
 template <typename T, int BN, int WAVES_N, int NWAVES, int SPLIT = 0, int NS = 2, int M32 = 0>
-__global__ __launch_bounds__(NWAVES * 64) void conv_igemm_kernel(const ConvK p) {
+// (second launch bound = waves per SIMD asked of the register allocator: the 4-wave split-layout forms fit three workgroups per CU by LDS, but
+//  left to itself hipcc spends 110 VGPRs + 72 AGPRs on the f16x3 one -- two waves per SIMD)
+__global__ __launch_bounds__(NWAVES * 64, (SPLIT == 3 && NWAVES == 4) ? 3 : 1) void conv_igemm_kernel(const ConvK p) {
   static_assert(!SPLIT || sizeof(T) == 4, "bf16x3 splitting applies to fp32 storage");
   static_assert(!M32 || SPLIT == 2, "the 32x32x16 form is built for the split layout");
   static_assert(SPLIT != 3 || NS == 2, "f16x3: two stages");

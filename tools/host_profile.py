@@ -16,7 +16,7 @@ B, S = int(os.environ.get('HP_B', 32)), int(os.environ.get('HP_S', 512))
 c = EFFICIENTDET['efficientdet-d0']
 torch.manual_seed(0)
 m = EfficientDet(80, network='efficientdet-d0', W_bifpn=c['W_bifpn'], D_bifpn=c['D_bifpn'], D_class=c['D_class'], compute_dtype=torch.float32,
-                 f32_arith='bf16x3').cuda()
+                 f32_arith=os.environ.get('HP_ARITH', 'f32_hf16x3_bwd_bf16x3')).cuda()
 m.train(); m.is_training = True; m.freeze_bn()
 opt = ClipAdamW([p for p in m.parameters() if p.requires_grad], lr=1e-4, max_norm=0.1)
 img, ann = synthetic_batch(B, S, seed=1, num_classes=80)
