@@ -51,6 +51,8 @@ def short(name):
     if m:
         if m.group(3) == '2':
             return 'conv_igemm_kernel<split,%s,bf16x3>' % m.group(2)
+        if m.group(3) == '3':
+            return 'conv_igemm_kernel<hsplit,%s,f16x3>' % m.group(2)
         return 'conv_igemm_kernel<%s,%s%s>' % ('bf16' if m.group(1) == 'unsigned short' else 'f32', m.group(2),
                                                 ',bf16x3' if m.group(3) == '1' else '')
     if 'conv_wgrad_split_kernel' in name:
@@ -59,7 +61,7 @@ def short(name):
     if m:
         return 'conv_wgrad_f32dma_kernel<%s%s>' % (m.group(1), ',bf16x3' if m.group(2) == '1' else '')
     m = re.search(r'(conv_wgrad\w*_kernel<[^>(]*>|dw_\w+_kernel|unpack_wgrad\w*_kernel|wgrad_\w+_kernel|loss_\w+_kernel|se_\w+_kernel|'
-                  r'channel_scale_kernel|fuse_\w+_kernel|opt_\w+_kernel|act_bwd_kernel|prepare_params_kernel|nms_\w+_kernel|decode_score_kernel|conv_pw_f32_kernel<\d+>|sort_\w+_kernel|radix_\w+_kernel|gather_dets_kernel|to_split_kernel)', name)
+                  r'channel_scale_kernel|fuse_\w+_kernel|opt_\w+_kernel|act_bwd_kernel|prepare_params_kernel|nms_\w+_kernel|decode_score_kernel|conv_pw_f32_kernel<\d+>|sort_\w+_kernel|radix_\w+_kernel|gather_dets_kernel|to_split_kernel|to_split2_kernel)', name)
     return m.group(1).replace('unsigned short', 'bf16').replace('float', 'f32') if m else None
 
 
@@ -109,7 +111,7 @@ def main():
                      'mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs)' % command,
            'kernels': kernels}
     json.dump(res, open(out_path, 'w'), indent=1)
-    for k in ('conv_igemm_kernel<bf16,128>', 'conv_igemm_kernel<f32,128>', 'conv_wgrad_tr_kernel<8>', 'conv_igemm_kernel<split,128,bf16x3>', 'conv_wgrad_split_kernel'):
+    for k in ('conv_igemm_kernel<hsplit,128,f16x3>', 'conv_igemm_kernel<bf16,128>', 'conv_igemm_kernel<f32,128>', 'conv_wgrad_tr_kernel<8>', 'conv_igemm_kernel<split,128,bf16x3>', 'conv_wgrad_split_kernel'):
         if k in kernels:
             print(k, json.dumps(kernels[k]))
 
