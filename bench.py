@@ -602,10 +602,24 @@ def leg_main(a):
 
 
 def run_attempt(a, path, attempt, rank, world, local, base_port, store, dry):
-    """This rank's child of one attempt -> (ok, result dict of the rank-0 child or None, reason it failed or None)."""
-    port = base_port + 101 + 13 * attempt
-    if port >= 65000:
-        port = base_port - 101 - 13 * attempt
+    """This rank's child of one attempt -> (ok, result dict of the rank-0 child or None, reason it failed or None).
+    The children's rendezvous port: rank 0 asks the OS for a free one per attempt and publishes it through the supervisors' store (an
+    arithmetic offset from the launcher's port may be taken -- every rank's child would then fail or hang until --leg-timeout); without
+    a store (never the case under a launcher) the offset rule remains."""
+    port = None
+    if store is not None:
+        key = 'effdet_port_%d' % attempt
+        try:
+            if rank == 0:
+                store.set(key, str(free_port()))
+            store.wait([key])
+            port = int(store.get(key))
+        except Exception:
+            port = None
+    if port is None:
+        port = base_port + 101 + 13 * attempt
+        if port >= 65000:
+            port = base_port - 101 - 13 * attempt
     env = {k: v for k, v in os.environ.items() if not k.startswith(('TORCHELASTIC_', 'GROUP_', 'ROLE_', 'LOCAL_WORLD'))}
     env.update(RANK=str(rank), LOCAL_RANK=str(local), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'), EFFDET_BENCH_DRY_PATH=path)
