@@ -35,7 +35,7 @@ class ConvDesc(C.Structure):
                 ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
                 ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
                 ('ldx', C.c_int), ('ldy', C.c_int), ('act', C.c_int), ('res_mode', C.c_int),
-                ('nseg', C.c_int), ('seg', Seg * MAX_SEG), ('w_image_stride', C.c_longlong), ('y_split', C.c_void_p)]
+                ('nseg', C.c_int), ('seg', Seg * MAX_SEG), ('w_image_stride', C.c_longlong), ('y_split', C.c_void_p), ('range_flag', C.c_void_p)]
 
 
 class WgradDesc(C.Structure):

@@ -36,6 +36,7 @@ __device__ __forceinline__ FuseW fuse_weights(const float* wraw, int wrows, int 
 
 struct FuseK {
   const void* a; const void* b; const void* c; void* out;
+  int* range_flag;          // out-of-fp16-range watch of the H-split output (common.h hsplit_watch), may be NULL
   void* out_h;              // fp32 only: the fused map once more (or, out == NULL, only) in the H-split layout of the f16x3 convs
   const void* dout; void* da; void* db; void* dc;
   const float* wraw; float* dn;
@@ -85,7 +86,7 @@ __global__ void fuse_fwd_kernel(const FuseK p) {
     for (int e = 0; e < CE; ++e) o[e] *= f.inv;
     if (p.out) ((uint4*)p.out)[i] = Chunk<T>::pack(o);
     if constexpr (sizeof(T) == 4) {
-      if (p.out_h) store4((hsplit_t*)p.out_h + i * 4, f32x4{o[0], o[1], o[2], o[3]});
+      if (p.out_h) { const f32x4 ov = f32x4{o[0], o[1], o[2], o[3]}; hsplit_watch(ov, p.range_flag); store4((hsplit_t*)p.out_h + i * 4, ov); }
     }
   }
 }
@@ -228,14 +229,14 @@ inline int grid_for(long long n, int cap = 4096) { long long g = (n + 255) / 256
 }  // namespace
 
 extern "C" int effdet_bifpn_fuse_fwd2(const void* a, const void* b, const void* c, void* out, void* out_hsplit, const float* wraw, int wrows,
-                                      int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
+                                      int wcols, int col, int mode, int dtype, int B, int H, int W, int C, int* range_flag,
                                       effdet_stream_t stream) {
   const int ce = dtype == EFFDET_F32 ? 4 : 8;
   if (!a || !b || (!out && !out_hsplit) || !wraw || mode < 0 || mode > 2 || (mode == 1 && !c) || C % ce) return EFFDET_EINVAL;
   if (out_hsplit && (dtype != EFFDET_F32 || C % 32 || ((unsigned long long)out_hsplit & 127ull))) return EFFDET_EUNSUPPORTED;
   if (wrows < 2 || wrows > 3 || (mode == 1 && wrows != 3)) return EFFDET_EINVAL;
   if (mode == 0 && ((H | W) & 1)) return EFFDET_EUNSUPPORTED;
-  FuseK k{}; k.a = a; k.b = b; k.c = c; k.out = out; k.out_h = out_hsplit; k.wraw = wraw; k.wrows = wrows; k.wcols = wcols; k.col = col; k.mode = mode;
+  FuseK k{}; k.a = a; k.b = b; k.c = c; k.out = out; k.out_h = out_hsplit; k.range_flag = range_flag; k.wraw = wraw; k.wrows = wrows; k.wcols = wcols; k.col = col; k.mode = mode;
   k.B = B; k.H = H; k.W = W; k.C = C;
   const long long n = (long long)B * H * W * (C / ce);
   hipStream_t st = (hipStream_t)stream;
@@ -250,7 +251,7 @@ extern "C" int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c
                                      int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
                                      effdet_stream_t stream) {
   if (!out) return EFFDET_EINVAL;
-  return effdet_bifpn_fuse_fwd2(a, b, c, out, nullptr, wraw, wrows, wcols, col, mode, dtype, B, H, W, C, stream);
+  return effdet_bifpn_fuse_fwd2(a, b, c, out, nullptr, wraw, wrows, wcols, col, mode, dtype, B, H, W, C, nullptr, stream);
 }
 
 extern "C" int effdet_bifpn_fuse_bwd(const void* dout, const void* a, const void* b, const void* c, void* da, void* db, void* dc,

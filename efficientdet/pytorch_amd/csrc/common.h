@@ -116,6 +116,15 @@ __device__ __forceinline__ void hsplit4(const f32x4& v, uint2& hi, uint2& lo) {
   lo.x = pack2h((v[0] - h2f(hi.x & 0xffffu)) * 2048.f, (v[1] - h2f(hi.x >> 16)) * 2048.f);
   lo.y = pack2h((v[2] - h2f(hi.y & 0xffffu)) * 2048.f, (v[3] - h2f(hi.y >> 16)) * 2048.f);
 }
+// Out-of-range watch of the H-split producers: a value fp16 cannot hold (|v| >= 65520 rounds hi to inf; NaN) sets bit 0 of the caller's
+// device flag word (integer atomic, taken only in that case -- deterministic, free otherwise).  The outputs are inf / NaN either way; the
+// flag is what lets a host-side consumer (eval: a sigmoid turns an inf logit into a plausible 1.0) turn it into an error.
+__device__ __forceinline__ void hsplit_watch(const f32x4& v, int* flag) {
+  if (flag) {
+    const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    if (!(m < 65520.f)) atomicOr(flag, 1);          // (also true for NaN)
+  }
+}
 struct hsplit_t { uint32_t bits; };
 __device__ __forceinline__ void store4(hsplit_t* p, f32x4 v) {
   const unsigned long long a = (unsigned long long)p;

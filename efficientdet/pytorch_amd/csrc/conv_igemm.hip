@@ -48,6 +48,7 @@ struct ConvK {
   int cpt;   // chunks per tap (= Cin/CE)
   int act, res_mode, out_f32, vec_ok;
   int out_split;               // y (and a ReLU-mask res) are in the split layout: 32-channel groups of [32 x bf16 hi | 32 x bf16 lo]
+  int* range_flag;             // f16x3 convs writing H-split output: out-of-fp16-range watch (common.h hsplit_watch), may be NULL
   void* ysplit;                // plain-fp32 convs only: the output values a SECOND time, in the split layout (same row addressing as y)
   int nseg, mtiles, ntiles;
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(NWAVES * 64, (SPLIT == 3 && NWAVES == 4) ? 3 : 1) v
         // values once more in the bf16 split layout (operand of the next layer's weight gradient, ReLU mask of this layer's data gradient)
         const unsigned goff = (unsigned)(n0 >> 5) * 128u + (unsigned)(n0 & 31) * 2u;
         uint2 hi, lo;
+        hsplit_watch(v, p.range_flag);
         hsplit4(v, hi, lo);
         char* dst = (char*)p.y + orow * 4 + goff;
         *(uint2*)dst = hi; *(uint2*)(dst + 64) = lo;
@@ -1280,7 +1282,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     for (int s = 0; s < p->nseg; ++s)
       if (p->seg[s].out_off % 32 || p->seg[s].out_bstride % 32) return EFFDET_EUNSUPPORTED;
   }
-  k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res; k.ysplit = p->y_split;
+  k.x = p->x; k.w = p->w; k.y = p->y; k.z = p->z; k.res = p->res; k.ysplit = p->y_split; k.range_flag = hfmt ? p->range_flag : nullptr;
   k.scale = p->scale; k.shift = p->shift; k.rowscale = p->rowscale;
   k.bc_scale = p->bc_scale; k.bc_shift = p->bc_shift;
   if ((p->bc_scale != nullptr) != (p->bc_shift != nullptr)) return EFFDET_EINVAL;

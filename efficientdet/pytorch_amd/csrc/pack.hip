@@ -196,11 +196,11 @@ __global__ void pad_rows_kernel(const T* __restrict__ src, T* __restrict__ dst, 
 }
 
 // plain fp32 -> split (bf16 halves) and / or H-split (f16 hi + scaled lo), 4 elements per thread
-__global__ void to_split2_kernel(const float* __restrict__ src, split_t* __restrict__ ds, hsplit_t* __restrict__ dh, long long n4) {
+__global__ void to_split2_kernel(const float* __restrict__ src, split_t* __restrict__ ds, hsplit_t* __restrict__ dh, long long n4, int* range_flag) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const f32x4 v = *(const f32x4*)(src + i * 4);
     if (ds) store4(ds + i * 4, v);
-    if (dh) store4(dh + i * 4, v);
+    if (dh) { hsplit_watch(v, range_flag); store4(dh + i * 4, v); }
   }
 }
 
@@ -382,11 +382,11 @@ extern "C" int effdet_to_split(const float* src, void* dst, long long n, effdet_
   return EFFDET_OK;
 }
 
-extern "C" int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, effdet_stream_t stream) {
+extern "C" int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, int* range_flag, effdet_stream_t stream) {
   if (!src || (!dst_split && !dst_hsplit) || n < 4 || (n & 3) || ((unsigned long long)src & 15ull) || ((unsigned long long)dst_split & 127ull) ||
       ((unsigned long long)dst_hsplit & 127ull) || (const void*)src == dst_split || (const void*)src == dst_hsplit || dst_split == dst_hsplit) return EFFDET_EINVAL;
   long long g = (n / 4 + 255) / 256; if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(to_split2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst_split, (hsplit_t*)dst_hsplit, n / 4);
+  hipLaunchKernelGGL(to_split2_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, src, (split_t*)dst_split, (hsplit_t*)dst_hsplit, n / 4, range_flag);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

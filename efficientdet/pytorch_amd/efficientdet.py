@@ -461,6 +461,8 @@ class EfficientDet(nn.Module):
         # every forward path starts here: replay (or start recording) this model's batched parameter preparation
         key = (dt, img.device, self.f32_arith)
         ops.set_model_arith(self.f32_arith)
+        if ops.F32_ARITH_HEAD == 'f16x3' and not torch.cuda.is_current_stream_capturing():
+            ops.range_flag(img.device)            # (the out-of-range watch word exists before anything could be captured)
         if not self.batched_prep or getattr(self, '_is_replica', False):
             # (replicas of nn.DataParallel are rebuilt every forward with fresh parameter tensors: nothing to record against)
             ops.set_prep(None)
@@ -533,6 +535,8 @@ class EfficientDet(nn.Module):
         idx, count = ops.nms(boxes, score, float(self.threshold), float(self.iou_threshold))
         s, l, b = ops.gather_dets(boxes, score, label, idx, count)
         counts = count.tolist()                                  # the one device->host sync (the reference syncs too)
+        if ops.MODEL_ARITH[self.f32_arith][2] == 'f16x3' and not torch.cuda.is_current_stream_capturing():
+            ops.check_range_flag(s.device)                       # (a sigmoid turns an inf logit into a plausible score: make overflow an error)
         return [(s[i, :n], l[i, :n], b[i, :n]) for i, n in enumerate(counts)]
 
     def forward(self, inputs):

@@ -464,7 +464,8 @@ def _pyramid_to_split(src_maps, B, sizes, C_, dtype, dev, bf=True, h=False):
         n = s_.B * s_.H * s_.W * s_.C
         if h:
             ops.L.check(ops.L.lib().effdet_to_split2(ops.L.ptr(s_.tensor()), ops.C.c_void_p(dst[i].addr() if bf else None),
-                                                     ops.C.c_void_p(dsth[i].addr()), ops.C.c_longlong(n), ops.L.stream_ptr()), 'effdet_to_split2')
+                                                     ops.C.c_void_p(dsth[i].addr()), ops.C.c_longlong(n), ops.L.ptr(ops.range_flag(dev)),
+                                                     ops.L.stream_ptr()), 'effdet_to_split2')
         else:
             ops.L.check(ops.L.lib().effdet_to_split(ops.L.ptr(s_.tensor()), ops.C.c_void_p(dst[i].addr()), ops.C.c_longlong(n), ops.L.stream_ptr()),
                         'effdet_to_split')

@@ -210,6 +210,8 @@ class GraphedDetect:
                                'captured NMS); build a new GraphedDetect')
         self.graph.replay()
         counts = self.count.tolist()                       # the one device->host sync (the reference syncs too)
+        if ops.MODEL_ARITH[getattr(m, 'f32_arith', 'f32')][2] == 'f16x3':
+            ops.check_range_flag(self.s.device)            # f16x3: an activation beyond fp16's range is an error, not a plausible score
         # the graph's output buffers are rewritten by the next replay: hand out COPIES of the kept rows (one clone of the rows up to
         # the largest count), so an evaluator that accumulates results over batches keeps what it was given -- like model.detect
         k = max(counts) if counts else 0

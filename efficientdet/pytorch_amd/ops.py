@@ -98,6 +98,31 @@ def set_model_arith(name):
     F32_ARITH_HEAD = head
 
 
+# Out-of-fp16-range watch of the f16x3 arithmetic: one device int per GPU that every H-split producer (pyramid conversion, BiFPN fusion,
+# tower conv epilogues) ORs bit 0 into when a value cannot be held (|v| >= 65520 or NaN).  Created outside stream capture (the model's
+# forward asks for it before anything else), never reset by the kernels.
+_range_flags = {}
+
+
+def range_flag(device):
+    device = torch.device(device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _range_flags.get(key)
+    if t is None:
+        t = _range_flags[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
+def check_range_flag(device, what='f16x3'):
+    """Host-side read of the watch (synchronises the current stream): raises -- and clears the flag -- if a value left fp16's range since
+    the last check."""
+    t = range_flag(device)
+    if int(t.item()) != 0:
+        t.zero_()
+        raise FloatingPointError('%s: an activation of the RetinaHead / BiFPN left the range of the fp16 operand split (|x| >= 65520 or NaN); '
+                                 "the outputs of this call are not valid -- use f32_arith='f32_bwd_bf16x3' or 'f32' for this model" % what)
+
+
 class backward_scope:
     """with backward_scope(ctx.prep, ctx.arith): the body of an autograd node's backward -- this model's parameter arena and its BACKWARD
     arithmetic for the launches inside, and the arithmetic found at entry put back at exit, so that direct ops.conv2d / functional.* calls
@@ -436,6 +461,7 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
             assert (r.addr() - br) * isy == (y.addr() - base_y) * r.t.element_size() and r.ld == y.ld and r.bstride == y.bstride
         d.res = br
     d.y_split = None
+    d.range_flag = range_flag(x0.t.device).data_ptr() if (hsplit and not out_f32) else None
     if ysplit is not None:
         bs = min(q.addr() for q in ysplit)
         for y, q in zip(ys, ysplit):
@@ -938,7 +964,8 @@ def bifpn_fuse_fwd(a, b, c, wraw, col, mode, plain=True, hsplit=False):
     wr, wc = wraw.shape
     L.check(L.lib().effdet_bifpn_fuse_fwd2(L.ptr(a.tensor()), L.ptr(b.tensor()), L.ptr(c.tensor() if c is not None else None),
                                            L.ptr(out.t if plain else None), L.ptr(outh.t if hsplit else None), L.ptr(wraw.detach()), wr, wc, col, mode,
-                                           L.dtype_code(a.dtype), a.B, a.H, a.W, a.C, L.stream_ptr()), 'effdet_bifpn_fuse_fwd2')
+                                           L.dtype_code(a.dtype), a.B, a.H, a.W, a.C, L.ptr(range_flag(a.t.device) if hsplit else None),
+                                           L.stream_ptr()), 'effdet_bifpn_fuse_fwd2')
     return (out, outh) if hsplit else out
 
 

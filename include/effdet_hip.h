@@ -104,6 +104,8 @@ typedef struct {
                              * output values a second time in the EFFDET_F32_SPLIT layout, addressed like y (same ldy / out_off /
                              * out_bstride relative to y_split).  An exact-fp32 forward leaves the operands of split-layout bf16x3
                              * GRADIENT kernels this way: forward values untouched, no conversion pass (models/retinahead.py:109-118) */
+  int* range_flag;          /* optional (dtype EFFDET_F32_HSPLIT, y H-split): device int; bit 0 is set (integer atomicOr, only then) when an
+                             * output value cannot be held by the H-split layout (|v| >= 65520 or NaN).  The caller owns, resets and reads it. */
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
 /* Per-image 1x1 weights for effdet_conv_t.w_image_stride:  out[b][n][k] = w[n][k] * gate[b][k]  in the packed layout of `dtype`
@@ -394,7 +396,7 @@ int effdet_bifpn_fuse_fwd(const void* a, const void* b, const void* c, void* out
  * fp32 only, C % 32 == 0, 128-byte aligned) -- the operand of the node's 3x3 conv (models/bifpn.py:189-202, ConvModule) when it runs in
  * the f16x3 arithmetic; training keeps the plain form as well (operand of the conv's weight gradient). */
 int effdet_bifpn_fuse_fwd2(const void* a, const void* b, const void* c, void* out, void* out_hsplit, const float* wraw,
-                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C,
+                           int wrows, int wcols, int col, int mode, int dtype, int B, int H, int W, int C, int* range_flag,
                            effdet_stream_t stream);
 /* backward: given dout -> da, db, dc (each overwritten, or += when *_accum), and the partial sums of
  * d loss / d n_r (grad wrt the ONCE-normalised weights), one row per workgroup and NO float atomics:
@@ -518,8 +520,9 @@ int effdet_pad_rows(const void* src, void* dst, int dtype, long long src_off, lo
 int effdet_to_split(const float* src, void* dst, long long n, effdet_stream_t stream);
 /* The same pass writing up to two layouts of the same values: dst_split (EFFDET_F32_SPLIT, bf16 halves; may be NULL) and dst_hsplit
  * (EFFDET_F32_HSPLIT, fp16 hi + scaled lo; may be NULL) -- the BiFPN pyramid entering the RetinaHead once as the operand of the f16x3
- * forward convs and once as the operand of the bf16x3 weight gradients (models/retinahead.py:109-113).  Same requirements as above. */
-int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, effdet_stream_t stream);
+ * forward convs and once as the operand of the bf16x3 weight gradients (models/retinahead.py:109-113).  Same requirements as above.
+ * range_flag (may be NULL): see effdet_conv_t.range_flag -- set when a value does not fit the H-split layout. */
+int effdet_to_split2(const float* src, void* dst_split, void* dst_hsplit, long long n, int* range_flag, effdet_stream_t stream);
 
 /* NCHW fp32 <-> NHWC dtype conversions for the module boundary (feature maps returned by extract_feat) */
 int effdet_nhwc_to_nchw_f32(const void* x, float* y, int dtype, int B, int H, int W, int C, effdet_stream_t stream);

@@ -13,6 +13,15 @@ from tests.gpu_util import assert_close
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _clear_range_watch():
+    """Several cases here feed values beyond fp16's range on purpose: leave the device's watch word clean for whoever runs next."""
+    yield
+    from efficientdet.pytorch_amd import ops
+    for t in ops._range_flags.values():
+        t.zero_()
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous().cuda()
 
@@ -36,7 +45,7 @@ def to_split2(x, bf=True):
     L, C = ops.L, ops.C
     s = torch.empty_like(x) if bf else None
     h = torch.empty_like(x)
-    L.check(L.lib().effdet_to_split2(L.ptr(x), L.ptr(s), L.ptr(h), C.c_longlong(x.numel()), L.stream_ptr()), 'effdet_to_split2')
+    L.check(L.lib().effdet_to_split2(L.ptr(x), L.ptr(s), L.ptr(h), C.c_longlong(x.numel()), L.ptr(ops.range_flag(x.device)), L.stream_ptr()), 'effdet_to_split2')
     return s, h
 
 
@@ -243,6 +252,34 @@ def test_conv_f16x3_grouped_levels():
         ref = F.relu(F.conv2d(x, w, b, padding=1))
         assert_close(from_hsplit(Fn.level_tensor(m))[0].float().permute(0, 3, 1, 2), ref, 1e-4, 'level %s' % (tuple(x.shape),))
         assert_close(from_split(Fn.level_tensor(ms)).permute(0, 3, 1, 2), ref, 1e-4, 'split copy %s' % (tuple(x.shape),))
+
+
+def test_out_of_range_activations_are_an_error_not_a_plausible_score():
+    """|x| >= 65520 cannot be held by the fp16 split: the producers set the caller's watch word (an inf logit would come out of the sigmoid as
+    a plausible 1.0), and the host-side check turns it into an exception and clears it.  Exactly at the edge: 65504 passes, 65520 does not."""
+    from efficientdet.pytorch_amd import ops
+    dev = torch.device('cuda', torch.cuda.current_device())
+    ops.range_flag(dev).zero_()
+    ok = torch.full((1, 2, 2, 32), 65504.0, device='cuda')
+    to_split2(ok, bf=False)
+    ops.check_range_flag(dev)                                   # in range: no complaint
+    to_split2(torch.full((1, 2, 2, 32), 65520.0, device='cuda'), bf=False)
+    with pytest.raises(FloatingPointError):
+        ops.check_range_flag(dev)
+    ops.check_range_flag(dev)                                   # ... and the flag was cleared
+    # a conv whose OUTPUT leaves the range (H-split epilogue), and NaN inputs
+    x = torch.full((1, 64, 4, 4), 100.0)
+    w = torch.full((64, 64, 3, 3), 2.0)
+    y, _ = _run_h(x, w, None, 0, False)                         # 9 * 64 * 200 = 115 200 per output
+    with pytest.raises(FloatingPointError):
+        ops.check_range_flag(dev)
+    assert not bool(torch.isfinite(from_hsplit(y)[0]).any())
+    y, _ = _run_h(x, w, None, 0, True)                          # plain fp32 output: representable, correct, no flag
+    ops.check_range_flag(dev)
+    assert float(y.max()) == 115200.0
+    to_split2(torch.full((1, 1, 1, 32), float('nan'), device='cuda'), bf=False)
+    with pytest.raises(FloatingPointError):
+        ops.check_range_flag(dev)
 
 
 def test_f16x3_descriptor_is_refused_where_it_does_not_apply():

@@ -42,7 +42,7 @@ def pyr(Cc, fill=None, kind='plain'):
             v = ops.to_split(v)
         elif kind == 'h':
             o = torch.empty_like(v)
-            L.check(L.lib().effdet_to_split2(L.ptr(v), None, L.ptr(o), C.c_longlong(v.numel()), L.stream_ptr()), 'to_split2')
+            L.check(L.lib().effdet_to_split2(L.ptr(v), None, L.ptr(o), C.c_longlong(v.numel()), None, L.stream_ptr()), 'to_split2')
             v = o
         flat.copy_(v)
     return maps
