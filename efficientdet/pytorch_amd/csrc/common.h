@@ -120,6 +120,9 @@ __device__ __forceinline__ void hsplit4(const f32x4& v, uint2& hi, uint2& lo) {
 // device flag word (integer atomic, taken only in that case -- deterministic, free otherwise).  The outputs are inf / NaN either way; the
 // flag is what lets a host-side consumer (eval: a sigmoid turns an inf logit into a plausible 1.0) turn it into an error.
 __device__ __forceinline__ void hsplit_watch(const f32x4& v, int* flag) {
+#ifdef EFFDET_NO_RANGE_WATCH      // (A/B build: what the watch costs -- nothing measurable, profiles/HISTORY.md)
+  (void)v; (void)flag; return;
+#endif
   if (flag) {
     const float m = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
     if (!(m < 65520.f)) atomicOr(flag, 1);          // (also true for NaN)

@@ -273,7 +273,7 @@ def test_out_of_range_activations_are_an_error_not_a_plausible_score():
     y, _ = _run_h(x, w, None, 0, False)                         # 9 * 64 * 200 = 115 200 per output
     with pytest.raises(FloatingPointError):
         ops.check_range_flag(dev)
-    assert not bool(torch.isfinite(from_hsplit(y)[0]).any())
+    assert not bool(torch.isfinite(from_hsplit(y)[0][0, 1:3, 1:3]).any())     # (the corners see 4 taps: 51 200, still in range)
     y, _ = _run_h(x, w, None, 0, True)                          # plain fp32 output: representable, correct, no flag
     ops.check_range_flag(dev)
     assert float(y.max()) == 115200.0
