@@ -254,6 +254,28 @@ def test_conv_f16x3_grouped_levels():
         assert_close(from_split(Fn.level_tensor(ms)).permute(0, 3, 1, 2), ref, 1e-4, 'split copy %s' % (tuple(x.shape),))
 
 
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_bifpn_fusion_writes_the_h_split_operand(mode):
+    """effdet_bifpn_fuse_fwd2: the H-split output is exactly the H-split of the plain output (same values, one pass), with and without
+    the plain copy -- the operand of the node's f16x3 conv (models/bifpn.py:189-202)."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    g = torch.Generator().manual_seed(3 + mode)
+    B, H, W, C = 2, 8, 12, 64
+    a = Map.of(torch.randn(B, H, W, C, generator=g).cuda())
+    hb, wb = (H // 2, W // 2) if mode == 0 else (2 * H, 2 * W)
+    b = Map.of(torch.randn(B, hb, wb, C, generator=g).cuda())
+    c = Map.of(torch.randn(B, H, W, C, generator=g).cuda()) if mode == 1 else None
+    wraw = torch.rand(3 if mode == 1 else 2, 5, generator=g).cuda()
+    plain = ops.bifpn_fuse_fwd(a, b, c, wraw, 2, mode)
+    both, hs = ops.bifpn_fuse_fwd(a, b, c, wraw, 2, mode, plain=True, hsplit=True)
+    none, hs2 = ops.bifpn_fuse_fwd(a, b, c, wraw, 2, mode, plain=False, hsplit=True)
+    torch.cuda.synchronize()
+    assert none is None and torch.equal(both.tensor(), plain.tensor()) and torch.equal(hs.tensor().view(torch.int32), hs2.tensor().view(torch.int32))
+    want = to_split2(plain.tensor().contiguous(), bf=False)[1]
+    assert torch.equal(hs.tensor().view(torch.int32), want.view(torch.int32))
+
+
 def test_out_of_range_activations_are_an_error_not_a_plausible_score():
     """|x| >= 65520 cannot be held by the fp16 split: the producers set the caller's watch word (an inf logit would come out of the sigmoid as
     a plausible 1.0), and the host-side check turns it into an exception and clears it.  Exactly at the edge: 65504 passes, 65520 does not."""
