@@ -13,7 +13,8 @@ from oracle import effdet_oracle as O
 pytestmark = pytest.mark.gpu
 
 MODES = {'f32': (torch.float32, 'f32'), 'f32_bf16x3': (torch.float32, 'bf16x3'), 'bf16': (torch.bfloat16, 'f32'),
-         'f32_bwd_bf16x3': (torch.float32, 'f32_bwd_bf16x3')}      # (the last: the bench headline)
+         'f32_bwd_bf16x3': (torch.float32, 'f32_bwd_bf16x3'),
+         'f32_hf16x3_bwd_bf16x3': (torch.float32, 'f32_hf16x3_bwd_bf16x3')}      # (the last: the bench headline)
 
 
 def _model(net, nc, mode, seed=0, **kw):
@@ -82,7 +83,7 @@ def test_two_train_passes_are_bitwise_equal_at_benchmark_size():
     assert all(bool(torch.isfinite(v).all()) for v in a.values())
 
 
-@pytest.mark.parametrize('mode', ['f32_bwd_bf16x3', 'f32_bf16x3', 'bf16'])
+@pytest.mark.parametrize('mode', ['f32_hf16x3_bwd_bf16x3', 'f32_bwd_bf16x3', 'f32_bf16x3', 'bf16'])
 def test_two_train_passes_are_bitwise_equal_at_benchmark_size_fast_modes(mode):
     net, nc = 'efficientdet-d0', 80
     m = _model(net, nc, mode).cuda()

@@ -52,13 +52,20 @@ def _restore_arith():
                                                               #  B = 1 takes the 16x16x32 head kernel, B = 8 the persistent 32x32x16
                                                               #  one -- another summation order, amplified like storage rounding)
     ('efficientdet-d4', 8, 1024, torch.float32, 1e-4),        # configs[4] in the parity modes: exact fp32 ...
-    ('efficientdet-d4', 8, 1024, 'f32_bf16x3', 3e-4),         # ... and fp32 storage + bf16x3 products (the headline mode)
+    ('efficientdet-d4', 8, 1024, 'f32_bf16x3', 3e-4),         # ... and fp32 storage + bf16x3 products
+    ('efficientdet-d0', 32, 512, 'f32_hf16x3_bwd_bf16x3', 1e-4),      # the round-6 headline: f16x3 head + BiFPN convs (B = 1: the small BiFPN
+    ('efficientdet-d4', 8, 1024, 'f32_hf16x3_bwd_bf16x3', 1e-4),      #  launches stay on the exact kernel -- same values to fp32 rounding)
 ])
 def test_batch_independence_at_benchmark_size(net, B, S, dtype, tol):
     """fp32: identical K-reduction order per output element; what differs between B = 1 and B = 32 is the number of tile groups
     the squeeze-excite pool is summed over (1e-6); bf16: that flips bf16 roundings which the network amplifies like any storage
     rounding (gate: the golden tests' tolerance)."""
-    m = _model(net, 80, torch.float32, False, f32_arith='bf16x3') if dtype == 'f32_bf16x3' else _model(net, 80, dtype, False)
+    if dtype == 'f32_bf16x3':
+        m = _model(net, 80, torch.float32, False, f32_arith='bf16x3')
+    elif isinstance(dtype, str):
+        m = _model(net, 80, torch.float32, False, f32_arith=dtype)
+    else:
+        m = _model(net, 80, dtype, False)
     img = O.synthetic_batch(B, S, seed=5, num_classes=80)[0].cuda()
     with torch.no_grad():
         cls, reg, anc = m.forward_raw(img)
@@ -111,7 +118,7 @@ def test_loss_and_gradients_are_batch_means_at_benchmark_size():
     print('batch loss %s vs mean of per-image losses %s; worst gradient deviation %s' % (full_loss, [x / B for x in lsum], worst))
 
 
-@pytest.mark.parametrize('arith', ['f32', 'bf16x3', 'f32_bwd_bf16x3'])
+@pytest.mark.parametrize('arith', ['f32', 'bf16x3', 'f32_bwd_bf16x3', 'f32_hf16x3_bwd_bf16x3'])
 def test_largest_family_at_its_native_size(arith):
     """EfficientDet-D6 (B6 backbone: 45 MBConv blocks, BiFPN 384 x 8, 5-conv heads; D7 is the same network at another size) at
     its own 1408 x 1408, B = 2, train mode: the batch loss is the mean of the two per-image losses, every live gradient is the
