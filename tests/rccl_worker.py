@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    out_path, arith = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'bf16x3')
+    out_path, arith = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else 'f32_hf16x3_bwd_bf16x3')
     from efficientdet.pytorch_amd import EfficientDet, EFFICIENTDET, ddp, synthetic_batch
     from efficientdet.pytorch_amd.graph import GraphedTrainStep
     from efficientdet.pytorch_amd.optim import ClipAdamW
