@@ -28,10 +28,12 @@ FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').s
 # 56 -> 61, M = 512 55 -> 61; D0 B = 32 @512, 64 -> 64: M = 131072 97 -> 59, M = 32768 35 -> 27, M = 8192 22 -> 27)
 BIFPN_F16X3_MIN_WORK = float(os.environ.get('EFFDET_BIFPN_F16X3_MIN_WORK', '1.2e8'))
 GATE_IN_WEIGHTS = os.environ.get('EFFDET_GATE_IN_WEIGHTS', '1') == '1'  # the SE gate folded into per-image project weights (no channel_scale pass)
-# ... in training too (fp32 storage, fused SE backward): the depthwise forward then stores its Swish output next to the pre-activation,
-# which costs about what channel_scale's pass did -- 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on) in round 4, OFF then; round 6, same
-# GPU call, alternating: 28.79 / 28.75 ms (off) vs 28.66 / 28.62 (on) and 16 launches fewer (397 -> 381): ON
-GATE_IN_WEIGHTS_TRAIN = os.environ.get('EFFDET_GATE_IN_WEIGHTS_TRAIN', '1') == '1'
+# ... in training too (fp32 storage, fused SE backward): built, tested, and OFF.  The depthwise forward then stores its Swish output
+# next to the pre-activation, which costs about what channel_scale's pass did: 27.65 / 27.97 ms (off) vs 27.72 / 27.62 ms (on) in round 4;
+# round 6, alternating in one GPU call: 28.79 / 28.75 (off) vs 28.66 / 28.62 (on), 16 launches fewer -- but W diag(gate) is another
+# rounding of the project conv's products, and with it the D1 and D6 train goldens leave their `1e-3 + s_k` gates (the single ReLU /
+# max-pool ties of those fixtures fall the other way): 0.4 % of the step is not worth a parity gate
+GATE_IN_WEIGHTS_TRAIN = os.environ.get('EFFDET_GATE_IN_WEIGHTS_TRAIN', '0') == '1'
 
 
 def chunk_elems(dtype):
