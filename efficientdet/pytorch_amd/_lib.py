@@ -11,7 +11,8 @@ import torch  # noqa: F401  (must be imported first: the .so binds to torch's al
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
-ABI_VERSION = 8                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
+MAX_CONV_SEG = 10                  # effdet_conv_t: 5 pyramid levels x 2 independent convs of one geometry (the head's two towers)
+ABI_VERSION = 9                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 F32_HSPLIT = 4                                     # the f16x3 forward arithmetic: [32 x f16 hi | 32 x f16 lo * 2^11] activations, row-scaled f16 hi | lo weights
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
@@ -35,7 +36,8 @@ class ConvDesc(C.Structure):
                 ('B', C.c_int), ('Cin', C.c_int), ('Cout', C.c_int), ('KH', C.c_int), ('KW', C.c_int),
                 ('stride', C.c_int), ('pad_t', C.c_int), ('pad_l', C.c_int),
                 ('ldx', C.c_int), ('ldy', C.c_int), ('act', C.c_int), ('res_mode', C.c_int),
-                ('nseg', C.c_int), ('seg', Seg * MAX_SEG), ('w_image_stride', C.c_longlong), ('y_split', C.c_void_p), ('range_flag', C.c_void_p)]
+                ('nseg', C.c_int), ('seg', Seg * MAX_CONV_SEG), ('w_image_stride', C.c_longlong), ('y_split', C.c_void_p), ('range_flag', C.c_void_p),
+                ('seg_w', C.c_void_p * MAX_CONV_SEG), ('seg_shift', C.c_void_p * MAX_CONV_SEG)]
 
 
 class WgradDesc(C.Structure):

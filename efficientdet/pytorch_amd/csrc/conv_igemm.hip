@@ -36,6 +36,8 @@ struct SegD {
   int H, W, Ho, Wo, M, tile_start;
   long long in_off, in_bs, out_off, out_bs;
   unsigned x_bytes;   // byte extent of this segment's input (its own SRD: 32-bit offsets span one tensor only)
+  long long w_off;    // per-segment weights (effdet_conv_t.seg_w): BYTE offset of this segment's packed weights from ConvK::w ...
+  long long sh_off;   // ... and ELEMENT offset of its shift (bias) row from ConvK::shift; 0 / 0 = the shared operands
 };
 
 struct ConvK {
@@ -54,7 +56,7 @@ struct ConvK {
   unsigned w_bytes;            // extent of the packed weights for the bounds-checked buffer loads
   int kord;                    // K walk of the persistent kernel: 0 tap-major, 1 channel-group-major
   long long w_img_bytes;       // != 0: image b reads its own packed weights at w + b * w_img_bytes (one segment, Ho*Wo % BM == 0)
-  SegD seg[EFFDET_MAX_SEG];
+  SegD seg[EFFDET_MAX_CONV_SEG];
 };
 
 constexpr int BM = 128;
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(NWAVES * 64, (SPLIT == 3 && NWAVES == 4) ? 3 : 1) v
   const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
   int si = 0;
 #pragma unroll
-  for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+  for (int s = 1; s < EFFDET_MAX_CONV_SEG; ++s)
     if (s < p.nseg && mt >= p.seg[s].tile_start) si = s;
   const SegD sg = p.seg[si];
   const int m_base = (mt - sg.tile_start) * BM;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(NWAVES * 64, (SPLIT == 3 && NWAVES == 4) ? 3 : 1) v
   constexpr unsigned ES = sizeof(T);
   // (per-image weights: a tile never straddles images -- Ho*Wo % BM == 0, checked by the host -- so the image is workgroup-uniform)
   const long long w_img = p.w_img_bytes ? (long long)(m_base / HoWo) * p.w_img_bytes : 0ll;
-  const u32x4_t rx = make_srd_raw((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd_raw((const char*)p.w + w_img, p.w_bytes);
+  const u32x4_t rx = make_srd_raw((const T*)p.x + sg.in_off, sg.x_bytes), rw = make_srd_raw((const char*)p.w + w_img + sg.w_off, p.w_bytes);
   const unsigned xs_a = lds_addr(xs), ws_a = lds_addr(ws);
   const int kc = (tid & 7) ^ ((tid >> 4) & 7), r0 = tid >> 3;
   const int wrow0 = __builtin_amdgcn_readfirstlane(wave) * 8;     // first tile row of this wave's 1-KiB DMA piece
@@ -538,14 +540,17 @@ __global__ __launch_bounds__(NWAVES * 64, (SPLIT == 3 && NWAVES == 4) ? 3 : 1) v
         for (int r = 0; r < 4; ++r) if (n0 + r < p.Cout) Elem<T>::st((T*)p.y + o + r, v[r]);
     }
   };
+  // (per-segment operands: the f16x3 row scales sit behind the segment's own packed rows -- w_off bytes on; the bias row sh_off elements on)
+  const float* const seg_scale = p.scale ? (const float*)((const char*)p.scale + (SPLIT == 3 ? sg.w_off : 0ll)) : nullptr;
+  const float* const seg_shift = p.shift ? p.shift + sg.sh_off : nullptr;
   auto scale_shift = [&](int n0, f32x4& sc, f32x4& sh) {
     sc = f32x4{1.f, 1.f, 1.f, 1.f}; sh = f32x4{0.f, 0.f, 0.f, 0.f};
     if (n0 + 3 < p.Cout) {
-      if (p.scale) sc = *(const f32x4*)(p.scale + n0);
-      if (p.shift) sh = *(const f32x4*)(p.shift + n0);
+      if (seg_scale) sc = *(const f32x4*)(seg_scale + n0);
+      if (seg_shift) sh = *(const f32x4*)(seg_shift + n0);
     } else {
       for (int r = 0; r < 4; ++r)
-        if (n0 + r < p.Cout) { if (p.scale) sc[r] = p.scale[n0 + r]; if (p.shift) sh[r] = p.shift[n0 + r]; }
+        if (n0 + r < p.Cout) { if (seg_scale) sc[r] = seg_scale[n0 + r]; if (seg_shift) sh[r] = seg_shift[n0 + r]; }
     }
   };
   if constexpr (M32) {
@@ -665,7 +670,7 @@ __global__ __launch_bounds__(WM * WN * 64) void conv_igemm_pers_kernel(const Con
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     si = 0;
 #pragma unroll
-    for (int s = 1; s < EFFDET_MAX_SEG; ++s)
+    for (int s = 1; s < EFFDET_MAX_CONV_SEG; ++s)
       if (s < p.nseg && mt >= p.seg[s].tile_start) si = s;
     const SegD sg = p.seg[si];
     m_base = (mt - sg.tile_start) * TM; n_base = nt * TN; sW = sg.W;
@@ -1162,7 +1167,7 @@ static bool pw_eligible(const effdet_conv_t* p) {
 static int retile(ConvK& k, int bm) {
   int tiles = 0;
   for (int s = 0; s < k.nseg; ++s) { k.seg[s].tile_start = tiles; tiles += (k.seg[s].M + bm - 1) / bm; }
-  for (int s = k.nseg; s < EFFDET_MAX_SEG; ++s) k.seg[s].tile_start = 0x7fffffff;
+  for (int s = k.nseg; s < EFFDET_MAX_CONV_SEG; ++s) k.seg[s].tile_start = 0x7fffffff;
   k.mtiles = tiles;
   return tiles;
 }
@@ -1256,7 +1261,7 @@ extern "C" int effdet_tuning_set(int key, int value) {
 // (v = 442 | 242 | 243 | 423; 4420 / 4220 = their <= 128-channel forms).
 static int plan_conv(const effdet_conv_t* p, ConvK& k) {
   if (!p || !p->x || !p->w || !p->y) return EFFDET_EINVAL;
-  if (p->nseg < 1 || p->nseg > EFFDET_MAX_SEG) return EFFDET_EINVAL;
+  if (p->nseg < 1 || p->nseg > EFFDET_MAX_CONV_SEG) return EFFDET_EINVAL;
   if (p->dtype != EFFDET_F32 && p->dtype != EFFDET_BF16 && p->dtype != EFFDET_F32_BF16X3 && p->dtype != EFFDET_F32_SPLIT && p->dtype != EFFDET_F32_HSPLIT) return EFFDET_EINVAL;
   const int ce = p->dtype == EFFDET_BF16 ? 8 : 4;
   if (p->Cin % ce || p->ldx % ce || p->KH < 1 || p->KW < 1 || p->stride < 1) return EFFDET_EUNSUPPORTED;
@@ -1308,6 +1313,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     if (p->w_image_stride < 0 || (p->w_image_stride & 15) || p->nseg != 1 || splitfmt || (p->seg[0].Ho * p->seg[0].Wo) % BM) return EFFDET_EUNSUPPORTED;
   }
   int tiles = 0;
+  bool per_seg = false;        // some segment brings its own weights / bias (effdet_conv_t.seg_w / seg_shift)
   bool vec = (p->ldy % 4 == 0) && (p->Cout % 4 == 0);
   for (int s = 0; s < p->nseg; ++s) {
     const effdet_seg_t& g = p->seg[s];
@@ -1316,13 +1322,18 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     d.M = p->B * g.Ho * g.Wo;
     d.tile_start = tiles;
     d.in_off = g.in_off; d.in_bs = g.in_bstride; d.out_off = g.out_off; d.out_bs = g.out_bstride;
+    d.w_off = p->seg_w[s] ? (long long)((const char*)p->seg_w[s] - (const char*)p->w) : 0ll;
+    d.sh_off = p->seg_shift[s] ? (long long)(p->seg_shift[s] - p->shift) : 0ll;
+    if (p->seg_w[s] || p->seg_shift[s]) per_seg = true;
+    if ((p->seg_shift[s] && !p->shift) || (d.w_off & 15)) return EFFDET_EINVAL;
     if (d.M <= 0) return EFFDET_EINVAL;
     if (g.in_off % ce || g.in_bstride % ce) return EFFDET_EUNSUPPORTED;
     if (g.out_off % 4 || g.out_bstride % 4) vec = false;
     tiles += (d.M + BM - 1) / BM;
   }
-  for (int s = p->nseg; s < EFFDET_MAX_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
+  for (int s = p->nseg; s < EFFDET_MAX_CONV_SEG; ++s) { k.seg[s] = k.seg[0]; k.seg[s].tile_start = 0x7fffffff; }
   k.mtiles = tiles; k.vec_ok = vec ? 1 : 0;
+  if (per_seg && (p->w_image_stride || p->scale)) return EFFDET_EUNSUPPORTED;
   // byte extents actually addressed through each segment's SRD (32-bit offsets): refuse tensors beyond 4 GiB - 64 KiB
   const long long es = p->dtype == EFFDET_BF16 ? 2 : 4;
   for (int s = 0; s < p->nseg; ++s) {
@@ -1338,7 +1349,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     k.scale = (const float*)((const char*)p->w + wb);        // [Cout] x 1 / S_n, written by the pack right behind the rows
     return p->Cout > 64 ? 30 : 31;                           // conv_igemm_kernel<float, 128 | 64, ..., SPLIT = 3>
   }
-  if (p->dtype == EFFDET_BF16 && !p->bc_scale && !p->w_image_stride && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
+  if (p->dtype == EFFDET_BF16 && !per_seg && !p->bc_scale && !p->w_image_stride && p->Cin % 64 == 0 && p->KH * p->KW <= 32 && p->Cout >= 128 && big_variant() != 0 && wb < 0x40000000LL) {
     long long mtot = 0;
     bool fits = true;        // offsets + the tap walk's SGPR offset must stay below the 2-GiB sentinel
     for (int s = 0; s < p->nseg; ++s) {
@@ -1359,7 +1370,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
       }
     }
   }
-  if (!p->w_image_stride && !p->y_split && pw_eligible(p)) return 20;
+  if (!per_seg && !p->w_image_stride && !p->y_split && pw_eligible(p)) return 20;
   const int bt = k.Cout > 64 ? 0 : k.Cout > 32 ? 1 : k.Cout > 16 ? 2 : 3;
   if (p->dtype == EFFDET_F32_BF16X3) return (k.Kc % 8) ? EFFDET_EUNSUPPORTED : 4 + bt;   // K-step = one [hi|lo] weight group
   if (p->dtype == EFFDET_F32_SPLIT) {
@@ -1367,7 +1378,7 @@ static int plan_conv(const effdet_conv_t* p, ConvK& k) {
     // In-step A/B on the D0 train step (same box, ms/step): off 27.83 | all eligible 27.57 | forward convs only (default) 27.33 |
     // residual-epilogue convs only 27.94 -- the exposed epilogue of the persistent form costs more where it also reads the ReLU mask.
     if (g_tuning[EFFDET_TUNE_SPLIT_PERS] < 0) g_tuning[EFFDET_TUNE_SPLIT_PERS] = getenv("EFFDET_SPLIT_PERS") ? atoi(getenv("EFFDET_SPLIT_PERS")) : 2;
-    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && !p->bc_scale && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
+    if (g_tuning[EFFDET_TUNE_SPLIT_PERS] > 0 && !per_seg && !p->bc_scale && p->KH * p->KW <= 32 && p->Cout >= 192 && wb < 0x40000000LL) {
       long long mtot = 0;
       bool fits = true;
       for (int s = 0; s < p->nseg; ++s) {

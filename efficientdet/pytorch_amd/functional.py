@@ -384,6 +384,21 @@ def pyramid_alloc(B, sizes, C, dtype, device):
     return flat, maps
 
 
+def pyramid_alloc_pair(B, sizes, C, dtype, device):
+    """Two pyramids of one geometry (the same layer of the head's two towers) in ONE flat buffer, tower-major then level-major: every
+    buffer allocated this way has the same relative offsets, which is what lets one grouped launch address outputs, split copies and
+    ReLU-mask residuals of both towers from one base each.  -> (flat, maps of tower A, maps of tower B)"""
+    tot = sum(B * h * w * C for (h, w) in sizes)
+    flat = torch.empty(2 * tot, dtype=dtype, device=device)
+    out = []
+    for half in (0, 1):
+        maps, off = [], half * tot
+        for (h, w) in sizes:
+            maps.append(Map(flat, B, h, w, C, off=off)); off += B * h * w * C
+        out.append(maps)
+    return flat, out[0], out[1]
+
+
 def level_tensor(m):
     n = m.B * m.H * m.W * m.C
     return m.t[m.off:m.off + n].view(m.B, m.H, m.W, m.C)
@@ -439,6 +454,7 @@ class _Fork:
         return False
 
 
+HEAD_PAIR_TOWERS = os.environ.get('EFFDET_HEAD_PAIR_TOWERS', '1') == '1'     # A/B switch: layer t of both towers as one launch (f16x3 forward, split-layout data gradients)
 HEAD_SPLIT = os.environ.get('EFFDET_HEAD_SPLIT', '1') == '1'     # A/B switch: split-layout head activations in the bf16x3 arithmetic
 _split_ok = {}
 
@@ -523,11 +539,37 @@ def head_fwd(p, HP, num_classes, dtype, train):
         else:
             ops.conv2d(cur, ops.pack_weight(HP['retina_reg.weight'], dtype, x3=split, h3=hs), head_out_maps(reg, B, sizes, 4),
                        Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, split=split, hsplit=hs)
-    with _Fork(dev, HEAD_TWO_STREAMS and ops.PROFILE is None) as fk:
-        with fk.side():
-            tower_fwd('reg')
-        tower_fwd('cls')
-    saved = (pin, acts, sizes, HP, num_classes, split or split_bwd) if train else None
+    paired = hs and HEAD_PAIR_TOWERS
+    if paired:
+        # The two towers are independent chains of identical launches: layer t of BOTH as ONE launch (per-segment weights / bias,
+        # effdet_conv_t.seg_w / seg_shift): 2 x 2728 tiles on the 512 workgroup slots = 10.66 rounds instead of twice 5.33 -- the
+        # draining third of a round is paid once per layer, not twice.  Same tiles, same K walk: bit for bit the separate launches.
+        cur = {'cls': pin_h, 'reg': pin_h}
+        for t in range(4):
+            w2 = [HP[f'{tw}_convs.{t}.weight'] for tw in ('cls', 'reg')]
+            b2 = [HP[f'{tw}_convs.{t}.bias'] for tw in ('cls', 'reg')]
+            wp2 = [ops.pack_weight(w, dtype, h3=True) for w in w2]
+            _, ya, yb = pyramid_alloc_pair(B, sizes, 256, dtype, dev)
+            sa = sb = None
+            if split_bwd:
+                _, sa, sb = pyramid_alloc_pair(B, sizes, 256, dtype, dev)
+            L5 = len(sizes)
+            ops.conv2d(cur['cls'] + cur['reg'], wp2[0], ya + yb, Cin=w2[0].shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, shift=b2[0],
+                       act=ACT_RELU, hsplit=True, ysplit=(sa + sb) if split_bwd else None,
+                       seg_w=[wp2[0]] * L5 + [wp2[1]] * L5, seg_shift=[b2[0]] * L5 + [b2[1]] * L5)
+            acts['cls'].append(sa if split_bwd else ya); acts['reg'].append(sb if split_bwd else yb)
+            cur = {'cls': ya, 'reg': yb}
+        ops.conv2d(cur['cls'], ops.pack_weight(HP['retina_cls.weight'], dtype, h3=True), head_out_maps(cls, B, sizes, num_classes),
+                   Cin=256, Cout=9 * num_classes, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_cls.bias'],
+                   act=ACT_SIGMOID, out_f32=True, hsplit=True)
+        ops.conv2d(cur['reg'], ops.pack_weight(HP['retina_reg.weight'], dtype, h3=True), head_out_maps(reg, B, sizes, 4),
+                   Cin=256, Cout=36, KH=3, KW=3, pad_t=1, pad_l=1, shift=HP['retina_reg.bias'], out_f32=True, hsplit=True)
+    else:
+        with _Fork(dev, HEAD_TWO_STREAMS and ops.PROFILE is None) as fk:
+            with fk.side():
+                tower_fwd('reg')
+            tower_fwd('cls')
+    saved = (pin, acts, sizes, HP, num_classes, split or split_bwd, paired and split_bwd) if train else None
     return cls, reg, saved
 
 
@@ -549,14 +591,16 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
     cls_gscale (fp32 tensor [1]): dcls_logit was computed for an upstream gradient of one (ops.focal_loss_fwd_grad); the
     real scalar enters here where the chain is linear: as the per-image output scale of retina_cls's data-gradient conv
     and as a factor on retina_cls's own parameter gradients."""
-    p, acts, sizes, HP, nc, split = saved
+    p, acts, sizes, HP, nc, split = saved[:6]
+    paired = len(saved) > 6 and saved[6] and split          # the forward laid both towers' activations out pairwise (pyramid_alloc_pair)
     dev = p[0].t.device
     B, Wc = p[0].B, p[0].C
     g = {}
     apix = sum(h * w for (h, w) in sizes)
     last = {}
 
-    def tower_bwd(tower, dout, per, pix_ld):
+    def tower_final(tower, dout, per, pix_ld):
+        """retina_cls / retina_reg: weight gradient + data gradient back into the tower (ReLU mask of its last layer fused) -> dz maps"""
         fin = f'retina_{tower}'
         wf = HP[fin + '.weight']
         Cf = wf.shape[0]
@@ -587,14 +631,20 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
         _, dz = pyramid_alloc(B, sizes, 256, dtype, dev)
         ops.conv2d(dzmaps, ops.pack_weight(wf, dtype, mode=1, cin_pad=Cfp, x3=split), dz, Cin=Cfp, Cout=256, KH=3, KW=3, pad_t=1,
                    pad_l=1, res=acts[tower][3], res_mode=RES_RELU_MASK, rowscale=rows, split=split)
+        return dz
+
+    def layer_wgrad(tower, t, dz):
+        w = HP[f'{tower}_convs.{t}.weight']
+        xin = acts[tower][t - 1] if t > 0 else p
+        G, dbp = ops.conv2d_wgrad(xin, dz, Cin=w.shape[1], Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, split=split)
+        dw = torch.empty_like(w); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
+        g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
+
+    def tower_bwd(tower, dout, per, pix_ld):
+        dz = tower_final(tower, dout, per, pix_ld)
         for t in range(3, -1, -1):
-            w = HP[f'{tower}_convs.{t}.weight']
-            xin = acts[tower][t - 1] if t > 0 else p
-            Cin = w.shape[1]
-            G, dbp = ops.conv2d_wgrad(xin, dz, Cin=Cin, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, split=split)
-            dw = torch.empty_like(w); db = ops.unpack_wgrad(G, dw, dbias_part=dbp)
-            g[f'{tower}_convs.{t}.weight'], g[f'{tower}_convs.{t}.bias'] = dw, db
-            wd = ops.pack_weight(w, dtype, mode=1, x3=split)
+            layer_wgrad(tower, t, dz)
+            wd = ops.pack_weight(HP[f'{tower}_convs.{t}.weight'], dtype, mode=1, x3=split)
             if t > 0:
                 _, nz = pyramid_alloc(B, sizes, 256, dtype, dev)
                 ops.conv2d(dz, wd, nz, Cin=256, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1, res=acts[tower][t - 1],
@@ -603,17 +653,35 @@ def head_bwd(saved, dcls_logit, dreg, dtype, dcls_ld=0, cls_gscale=None, dreg_ld
             else:
                 last[tower] = (dz, wd)                  # 256 -> Wc back to the neck: after the join (the towers' sum)
 
-    # (the two towers on two streams, see HEAD_TWO_STREAMS: the deferred unpack jobs of both leave in the node's ONE tail launch, on the
-    #  main stream, after the join -- hence no early flush in between)
-    two = HEAD_TWO_STREAMS and ops.PROFILE is None
-    ops.hold_tail_flush(two)
-    try:
-        with _Fork(dev, two) as fk:
-            with fk.side():
-                tower_bwd('reg', dreg, 4, dreg_ld)
-            tower_bwd('cls', dcls_logit, nc, dcls_ld)
-    finally:
-        ops.hold_tail_flush(False)
+    if paired:
+        # both towers in lockstep: the weight gradients stay one launch per (tower, layer), the 256 -> 256 data gradients of layer t run
+        # as ONE launch for both towers (head_fwd's pairing, same reason: 10.66 rounds of tiles instead of twice 5.33)
+        dzs = {'reg': tower_final('reg', dreg, 4, dreg_ld), 'cls': tower_final('cls', dcls_logit, nc, dcls_ld)}
+        L5 = len(sizes)
+        for t in range(3, -1, -1):
+            for tw in ('reg', 'cls'):
+                layer_wgrad(tw, t, dzs[tw])
+            wd2 = [ops.pack_weight(HP[f'{tw}_convs.{t}.weight'], dtype, mode=1, x3=split) for tw in ('cls', 'reg')]
+            if t > 0:
+                _, na, nb = pyramid_alloc_pair(B, sizes, 256, dtype, dev)
+                ops.conv2d(dzs['cls'] + dzs['reg'], wd2[0], na + nb, Cin=256, Cout=256, KH=3, KW=3, pad_t=1, pad_l=1,
+                           res=acts['cls'][t - 1] + acts['reg'][t - 1], res_mode=RES_RELU_MASK, split=split,
+                           seg_w=[wd2[0]] * L5 + [wd2[1]] * L5)
+                dzs = {'cls': na, 'reg': nb}
+            else:
+                last['cls'], last['reg'] = (dzs['cls'], wd2[0]), (dzs['reg'], wd2[1])
+    else:
+        # (the two towers on two streams, see HEAD_TWO_STREAMS: the deferred unpack jobs of both leave in the node's ONE tail launch, on
+        #  the main stream, after the join -- hence no early flush in between)
+        two = HEAD_TWO_STREAMS and ops.PROFILE is None
+        ops.hold_tail_flush(two)
+        try:
+            with _Fork(dev, two) as fk:
+                with fk.side():
+                    tower_bwd('reg', dreg, 4, dreg_ld)
+                tower_bwd('cls', dcls_logit, nc, dcls_ld)
+        finally:
+            ops.hold_tail_flush(False)
     # back to plain fp32 for the neck (out_f32 in the split form): the first tower writes, the second accumulates onto it
     _, dp_maps = pyramid_alloc(B, sizes, Wc, dtype, dev)
     dz, wd = last['cls']

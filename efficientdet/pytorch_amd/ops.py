@@ -430,13 +430,15 @@ def scale_pack_weight(w_oihw, gate, dtype):
 
 def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=None, shift=None, act=ACT_NONE,
            res=None, res_mode=RES_NONE, rowscale=None, zs=None, out_f32=False, split=False, bc_scale=None, bc_shift=None,
-           w_image_stride=0, ysplit=None, hsplit=False):
+           w_image_stride=0, ysplit=None, hsplit=False, seg_w=None, seg_shift=None):
     """Grouped implicit-GEMM conv: xs/ys (and optional zs/res) are lists of Map, one per pyramid level.
     split=True (EFFDET_F32_SPLIT): xs hold the split layout ([32 x bf16 hi | 32 x bf16 lo] per 32 channels, 4 B per element), wp
     is packed for bf16x3; ys are written split too unless out_f32 (then plain fp32; res, if any, is plain and ADDed).
     ysplit (exact-fp32 and f16x3 convs only): Maps addressed like ys that receive the output a second time in the split layout.
     hsplit=True (EFFDET_F32_HSPLIT, the f16x3 forward arithmetic): xs hold the H-split layout ([32 x f16 hi | 32 x f16 lo * 2^11] per 32
-    channels), wp = pack_weight(..., h3=True); ys are written H-split too unless out_f32; no scale / res / rowscale."""
+    channels), wp = pack_weight(..., h3=True); ys are written H-split too unless out_f32; no scale / res / rowscale.
+    seg_w / seg_shift (lists, one entry per map, None = wp / shift): the maps are INDEPENDENT convs of one geometry with their own packed
+    weights / bias rows -- the same layer of the head's two towers in one launch (<= 10 maps).  Same values as separate launches."""
     if isinstance(xs, Map):
         xs, ys = [xs], [ys]
         zs = [zs] if zs is not None else None
@@ -462,6 +464,9 @@ def conv2d(xs, wp, ys, *, Cin, Cout, KH, KW, stride=1, pad_t=0, pad_l=0, scale=N
         d.res = br
     d.y_split = None
     d.range_flag = range_flag(x0.t.device).data_ptr() if (hsplit and not out_f32) else None
+    for i in range(len(xs)):
+        d.seg_w[i] = seg_w[i].data_ptr() if (seg_w is not None and seg_w[i] is not None) else None
+        d.seg_shift[i] = seg_shift[i].data_ptr() if (seg_shift is not None and seg_shift[i] is not None) else None
     if ysplit is not None:
         bs = min(q.addr() for q in ysplit)
         for y, q in zip(ys, ysplit):

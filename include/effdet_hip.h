@@ -60,6 +60,7 @@ enum { EFFDET_ACT_NONE = 0, EFFDET_ACT_RELU = 1, EFFDET_ACT_SWISH = 2, EFFDET_AC
 enum { EFFDET_RES_NONE = 0, EFFDET_RES_ADD = 1, EFFDET_RES_RELU_MASK = 2, EFFDET_RES_SWISH_GRAD = 3 };
 
 #define EFFDET_MAX_SEG 5
+#define EFFDET_MAX_CONV_SEG 10   /* effdet_conv_t only: 5 pyramid levels x 2 independent convs of the same geometry (the RetinaHead's two towers) */
 
 /* One pyramid level ("segment") of a grouped launch.  A single-tensor conv has nseg = 1.
  * Element (b, h, w, c) of the input lives at  x + in_off  + b*in_bstride  + (h*W  + w )*ldx + c,
@@ -95,7 +96,7 @@ typedef struct {
   int ldx, ldy;                           /* channel strides (elements) of x rows and y/z/res rows */
   int act, res_mode;
   int nseg;
-  effdet_seg_t seg[EFFDET_MAX_SEG];
+  effdet_seg_t seg[EFFDET_MAX_CONV_SEG];
   long long w_image_stride; /* 0: one weight tensor for every image.  != 0 (BYTES; one segment, Ho*Wo a multiple of 128, the
                              * implicit-GEMM kernels only): image b reads its OWN packed weights at w + b * w_image_stride -- how the
                              * squeeze-excite gate of an MBConv block is applied without a pass over the activations:
@@ -106,6 +107,12 @@ typedef struct {
                              * GRADIENT kernels this way: forward values untouched, no conversion pass (models/retinahead.py:109-118) */
   int* range_flag;          /* optional (dtype EFFDET_F32_HSPLIT, y H-split): device int; bit 0 is set (integer atomicOr, only then) when an
                              * output value cannot be held by the H-split layout (|v| >= 65520 or NaN).  The caller owns, resets and reads it. */
+  const void* seg_w[EFFDET_MAX_CONV_SEG];      /* optional per-segment operands (NULL entry: the descriptor's w / shift): segments of ONE launch may be */
+  const float* seg_shift[EFFDET_MAX_CONV_SEG]; /* independent convs of the same geometry with their own packed weights and bias -- the same layer of
+                             * the RetinaHead's classification and regression towers (models/retinahead.py:112-118) as one launch of 2 x 2728 tiles
+                             * instead of two of 2728 (5.33 rounds of the 512 workgroup slots each: the draining third of a round is paid once).
+                             * Same dtype / packing / byte size as w; plain implicit-GEMM kernels only (no persistent / skinny form, no
+                             * w_image_stride); seg_shift needs shift != NULL.  Values are those of the separate launches, bit for bit. */
 } effdet_conv_t;
 int effdet_conv2d(const effdet_conv_t* p, effdet_stream_t stream);
 /* Per-image 1x1 weights for effdet_conv_t.w_image_stride:  out[b][n][k] = w[n][k] * gate[b][k]  in the packed layout of `dtype`
@@ -575,7 +582,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 8
+#define EFFDET_ABI_VERSION 9
 int effdet_abi_version(void);
 
 #ifdef __cplusplus

@@ -53,7 +53,7 @@ def test_struct_layouts_match_header():
     import ctypes as C
     from efficientdet.pytorch_amd import _lib
     assert C.sizeof(_lib.Seg) == 4 * 4 + 4 * 8
-    assert C.sizeof(_lib.ConvDesc) == 10 * 8 + 15 * 4 + 4 + 5 * C.sizeof(_lib.Seg) + 8 + 8 + 8  # 10 ptrs, 15 ints (+pad), 5 segs, w_image_stride, y_split, range_flag
+    assert C.sizeof(_lib.ConvDesc) == 10 * 8 + 15 * 4 + 4 + 10 * C.sizeof(_lib.Seg) + 8 + 8 + 8 + 2 * 10 * 8  # 10 ptrs, 15 ints (+pad), 10 segs, w_image_stride, y_split, range_flag, seg_w[10], seg_shift[10]
     assert C.sizeof(_lib.WgradDesc) == 4 * 8 + 13 * 4 + 4 + 5 * C.sizeof(_lib.Seg)        # 4 ptrs, 13 ints (+pad), 5 segs
 
 

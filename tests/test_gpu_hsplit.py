@@ -276,6 +276,32 @@ def test_bifpn_fusion_writes_the_h_split_operand(mode):
     assert torch.equal(hs.tensor().view(torch.int32), want.view(torch.int32))
 
 
+def test_two_independent_convs_in_one_launch_equal_the_separate_launches():
+    """effdet_conv_t.seg_w / seg_shift: the same layer of the head's two towers (own inputs, own packed weights, own bias) as ONE grouped
+    launch of 10 segments -- bit for bit the two 5-segment launches (same tiles, same K walk), H-split output and bf16 split copy alike."""
+    from efficientdet.pytorch_amd import ops, functional as Fn
+    g = torch.Generator().manual_seed(21)
+    B, sizes, Cin, Cout = 2, [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)], 64, 256
+    ws = [torch.randn(Cout, Cin, 3, 3, generator=g).cuda() / 24.0 for _ in range(2)]
+    bs = [torch.randn(Cout, generator=g).cuda() * 0.1 for _ in range(2)]
+    wps = [ops.pack_weight(w, torch.float32, h3=True) for w in ws]
+    xs = []
+    for _ in range(2):
+        pm = [ops.Map.of(_nhwc(F.relu(torch.randn(B, Cin, h, w, generator=g)))) for (h, w) in sizes]
+        xs.append(Fn._pyramid_to_split(pm, B, sizes, Cin, torch.float32, 'cuda', bf=False, h=True)[1])
+    kw = dict(Cin=Cin, Cout=Cout, KH=3, KW=3, pad_t=1, pad_l=1, act=ops.ACT_RELU, hsplit=True)
+    fy, ya, yb = Fn.pyramid_alloc_pair(B, sizes, Cout, torch.float32, 'cuda')
+    fs, sa, sb = Fn.pyramid_alloc_pair(B, sizes, Cout, torch.float32, 'cuda')
+    ops.conv2d(xs[0] + xs[1], wps[0], ya + yb, shift=bs[0], ysplit=sa + sb, seg_w=[wps[0]] * 5 + [wps[1]] * 5, seg_shift=[bs[0]] * 5 + [bs[1]] * 5, **kw)
+    gy, za, zb = Fn.pyramid_alloc_pair(B, sizes, Cout, torch.float32, 'cuda')
+    gs, ta, tb = Fn.pyramid_alloc_pair(B, sizes, Cout, torch.float32, 'cuda')
+    ops.conv2d(xs[0], wps[0], za, shift=bs[0], ysplit=ta, **kw)
+    ops.conv2d(xs[1], wps[1], zb, shift=bs[1], ysplit=tb, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(fy.view(torch.int32), gy.view(torch.int32)) and torch.equal(fs.view(torch.int32), gs.view(torch.int32))
+    assert not torch.equal(Fn.level_tensor(ya[0]).view(torch.int32), Fn.level_tensor(yb[0]).view(torch.int32))      # (the towers differ)
+
+
 def test_out_of_range_activations_are_an_error_not_a_plausible_score():
     """|x| >= 65520 cannot be held by the fp16 split: the producers set the caller's watch word (an inf logit would come out of the sigmoid as
     a plausible 1.0), and the host-side check turns it into an exception and clears it.  Exactly at the edge: 65504 passes, 65520 does not."""
