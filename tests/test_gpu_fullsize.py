@@ -158,7 +158,7 @@ def test_largest_family_at_its_native_size(arith):
     # effect on the reference arithmetic itself (its own stem gradient moves by 1.25e-2 under a 1.2e-6 input scaling).  Stated gate for
     # the stem tensors: 1e-2.
     gtol = 2e-2 if arith == 'bf16x3' else 2e-3
-    stem_tol = 2e-2 if arith == 'bf16x3' else 1e-2
+    stem_tol = 2e-2 if arith == 'bf16x3' else 8e-3          # (measured 6.1e-3 in every exact-trunk mode; round-5 advisor: keep the gate near the measurement)
     for k, v in full.items():
         d = float((v - acc[k]).norm()); rel = d / max(float(v.norm()), 1e-30)
         if rel > worst[0]:
@@ -166,7 +166,8 @@ def test_largest_family_at_its_native_size(arith):
         if rel > (stem_tol if k.startswith(('backbone._conv_stem', 'backbone._bn0')) else gtol):
             bad.append((k, rel, d, float(v.norm())))
     assert not bad, bad
-    print('D6 @1408 B=2 (%s): losses %s vs per-image mean %s; worst gradient deviation %s' % (arith, fl, ls, worst))
+    stem = max((float((v - acc[k]).norm()) / max(float(v.norm()), 1e-30) for k, v in full.items() if k.startswith(('backbone._conv_stem', 'backbone._bn0'))), default=0.0)
+    print('D6 @1408 B=2 (%s): losses %s vs per-image mean %s; worst gradient deviation %s; stem tensors %.2e' % (arith, fl, ls, worst, stem))
 
 
 def _iou_gt(a, b, thr):

@@ -84,6 +84,19 @@ def test_preprocess_oracle_identity_geometry():
     assert np.allclose(up[0], [0, 0.25, 0.75, 1.0]) and np.allclose(up[:, 0], [0, 0.5, 1.5, 2.0])   # half-pixel centres + edge clamp
 
 
+def test_resize_rule_agrees_with_an_independent_bilinear_implementation():
+    """`cv2.resize` (absent) stays "parity unpinned"; what CAN be checked here: the restated INTER_LINEAR rule (half-pixel centres, edge
+    clamp, no antialiasing) against torch's independent implementation of the same documented rule,
+    F.interpolate(mode='bilinear', align_corners=False), up- and down-sampling, non-integer ratios."""
+    import torch.nn.functional as F
+    rng = np.random.RandomState(5)
+    for (h, w, rh, rw) in [(50, 100, 48, 96), (97, 64, 96, 63), (33, 80, 39, 96), (120, 45, 96, 36), (17, 23, 64, 64)]:
+        img = rng.rand(h, w, 3).astype(np.float32)
+        got = PO.resize_bilinear(img, rw, rh)
+        ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(rh, rw), mode='bilinear', align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert got.shape == ref.shape and float(np.abs(got - ref).max()) <= 2e-5, (h, w, rh, rw, float(np.abs(got - ref).max()))     # (fp32 vs fp64 source coordinates: ~1e-5 of a unit pixel difference)
+
+
 def test_finalize_oracle_formats():
     s = np.array([0.9, 0.8, 0.5, 0.04], dtype=np.float32); l = np.array([1, 0, 1, 2]); b = np.arange(16, dtype=np.float32).reshape(4, 4)
     d = PO.finalize_reference(s, l, b, scale=2.0, score_threshold=0.05, max_detections=2)
