@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('EFFDET_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libeffdet_hip.so')   # override: A/B experiment builds (tools/)
 MAX_SEG = 5
 MAX_CONV_SEG = 10                  # effdet_conv_t: 5 pyramid levels x 2 independent convs of one geometry (the head's two towers)
-ABI_VERSION = 9                    # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
+ABI_VERSION = 10                   # EFFDET_ABI_VERSION of include/effdet_hip.h this binding was written against (tests/test_abi.py)
 F32, BF16, F32_BF16X3, F32_SPLIT = 0, 1, 2, 3      # F32_BF16X3: fp32 storage, bf16x3 products (conv2d / conv2d_wgrad only); F32_SPLIT: [32 hi | 32 lo] bf16 pairs
 F32_HSPLIT = 4                                     # the f16x3 forward arithmetic: [32 x f16 hi | 32 x f16 lo * 2^11] activations, row-scaled f16 hi | lo weights
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_SIGMOID = 0, 1, 2, 3
@@ -86,7 +86,7 @@ _lib = None
 SYMBOLS = [
     'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_conv2d_wgrad_seg_slabs', 'effdet_conv2d_wgrad_kernel', 'effdet_pack_conv_weight', 'effdet_scale_pack_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_backward_tail', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
-    'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_mbconv_expand_dw_fwd', 'effdet_mbconv_expand_dw_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes',
+    'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_mbconv_expand_dw_fwd', 'effdet_mbconv_expand_dw_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes', 'effdet_dwconv_bwd', 'effdet_dwconv_bwd_workspace_bytes',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
     'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_fwd2', 'effdet_bifpn_fuse_bwd',
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',
@@ -114,7 +114,7 @@ def lib():
         _lib = cand
         _lib.effdet_version.restype = C.c_char_p
         for name in ('effdet_num_anchors', 'effdet_nms_workspace_bytes', 'effdet_loss_workspace_bytes',
-                     'effdet_conv2d_wgrad_workspace_bytes', 'effdet_dwconv_wgrad_workspace_bytes',
+                     'effdet_conv2d_wgrad_workspace_bytes', 'effdet_dwconv_wgrad_workspace_bytes', 'effdet_dwconv_bwd_workspace_bytes',
                      'effdet_se_gate_bwd_workspace_floats'):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = C.c_longlong

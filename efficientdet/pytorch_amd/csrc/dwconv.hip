@@ -545,6 +545,224 @@ __global__ __launch_bounds__(256) void dw_dgrad_lds_kernel(const DwK p) {
   }
 }
 
+// ---------------------------------------------------------------- data gradient + weight gradient in ONE pass (training, fp32)
+// models/efficientnet.py:85-88 backward.  Both gradients of the depthwise conv pair every (input pixel, tap) with the SAME dz pixel:
+//   dx[p]  += dz[(p + pad - tap) / S] * w[tap]        g[tap] += dz[(p + pad - tap) / S] * x[p]
+// so the data-gradient tap loop -- dz halo tile in LDS, thread = (channel chunk, input pixels) -- feeds the weight gradient's k*k
+// accumulators with one more FMA per LDS value, and the separate weight-gradient launch (a second read of x and dz: 1.0 GB for block 1
+// of D0 at B = 32) disappears.  Condition: the producer stored its PRE-activation only (x == zprev: the expand conv's z-only storage,
+// or the stem's), so the one 16-byte load per output the data gradient issues anyway (for Swish') also yields x = swish(z).
+// sum dz rides along: the tap (pad_t, pad_l) pairs dz[ho][wo] with the input pixel (S ho, S wo), always inside the image, exactly once.
+// Output pixels outside the image (tile overhang) carry x = 0 = the zero padding of TF-"same".
+//   * the pre-activations of tile t+1 are fetched while tile t computes (plain loads, issued BEFORE the asm DMA of tile t+1 and first
+//     used behind the explicit wait at the end of tile t: the compiler's own waitcnt never drains the DMA early);
+//   * stride 2 walks the four parity classes; the tap loops are static over all k*k taps with a wave-uniform parity test, so the
+//     accumulators are indexed at compile time;
+//   * tile = 16 x 8 input pixels at 8-chunk slabs, 16 x 16 at 4-chunk slabs (stride 2) / 16 x 8 (stride 1): <= 4 outputs per thread,
+//     i.e. 16 + 16 registers for this and the next tile's pre-activations next to the 4 k*k accumulators.
+// Every workgroup leaves ONE slab row [k*k + 1][C] (fixed-order reduction: dw_wgrad_reduce_kernel), no float atomics.
+template <int K, int S, int CQ> struct BwTile {
+#ifndef EFFDET_DWB_S1_TH
+#define EFFDET_DWB_S1_TH 8
+#endif
+  static constexpr int TH = (S == 1 && CQ == 8) ? EFFDET_DWB_S1_TH : 16, TW = (S == 2 && CQ == 4) ? 16 : 8;
+  static constexpr int IH = (S == 1) ? TH + K - 1 : TH / 2 + (K + 1) / 2, IW = (S == 1) ? TW + K - 1 : TW / 2 + (K + 1) / 2;
+  static constexpr int NPIX = IH * IW;
+  static constexpr int npiece(int px) { return (NPIX + px - 1) / px; }
+};
+
+template <int K, int S, int CQ>
+__global__ __launch_bounds__(256) void dw_bwd_lds_kernel(const DwK p) {
+  typedef BwTile<K, S, CQ> TL;
+  constexpr int CE = 4;
+  constexpr unsigned ES = 4;
+  constexpr int PX = 64 / CQ, NPIECE = TL::npiece(PX), TILE = NPIECE * 64;
+  constexpr int ROWS = K * K + 1, SLABC = CQ * CE;
+  extern __shared__ __attribute__((aligned(16))) uint4 sm[];
+  uint4* zt = sm;                                       // [nbuf][TILE] dz halo tiles; reused for the final reduction
+  float* wt = (float*)(sm + p.nbuf * TILE);             // [K*K][CQ*CE], BN scale folded in
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (p.W + TL::TW - 1) / TL::TW, tiles_y = (p.H + TL::TH - 1) / TL::TH, tpi = tiles_x * tiles_y;
+  const int groups = (tpi + p.ppt - 1) / p.ppt;
+  const int2 bs = slab_block(p);
+  const int b = bs.x / groups, t0 = (bs.x - b * groups) * p.ppt, t1 = min(tpi, t0 + p.ppt);
+  const int chunk0 = bs.y * CQ;
+  const u32x4_t rz = make_srd_raw(p.x, p.x_bytes);      // p.x carries dz
+  const unsigned img_off = (unsigned)((long long)b * p.Ho * p.Wo * p.C * ES);
+  const unsigned zt_a = lds_addr(zt);
+  const int st_pl = lane / CQ, st_cq = lane % CQ;
+  const bool st_cok = chunk0 + st_cq < p.nch;
+  auto row0 = [&](int h0) { return (S == 1) ? h0 + p.pad_t - (K - 1) : floordiv2(h0 + p.pad_t - (K - 1) + 1); };
+  auto col0 = [&](int w0) { return (S == 1) ? w0 + p.pad_l - (K - 1) : floordiv2(w0 + p.pad_l - (K - 1) + 1); };
+  auto stage = [&](int tile, int buf) {
+    const int ty = tile / tiles_x, tx_ = tile - ty * tiles_x;
+    const int ro0 = row0(ty * TL::TH), co0 = col0(tx_ * TL::TW);
+    for (int piece = wave; piece < NPIECE; piece += 4) {
+      const int q = piece * PX + st_pl;
+      const int ih = q / TL::IW, iw = q - ih * TL::IW;
+      const int ho = ro0 + ih, wo = co0 + iw;
+      const bool ok = st_cok && q < TL::NPIX && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo;
+      dma16_async(rz, (unsigned)__builtin_amdgcn_readfirstlane((int)(zt_a + (unsigned)(buf * TILE + piece * 64) * 16u)),
+                  ok ? img_off + (unsigned)((ho * p.Wo + wo) * p.C + (chunk0 + st_cq) * CE) * ES : EFFDET_OOB);
+    }
+  };
+  constexpr int NPS = 256 / CQ;
+  constexpr int NCLS = (S == 1) ? 1 : 4;
+  constexpr int NOUT = TL::TH * TL::TW / NPS / NCLS;     // outputs per thread and class
+  constexpr int NO = NOUT * NCLS;                         // outputs per thread and tile
+  static_assert(NOUT >= 1 && NO <= 4, "tile geometry");
+  const int cq = tid % CQ, ps = tid / CQ;
+  const int c0 = (chunk0 + cq) * CE;
+  const bool cok = chunk0 + cq < p.nch;
+  const int HW = p.H * p.W;
+  const float* zin = (const float*)p.aux + (long long)b * HW * p.C + c0;      // pre-activation of the depthwise INPUT
+  // local (row, column) of output i = cls * NOUT + o of this thread (compile-time cls / o)
+  auto lpos = [&](int cls, int o, int& lh, int& lw) {
+    const int op = ps + NPS * o;
+    if (S == 1) { lh = op / TL::TW; lw = op - lh * TL::TW; }
+    else { const int hh = op / (TL::TW / 2), ww = op - hh * (TL::TW / 2); lh = 2 * hh + (cls >> 1); lw = 2 * ww + (cls & 1); }
+  };
+  auto load_pre = [&](int tile, f32x4* zr) {
+    const int h0 = (tile / tiles_x) * TL::TH, w0 = (tile % tiles_x) * TL::TW;
+#pragma unroll
+    for (int cls = 0; cls < NCLS; ++cls)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        int lh, lw; lpos(cls, o, lh, lw);
+        const int h = h0 + lh, w = w0 + lw;
+        zr[cls * NOUT + o] = (cok && h < p.H && w < p.W) ? *(const f32x4*)(zin + ((long long)h * p.W + w) * p.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  };
+  f32x4 zcur[NO], znext[NO];
+  load_pre(t0, zcur);
+  stage(t0, 0);
+  for (int i = tid; i < K * K * CQ * CE; i += 256) {
+    const int t = i / (CQ * CE), c = chunk0 * CE + (i - t * CQ * CE);
+    wt[i] = c < p.C ? p.w[t * p.C + c] * (p.scale ? p.scale[c] : 1.f) : 0.f;
+  }
+  f32x4 g[K * K], ds = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) g[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  dma_wait_all();
+  for (int tile = t0; tile < t1; ++tile) {
+    const int cur = (p.nbuf == 2) ? ((tile - t0) & 1) : 0;
+    __syncthreads();
+    const bool more = tile + 1 < t1;
+    if (more) load_pre(tile + 1, znext);                  // (ahead of the DMA: see the header)
+    asm volatile("" ::: "memory");                        // (pins the loads here also when no DMA follows: single-buffer launches)
+    if (p.nbuf == 2 && more) stage(tile + 1, cur ^ 1);
+    const uint4* zb = zt + cur * TILE;
+    const int h0 = (tile / tiles_x) * TL::TH, w0 = (tile % tiles_x) * TL::TW;
+    const int ro0 = row0(h0), co0 = col0(w0);
+    f32x4 outq[NO];
+#pragma unroll
+    for (int cls = 0; cls < NCLS; ++cls) {
+      const int ph = cls >> 1, pw = cls & 1;
+      f32x4 acc[NOUT], xe[NOUT];
+      int lh[NOUT], lw[NOUT], sbase[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        lpos(cls, o, lh[o], lw[o]);
+        sbase[o] = (lh[o] * TL::IW + lw[o]) * CQ + cq;
+        acc[o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 z = zcur[cls * NOUT + o];              // (zeros outside the image: swish(0) = 0)
+        xe[o] = f32x4{swishf_(z[0]), swishf_(z[1]), swishf_(z[2]), swishf_(z[3])};
+      }
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        if (S == 2 && ((ph + p.pad_t + kh) & 1)) continue;        // wave-uniform: only taps with (h + pad_t - kh) even reach a dz row
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) {
+          if (S == 2 && ((pw + p.pad_l + kw) & 1)) continue;
+#ifdef EFFDET_DWB_TAP_BARRIER
+          if (kw) { asm volatile("" : "+v"(g[kh * K + kw - 1])); __builtin_amdgcn_sched_barrier(0); }
+#endif
+          const f32x4 wv = *(const f32x4*)(wt + (kh * K + kw) * CQ * CE + cq * CE);
+          const bool centre = kh == p.pad_t && kw == p.pad_l;      // wave-uniform
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) {
+            uint4 q;
+            if (S == 1) {
+              // slot = (lh + K-1 - kh) * IW + (lw + K-1 - kw): a per-output base (hoisted: NOUT registers) + a compile-time tap constant
+              // that folds into the ds_read offset (written through h0 / ro0, hipcc kept all NOUT x K x K addresses in VGPRs)
+              q = zb[sbase[o] + ((K - 1 - kh) * TL::IW + (K - 1 - kw)) * CQ];
+            } else {
+              const int hn = h0 + lh[o] + p.pad_t - kh, wn = w0 + lw[o] + p.pad_l - kw;
+              q = zb[(((hn >> 1) - ro0) * TL::IW + ((wn >> 1) - co0)) * CQ + cq];
+            }
+            const f32x4 dv = f32x4{__uint_as_float(q.x), __uint_as_float(q.y), __uint_as_float(q.z), __uint_as_float(q.w)};
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+              acc[o][e] = fmaf(dv[e], wv[e], acc[o][e]);
+              g[kh * K + kw][e] = fmaf(dv[e], xe[o][e], g[kh * K + kw][e]);
+            }
+            if (centre) ds += dv;
+          }
+        }
+        // the partial sums are materialised HERE: hipcc otherwise sinks the whole data-gradient accumulation into the bounds-checked
+        // store blocks at the end of the tile and keeps every LDS value of the tile alive until then (256 VGPRs, 1 wave / SIMD)
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) asm volatile("" : "+v"(acc[o]));
+#pragma unroll
+        for (int kw = 0; kw < K; ++kw) asm volatile("" : "+v"(g[kh * K + kw]));       // (same for the weight-gradient rows: they sank to the loop latch)
+        asm volatile("" : "+v"(ds));
+        __builtin_amdgcn_sched_barrier(0);                // one tap row of LDS reads in flight
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        const f32x4 z = zcur[cls * NOUT + o];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[o][e] *= swish_gradf_(z[e]);
+        outq[cls * NOUT + o] = acc[o];
+      }
+    }
+    // the next tile's dz pieces and pre-activations have landed (they had the whole tap loop); the stores of this tile stay in
+    // flight across the barrier
+    dma_wait_all();
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NO; ++i) zcur[i] = znext[i];
+    }
+#pragma unroll
+    for (int cls = 0; cls < NCLS; ++cls)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) {
+        int lh, lw; lpos(cls, o, lh, lw);
+        const int h = h0 + lh, w = w0 + lw;
+        if (!cok || h >= p.H || w >= p.W) continue;
+        *(f32x4*)((float*)p.y + ((long long)b * HW + (long long)h * p.W + w) * p.C + c0) = outq[cls * NOUT + o];
+      }
+    if (p.nbuf == 1 && more) {
+      __syncthreads();
+      stage(tile + 1, 0);
+      dma_wait_all();
+    }
+  }
+  // ---- reduce the weight-gradient rows over the pixel slots: shuffles inside the wave, then the 4 waves through LDS ----
+  __syncthreads();
+  float* red = (float*)sm;                                // [4 waves][ROWS][SLABC]
+#pragma unroll
+  for (int t = 0; t < ROWS; ++t) {
+    f32x4 v = t < K * K ? g[t < K * K ? t : 0] : ds;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float s = v[e];
+#pragma unroll
+      for (int o = 32; o >= CQ; o >>= 1) s += __shfl_xor(s, o, 64);
+      v[e] = s;
+    }
+    if (lane < CQ) *(f32x4*)(red + (wave * ROWS + t) * SLABC + cq * CE) = v;
+  }
+  __syncthreads();
+  float* slab = (float*)p.z + (long long)bs.x * ROWS * p.C;           // [tile group over all images][ROWS][C]
+  for (int i = tid; i < ROWS * SLABC; i += 256) {
+    const int t = i / SLABC, c = i - t * SLABC;
+    const int ch = chunk0 * CE + c;
+    const float v = (red[i] + red[ROWS * SLABC + i]) + (red[2 * ROWS * SLABC + i] + red[3 * ROWS * SLABC + i]);
+    if (ch < p.C) slab[(long long)t * p.C + ch] = v;
+  }
+}
+
 // ---------------------------------------------------------------- weight gradient
 // g[tap][c] += sum_{b,ho,wo} dz * x(tap),  dsum[c] += sum dz.   4 channels per thread, K*K taps in registers.
 template <typename T, int K>
@@ -1022,6 +1240,77 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
   if (!extent(a, (long long)B * Ho * Wo * C, dtype)) return EFFDET_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   DW_DISPATCH(launch_dgrad_lds, dtype, k, stride, a, st);
+  EFFDET_CHECK_LAUNCH();
+  return EFFDET_OK;
+}
+
+namespace {
+// ---- fused data + weight gradient (dw_bwd_lds_kernel): fp32, k = 3 ----
+inline bool bwd_fused_ok(int dtype, int k, int H, int W) {
+  static const int off = getenv("EFFDET_DW_BWD_FUSED") ? atoi(getenv("EFFDET_DW_BWD_FUSED")) == 0 : 0;       // A/B switch
+  return !off && dtype == EFFDET_F32 && k == 3 && H * W >= 64;
+}
+template <int K, int S, int CQ>
+int bwd_geometry(DwK& a, dim3& grid, size_t& lds) {
+  typedef BwTile<K, S, CQ> TL;
+  const size_t tile = (size_t)TL::npiece(64 / CQ) * 1024, wb = (size_t)K * K * CQ * 4 * 4, red = (size_t)4 * (K * K + 1) * CQ * 4 * 4;
+  const int tpi = ((a.H + TL::TH - 1) / TL::TH) * ((a.W + TL::TW - 1) / TL::TW), nslab = (a.nch + CQ - 1) / CQ;
+  // Tiles per workgroup.  ~140 VGPRs = 3 workgroups per CU = 768 resident workgroups, each ending in a reduction + a slab row worth
+  // ~1.5 tiles of time: pick the run length whose ROUNDS of resident workgroups cost least (block 0 of D0 at B = 32: 32 768 tiles ->
+  // 43 per workgroup = exactly one round of 768; the ">= 1536 workgroups" rule of the other kernels gave 3.25 rounds, 4 paid)
+  static const int slots = getenv("EFFDET_DWB_SLOTS") ? atoi(getenv("EFFDET_DWB_SLOTS")) : 768;
+  int best = 1; double best_cost = 1e30;
+  for (int ppt = 1; ppt <= 64 && ppt <= tpi; ++ppt) {
+    const long long nwg = (long long)a.B * ((tpi + ppt - 1) / ppt) * nslab;
+    const double cost = (double)((nwg + slots - 1) / slots) * (ppt + 1.5);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = ppt; }
+  }
+  a.ppt = best;
+  a.nbuf = (a.ppt > 1 && 2 * tile + wb <= 80 * 1024) ? 2 : 1;
+  lds = a.nbuf * tile + wb;
+  if (lds < red) lds = red;
+  grid = slab_grid(a, a.B * ((tpi + a.ppt - 1) / a.ppt), nslab);
+  return a.B * ((tpi + a.ppt - 1) / a.ppt);            // slab rows
+}
+template <int K, int S, int CQ>
+int launch_bwd_lds(const DwK& a0, hipStream_t st, bool launch) {
+  DwK a = a0; dim3 grid; size_t lds;
+  const int rows = bwd_geometry<K, S, CQ>(a, grid, lds);
+  if (!launch) return rows;
+  EFFDET_SET_MAX_LDS((dw_bwd_lds_kernel<K, S, CQ>), lds);
+  hipLaunchKernelGGL((dw_bwd_lds_kernel<K, S, CQ>), grid, dim3(256), lds, st, a);
+  return rows;
+}
+int bwd_dispatch(const DwK& a, int stride, hipStream_t st, bool launch) {
+  if (slab_chunks(a.nch) == 4) return stride == 1 ? launch_bwd_lds<3, 1, 4>(a, st, launch) : launch_bwd_lds<3, 2, 4>(a, st, launch);
+  return stride == 1 ? launch_bwd_lds<3, 1, 8>(a, st, launch) : launch_bwd_lds<3, 2, 8>(a, st, launch);
+}
+}  // namespace
+
+extern "C" long long effdet_dwconv_bwd_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                                                        int Ho, int Wo) {
+  if (!bwd_fused_ok(dtype, k, H, W)) return 0;             // 0 = not available for this geometry: use the two separate entry points
+  DwK a{}; dim3 grid;
+  if (fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, H * W, grid)) return -1;
+  return (long long)bwd_dispatch(a, stride, nullptr, false) * (k * k + 1) * C * (long long)sizeof(float);
+}
+
+extern "C" int effdet_dwconv_bwd(const void* dz, const float* w, const float* scale, const void* zprev, void* dx, float* g, float* dsum,
+                                 void* workspace, long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
+                                 int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
+  if (!dz || !w || !zprev || !dx || !g || !workspace) return EFFDET_EINVAL;
+  if (!bwd_fused_ok(dtype, k, H, W)) return EFFDET_EUNSUPPORTED;
+  DwK a{}; dim3 grid;
+  int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, H * W, grid);
+  if (rc) return rc;
+  a.x = dz; a.w = w; a.scale = scale; a.aux = zprev; a.y = dx; a.z = workspace;
+  if (!extent(a, (long long)B * Ho * Wo * C, dtype)) return EFFDET_EUNSUPPORTED;
+  const int rows = k * k + 1;
+  if (workspace_bytes < (long long)bwd_dispatch(a, stride, nullptr, false) * rows * C * (long long)sizeof(float)) return EFFDET_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int nrows = bwd_dispatch(a, stride, st, true);
+  EFFDET_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dw_wgrad_reduce_kernel, dim3((rows * C + 63) / 64), dim3(256), 0, st, (const float*)workspace, g, dsum, nrows, rows, C);
   EFFDET_CHECK_LAUNCH();
   return EFFDET_OK;
 }

@@ -21,6 +21,7 @@ DW_SAVE_Y = os.environ.get('EFFDET_DW_SAVE_Y', '0') == '1'      # A/B switch: al
 BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     # A/B switch: grouped BiFPN weight gradients
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
+DW_BWD_FUSED = os.environ.get('EFFDET_DW_BWD_FUSED', '1') == '1'       # training, fp32, k = 3: depthwise data + weight gradient in one kernel
 FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage: expand conv inside the depthwise kernel
 FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').split(','))     # block input widths that take it (A/B)
 # f16x3 BiFPN convs from this much work per launch (output pixels x C^2; x 18 = FLOPs): below ~2 GFLOP the launch is a handful of tiles behind a
@@ -224,13 +225,20 @@ def mbconv_bwd(sv, dy):
     g['se_reduce.weight'], g['se_reduce.bias'] = dw1.view(Cs, Ce, 1, 1), db1
     g['se_expand.weight'], g['se_expand.bias'] = dw2.view(Ce, Cs, 1, 1), db2
     # ---- depthwise ----
-    gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0], in_act=sv['dw_in_act'])
-    g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,
-                                                                             P['bn1.running_mean'], sv['i1'])
     # (expand == 1, i.e. block 0: the depthwise conv reads the block input itself; given the pre-activation `xpre` of the producer --
     #  the stem's z -- its Swish' is applied here, in the data gradient's epilogue, instead of a separate pass in the stem's backward)
-    dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], sv.get('ze') if blk.expand != 1 else sv.get('xpre'), H, W, blk.k, blk.stride,
-                           blk.pad[0], blk.pad[0])
+    zprev = sv.get('ze') if blk.expand != 1 else sv.get('xpre')
+    fused = None
+    if DW_BWD_FUSED and sv['dw_in_act'] == ACT_SWISH and zprev is sv['xe'] and dtype == torch.float32:
+        # z-only storage: the depthwise input IS swish(zprev) -- one kernel reads dz_d and zprev once for both gradients (round 6)
+        fused = ops.dwconv_bwd(dzd, sv['wk'], sv['s1'], zprev, blk.k, blk.stride, blk.pad[0], blk.pad[0])
+    if fused is not None:
+        dze, gk, dsum1 = fused
+    else:
+        gk, dsum1 = ops.dwconv_wgrad(sv['xe'], dzd, blk.k, blk.stride, blk.pad[0], blk.pad[0], in_act=sv['dw_in_act'])
+        dze = ops.dwconv_dgrad(dzd, sv['wk'], sv['s1'], zprev, H, W, blk.k, blk.stride, blk.pad[0], blk.pad[0])
+    g['dw.weight'], g['bn1.weight'], g['bn1.bias'] = ops.dw_unpack_wgrad_bn(gk, sv['s1'], P['dw.weight'], dsum1,
+                                                                             P['bn1.running_mean'], sv['i1'])
     if blk.expand == 1:
         return dze, g           # block 0: depthwise acts on the block input directly, no skip
     # ---- expand conv; the identity-skip gradient is added in the data-gradient epilogue ----

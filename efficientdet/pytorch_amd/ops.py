@@ -854,6 +854,26 @@ def dwconv_wgrad(x, dz, k, stride, pad_t, pad_l, in_act=ACT_NONE):
     return g[:k * k], g[k * k]
 
 
+def dwconv_bwd(dz, w_kkc, scale, zprev, k, stride, pad_t, pad_l):
+    """Data + weight gradient of the depthwise conv in one pass (the conv's input was stored as the pre-activation ``zprev`` only).
+    -> (dx, g [k*k][C], dsum [C]), or None when the fused kernel does not serve the geometry (callers run dwconv_wgrad + dwconv_dgrad)."""
+    H, W = zprev.H, zprev.W
+    geo = (L.dtype_code(dz.dtype), dz.B, H, W, dz.C, k, stride, pad_t, pad_l, dz.H, dz.W)
+    nbytes = int(L.lib().effdet_dwconv_bwd_workspace_bytes(*geo))
+    if nbytes < 0:
+        raise RuntimeError('effdet_dwconv_bwd: invalid geometry')
+    if nbytes == 0 or zprev.ld != zprev.C or zprev.off != 0 or dz.ld != dz.C or dz.off != 0:
+        return None
+    dx = Map.new(dz.B, H, W, dz.C, dz.dtype, dz.t.device)
+    g = torch.empty((k * k + 1, dz.C), dtype=torch.float32, device=dz.t.device)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dz.t.device)
+    traffic = dz.t.element_size() * dz.B * dz.C * (dz.H * dz.W + 2 * H * W)
+    _timed('dw_bwd_lds_kernel', traffic, lambda: L.check(L.lib().effdet_dwconv_bwd(
+        L.ptr(dz.tensor()), L.ptr(w_kkc), L.ptr(scale), L.ptr(zprev.tensor()), L.ptr(dx.t), L.ptr(g), L.ptr(g[k * k]), L.ptr(ws),
+        C.c_longlong(nbytes), *geo, L.stream_ptr()), 'effdet_dwconv_bwd'), 'BYTES k%d s%d C%d %dx%d' % (k, stride, dz.C, H, W))
+    return dx, g[:k * k], g[k * k]
+
+
 # ----------------------------------------------------------------------------- squeeze-excite
 def se_gate_fwd(pool_part, w1, b1, w2, b2, inv_hw, save_mid=False):
     """pool_part: [B][G][C] partial sums of dwconv_fwd (or a plain [B][C] pool) -> (gate, mid, pool [B][C] = the pooled SUM)."""

@@ -320,6 +320,17 @@ long long effdet_dwconv_wgrad_workspace_bytes(int dtype, int B, int H, int W, in
 int effdet_dwconv_wgrad(const void* x, const void* dz, float* g_kkc, float* dsum, void* workspace,
                         long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, int in_act, effdet_stream_t stream);
+/* Data gradient AND weight gradient of the depthwise conv in one pass over dz and zprev (models/efficientnet.py:85-88 backward; replaces
+ * the two entry points above when the conv's input was stored as its producer's PRE-activation only, i.e. x = swish(zprev)):
+ *   dx = (sum_taps dz * w * scale) * swish'(zprev)      g[tap][c] = sum dz * swish(zprev)(tap)      dsum[c] = sum dz
+ * fp32, k = 3.  effdet_dwconv_bwd_workspace_bytes returns 0 when the fused form does not serve the geometry (use the two separate
+ * entry points), < 0 on invalid arguments, else the bytes of the slab workspace (one [k*k + 1][C] row set per workgroup, added in a
+ * fixed order by a reduce pass: no float atomics).  g_kkc / dsum are OVERWRITTEN. */
+long long effdet_dwconv_bwd_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                                            int Ho, int Wo);
+int effdet_dwconv_bwd(const void* dz, const float* w_kkc, const float* scale, const void* zprev, void* dx, float* g_kkc, float* dsum,
+                      void* workspace, long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
+                      int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
 /* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
  * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);
@@ -582,7 +593,7 @@ const char* effdet_version(void);
 /* ABI generation of this header: bumped whenever an entry point's signature or a descriptor struct's layout changes.  A binding
  * compares effdet_abi_version() of the library it loaded with the EFFDET_ABI_VERSION it was written against and refuses a
  * mismatch (a stale .so called through ctypes / cgo with shifted arguments reads garbage instead of failing). */
-#define EFFDET_ABI_VERSION 9
+#define EFFDET_ABI_VERSION 10
 int effdet_abi_version(void);
 
 #ifdef __cplusplus

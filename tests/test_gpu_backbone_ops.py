@@ -98,6 +98,41 @@ def test_dwconv_fwd_bwd(dtype, cfg):
     assert_close(nchw(dxm2), x.grad * (sg * (1 + zp * (1 - sg))), TOL[dtype], 'dw dgrad*swish')
 
 
+@pytest.mark.parametrize('cfg', [(2, 16, 16, 32, 3, 1, (1, 1)), (2, 17, 17, 96, 3, 2, (0, 1)), (2, 33, 21, 144, 3, 1, (1, 1)), (2, 32, 32, 96, 3, 2, (0, 1)),
+                                 (3, 40, 24, 16, 3, 2, (0, 1)), (2, 31, 31, 480, 3, 2, (1, 1)), (2, 64, 48, 144, 3, 1, (1, 1)), (4, 128, 128, 32, 3, 1, (1, 1)),
+                                 (2, 8, 8, 1152, 3, 2, (0, 1))])
+def test_dwconv_fused_data_and_weight_gradient(cfg):
+    """effdet_dwconv_bwd (one pass over dz and the stored pre-activation) vs torch autograd of conv(swish(zprev)) -- models/efficientnet.py:85-88 --
+    and vs the two separate kernels it replaces; two launches bitwise equal (slab reduction in a fixed order)."""
+    from efficientdet.pytorch_amd import ops
+    B, H, W, C, k, s, (plo, phi) = cfg
+    g = torch.Generator().manual_seed(5)
+    zp = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(C, 1, k, k, generator=g) * (2.0 / (k * k)) ** 0.5).requires_grad_(True)
+    scale = 0.5 + torch.rand(C, generator=g)
+    x = zp * torch.sigmoid(zp)
+    z = F.conv2d(F.pad(x, [plo, phi, plo, phi]), w, None, s, 0, 1, C) * scale.view(1, -1, 1, 1)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    dev = 'cuda'
+    wk = ops.dw_pack_weight(w.detach().to(dev))
+    zpm, dzm = nhwc(zp.detach(), torch.float32), nhwc(dz, torch.float32)
+    out = ops.dwconv_bwd(dzm, wk, scale.to(dev), zpm, k, s, plo, plo)
+    assert out is not None, 'the fused kernel must serve every fp32 k = 3 geometry from 8 x 8 up'
+    dxm, gk, dsum = out
+    out2 = ops.dwconv_bwd(dzm, wk, scale.to(dev), zpm, k, s, plo, plo)
+    assert torch.equal(out2[0].tensor(), dxm.tensor()) and torch.equal(out2[1], gk) and torch.equal(out2[2], dsum)
+    dw = ops.dw_unpack_wgrad(gk, scale.to(dev), w.detach().to(dev), torch.empty(C, device=dev))
+    assert_close(nchw(dxm), zp.grad, 2e-4, 'fused dw dgrad*swish\'')
+    assert_close(dw.cpu(), w.grad, 1e-3, 'fused dw wgrad')
+    assert_close(dsum.cpu(), dz.sum(dim=(0, 2, 3)), 1e-3, 'fused dw dsum')
+    # the separate kernels (same arithmetic per element for the data gradient: bitwise; the weight gradient sums in another order)
+    dx_sep = ops.dwconv_dgrad(dzm, wk, scale.to(dev), zpm, H, W, k, s, plo, plo)
+    g_sep, ds_sep = ops.dwconv_wgrad(zpm, dzm, k, s, plo, plo, in_act=ops.ACT_SWISH)
+    assert torch.equal(dx_sep.tensor(), dxm.tensor())
+    assert_close_scale(gk.cpu(), g_sep.cpu(), 2e-5, 'fused vs separate dw wgrad'); assert_close_scale(dsum.cpu(), ds_sep.cpu(), 2e-5, 'fused vs separate dsum')
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8), (5, 3, 3, 144, 6), (2, 4, 4, 672, 28)])
 def test_squeeze_excite_fwd_bwd(dtype, cfg):
