@@ -22,6 +22,7 @@ BIFPN_WGRAD_GROUP = os.environ.get('EFFDET_BIFPN_WGRAD_GROUP', '1') != '0'     #
 EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training: the expand conv stores its pre-activation only
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 DW_BWD_FUSED = os.environ.get('EFFDET_DW_BWD_FUSED', '1') == '1'       # training, fp32, k = 3: depthwise data + weight gradient in one kernel
+PW_BWD_FUSED = os.environ.get('EFFDET_PW_BWD_FUSED', '1') == '1'       # training, fp32, Cin 16 / 24 / 32: expand conv data + weight gradient in one kernel
 FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage: expand conv inside the depthwise kernel
 FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').split(','))     # block input widths that take it (A/B)
 # f16x3 BiFPN convs from this much work per launch (output pixels x C^2; x 18 = FLOPs): below ~2 GFLOP the launch is a handful of tiles behind a
@@ -242,12 +243,18 @@ def mbconv_bwd(sv, dy):
     if blk.expand == 1:
         return dze, g           # block 0: depthwise acts on the block input directly, no skip
     # ---- expand conv; the identity-skip gradient is added in the data-gradient epilogue ----
-    G0, dsum0 = ops.conv2d_wgrad(x, dze, Cin=Ci, Cout=Ce, KH=1, KW=1)
     we = P['expand.weight']
+    fusedp = ops.pw_bwd(dze, x, we, sv['s0'], dy if blk.skip else None) if PW_BWD_FUSED and dtype == torch.float32 else None
+    if fusedp is not None:
+        # the high-resolution blocks (Cin 16 / 24 / 32): both gradients of the expand conv from ONE read of the 6x-expanded gradient (round 6)
+        dx, G0, dsum0 = fusedp
+    else:
+        G0, dsum0 = ops.conv2d_wgrad(x, dze, Cin=Ci, Cout=Ce, KH=1, KW=1)
     g['expand.weight'], g['bn0.weight'], g['bn0.bias'] = ops.unpack_wgrad_bn(G0, we, sv['s0'], dsum0, P['bn0.running_mean'], sv['i0'])
-    dx = Map.new(B, H, W, Ci, dtype, dev)
-    ops.conv2d(dze, ops.pack_weight(we, dtype, mode=1, scale=sv['s0']), dx, Cin=Ce, Cout=Ci, KH=1, KW=1,
-               res=dy if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
+    if fusedp is None:
+        dx = Map.new(B, H, W, Ci, dtype, dev)
+        ops.conv2d(dze, ops.pack_weight(we, dtype, mode=1, scale=sv['s0']), dx, Cin=Ce, Cout=Ci, KH=1, KW=1,
+                   res=dy if blk.skip else None, res_mode=RES_ADD if blk.skip else RES_NONE)
     return dx, g
 
 

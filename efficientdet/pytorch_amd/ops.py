@@ -874,6 +874,25 @@ def dwconv_bwd(dz, w_kkc, scale, zprev, k, stride, pad_t, pad_l):
     return dx, g[:k * k], g[k * k]
 
 
+def pw_bwd(dz, x, w_expand, scale, res=None):
+    """Data + weight gradient of the MBConv expand conv in one pass over the expanded gradient ``dz`` (effdet_pw_bwd).
+    -> (dx Map, slabs [S][Cexp][1][Cin], dsum parts [S][Cexp]) for unpack_wgrad_bn, or None when the fused kernel does not serve the geometry."""
+    Cexp, Cin = w_expand.shape[0], w_expand.shape[1]
+    M = dz.B * dz.H * dz.W
+    dense = all(m is None or (m.ld == m.C and m.off == 0 and m.bstride == m.H * m.W * m.C and m.dtype == torch.float32) for m in (dz, x, res))
+    S = int(L.lib().effdet_pw_bwd_slabs(C.c_longlong(M), Cin, Cexp)) if dense and dz.C == Cexp and x.C == Cin else 0
+    if S < 1:
+        return None
+    dx = Map.new(x.B, x.H, x.W, Cin, torch.float32, x.t.device)
+    ws = torch.empty(S * (Cexp * Cin + Cexp), dtype=torch.float32, device=x.t.device)
+    slabs, parts = ws[:S * Cexp * Cin].view(S, Cexp, 1, Cin), ws[S * Cexp * Cin:].view(S, Cexp)
+    _timed('conv_pw_bwd_kernel', 4.0 * Cin * Cexp * M, lambda: L.check(L.lib().effdet_pw_bwd(
+        L.ptr(dz.tensor()), L.ptr(x.tensor()), L.ptr(w_expand.detach()), L.ptr(scale), L.ptr(res.tensor() if res is not None else None), L.ptr(dx.t),
+        L.ptr(slabs), L.ptr(parts), C.c_longlong(M), Cin, Cexp, L.stream_ptr()), 'effdet_pw_bwd'), 'Cin%d Cexp%d M%d' % (Cin, Cexp, M),
+        nbytes=4.0 * M * (Cexp + (3 if res is not None else 2) * Cin))
+    return dx, slabs, parts
+
+
 # ----------------------------------------------------------------------------- squeeze-excite
 def se_gate_fwd(pool_part, w1, b1, w2, b2, inv_hw, save_mid=False):
     """pool_part: [B][G][C] partial sums of dwconv_fwd (or a plain [B][C] pool) -> (gate, mid, pool [B][C] = the pooled SUM)."""

@@ -331,6 +331,16 @@ long long effdet_dwconv_bwd_workspace_bytes(int dtype, int B, int H, int W, int 
 int effdet_dwconv_bwd(const void* dz, const float* w_kkc, const float* scale, const void* zprev, void* dx, float* g_kkc, float* dsum,
                       void* workspace, long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
                       int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream);
+/* Backward of the MBConv expand conv (1x1, Cin -> Cexp = 6 Cin, frozen BN folded; models/efficientnet.py:82-84) in one pass over the
+ * expanded gradient dz [M][Cexp] (M = B*H*W pixels, fp32 NHWC, dense rows) -- replaces effdet_conv2d_wgrad + effdet_conv2d for this conv:
+ *   dx[M][Cin] = dz (scale[ce] * w_expand[ce][ci]) (+ res[M][Cin], optional: the identity-skip gradient)
+ *   slabs[S][Cexp][Cin] = per-workgroup partial sums of dz^T x (UNSCALED),  dsum_part[S][Cexp] = partial column sums of dz
+ * with S = effdet_pw_bwd_slabs(M, Cin, Cexp) (0 = the fused form does not serve this geometry: Cin in {16, 24, 32}, M >= 131072).
+ * The slabs are summed in slab order by effdet_unpack_conv_wgrad_bn / effdet_backward_tail (nslabs = S): no float atomics.
+ * w_expand is the OIHW 1x1 master weight as is. */
+int effdet_pw_bwd_slabs(long long M, int Cin, int Cexp);
+int effdet_pw_bwd(const float* dz, const float* x, const float* w_expand, const float* scale, const float* res, float* dx,
+                  float* slabs, float* dsum_part, long long M, int Cin, int Cexp, effdet_stream_t stream);
 /* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
  * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);

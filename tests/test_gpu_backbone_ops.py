@@ -133,6 +133,45 @@ def test_dwconv_fused_data_and_weight_gradient(cfg):
     assert_close_scale(gk.cpu(), g_sep.cpu(), 2e-5, 'fused vs separate dw wgrad'); assert_close_scale(dsum.cpu(), ds_sep.cpu(), 2e-5, 'fused vs separate dsum')
 
 
+@pytest.mark.parametrize('cfg', [(2, 256, 256, 16, True), (2, 256, 256, 16, False), (8, 128, 128, 24, True), (3, 217, 203, 24, False), (8, 128, 128, 32, True)])
+def test_expand_conv_fused_data_and_weight_gradient(cfg):
+    """effdet_pw_bwd (both gradients of the MBConv expand conv from one read of the expanded gradient; models/efficientnet.py:82-84 backward) vs a
+    float64 matmul, vs the two launches it replaces, through the unpack job that sums its slabs; two launches bitwise equal."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    B, H, W, Ci, skip = cfg
+    Ce = 6 * Ci
+    g = torch.Generator().manual_seed(11)
+    dev = 'cuda'
+    dz = torch.randn(B, H, W, Ce, generator=g).to(dev); x = torch.randn(B, H, W, Ci, generator=g).to(dev)
+    we = (torch.randn(Ce, Ci, 1, 1, generator=g) / Ci ** 0.5).to(dev); s0 = (0.5 + torch.rand(Ce, generator=g)).to(dev)
+    res = torch.randn(B, H, W, Ci, generator=g).to(dev) if skip else None
+    out = ops.pw_bwd(Map.of(dz), Map.of(x), we, s0, Map.of(res) if skip else None)
+    assert out is not None
+    dx, slabs, parts = out
+    out2 = ops.pw_bwd(Map.of(dz), Map.of(x), we, s0, Map.of(res) if skip else None)
+    assert torch.equal(out2[0].tensor(), dx.tensor()) and torch.equal(out2[1], slabs) and torch.equal(out2[2], parts)
+    mean, inv = torch.randn(Ce, device=dev), torch.rand(Ce, device=dev) + 0.5
+    dw, dgam, dbeta = ops.unpack_wgrad_bn(slabs, we, s0, parts, mean, inv)
+    torch.cuda.synchronize()
+    dz2, x2 = dz.double().view(-1, Ce), x.double().view(-1, Ci)
+    ws = (we.view(Ce, Ci) * s0.view(-1, 1)).double()                       # fl(w * s) as the kernel forms it, then exact
+    dx_ref = dz2 @ ws + (res.double().view(-1, Ci) if skip else 0)
+    G_ref = dz2.t() @ x2
+    assert_close(dx.tensor().view(-1, Ci).cpu(), dx_ref.float().cpu(), 1e-4, 'fused expand dgrad')
+    assert_close(dw.view(Ce, Ci).cpu(), (G_ref * s0.double().view(-1, 1)).float().cpu(), 1e-4, 'fused expand wgrad')
+    assert_close(dbeta.cpu(), dz2.sum(0).float().cpu(), 1e-4, 'fused expand dsum')
+    # the two separate launches
+    G0, d0 = ops.conv2d_wgrad(Map.of(x), Map.of(dz), Cin=Ci, Cout=Ce, KH=1, KW=1)
+    dw_s, dgam_s, dbeta_s = ops.unpack_wgrad_bn(G0, we, s0, d0, mean, inv)
+    dx_s = Map.new(B, H, W, Ci, torch.float32, dev)
+    ops.conv2d(Map.of(dz), ops.pack_weight(we, torch.float32, mode=1, scale=s0), dx_s, Cin=Ce, Cout=Ci, KH=1, KW=1,
+               res=Map.of(res) if skip else None, res_mode=ops.RES_ADD if skip else ops.RES_NONE)
+    assert_close_scale(dx.tensor().cpu(), dx_s.tensor().cpu(), 2e-6, 'fused vs separate expand dgrad')
+    assert_close_scale(dw.cpu(), dw_s.cpu(), 2e-6, 'fused vs separate expand wgrad')
+    assert_close_scale(dgam.cpu(), dgam_s.cpu(), 2e-5, 'fused vs separate dgamma'); assert_close_scale(dbeta.cpu(), dbeta_s.cpu(), 2e-6, 'fused vs separate dbeta')
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8), (5, 3, 3, 144, 6), (2, 4, 4, 672, 28)])
 def test_squeeze_excite_fwd_bwd(dtype, cfg):
