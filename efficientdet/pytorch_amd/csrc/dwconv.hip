@@ -674,9 +674,12 @@ __global__ __launch_bounds__(256) void dw_bwd_lds_kernel(const DwK p) {
 #pragma unroll
         for (int kw = 0; kw < K; ++kw) {
           if (S == 2 && ((pw + p.pad_l + kw) & 1)) continue;
-#ifdef EFFDET_DWB_TAP_BARRIER
-          if (kw) { asm volatile("" : "+v"(g[kh * K + kw - 1])); __builtin_amdgcn_sched_barrier(0); }
-#endif
+          if (K == 5 && kw) {      // k = 5: one tap of LDS values in flight (a whole row of 5 x NOUT cost 2 waves / SIMD)
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) asm volatile("" : "+v"(acc[o]));
+            asm volatile("" : "+v"(g[kh * K + kw - 1]));
+            __builtin_amdgcn_sched_barrier(0);
+          }
           const f32x4 wv = *(const f32x4*)(wt + (kh * K + kw) * CQ * CE + cq * CE);
           const bool centre = kh == p.pad_t && kw == p.pad_l;      // wave-uniform
 #pragma unroll
@@ -1246,9 +1249,13 @@ extern "C" int effdet_dwconv_dgrad(const void* dz, const float* w, const float* 
 
 namespace {
 // ---- fused data + weight gradient (dw_bwd_lds_kernel): fp32, k = 3 ----
-inline bool bwd_fused_ok(int dtype, int k, int H, int W) {
+inline bool bwd_fused_ok(int dtype, int k, int stride, int H, int W) {
   static const int off = getenv("EFFDET_DW_BWD_FUSED") ? atoi(getenv("EFFDET_DW_BWD_FUSED")) == 0 : 0;       // A/B switch
-  return !off && dtype == EFFDET_F32 && k == 3 && H * W >= 64;
+  static const int k5 = getenv("EFFDET_DW_BWD_FUSED_K5") ? atoi(getenv("EFFDET_DW_BWD_FUSED_K5")) : 1;
+  // k = 5 (100 accumulators, 2 workgroups per CU) pays from 32 x 32 maps up at stride 1, 64 x 64 at stride 2 (measured, D0 B = 32:
+  // 128^2 s2 304 -> 205 us, 64^2 195 -> 140, 32^2 139 -> 115; 32^2 s2 76 -> 82 and 16^2 61 -> 65 stay on the two kernels); k5 = 2 forces it
+  const bool k5ok = k5 == 2 || (k5 == 1 && H * W >= (stride == 1 ? 1024 : 4096));
+  return !off && dtype == EFFDET_F32 && (k == 3 || (k == 5 && k5ok)) && H * W >= 64;
 }
 template <int K, int S, int CQ>
 int bwd_geometry(DwK& a, dim3& grid, size_t& lds) {
@@ -1258,7 +1265,8 @@ int bwd_geometry(DwK& a, dim3& grid, size_t& lds) {
   // Tiles per workgroup.  ~140 VGPRs = 3 workgroups per CU = 768 resident workgroups, each ending in a reduction + a slab row worth
   // ~1.5 tiles of time: pick the run length whose ROUNDS of resident workgroups cost least (block 0 of D0 at B = 32: 32 768 tiles ->
   // 43 per workgroup = exactly one round of 768; the ">= 1536 workgroups" rule of the other kernels gave 3.25 rounds, 4 paid)
-  static const int slots = getenv("EFFDET_DWB_SLOTS") ? atoi(getenv("EFFDET_DWB_SLOTS")) : 768;
+  static const int slots_env = getenv("EFFDET_DWB_SLOTS") ? atoi(getenv("EFFDET_DWB_SLOTS")) : 0;
+  const int slots = slots_env > 0 ? slots_env : (K == 5 ? 512 : 768);            // (k = 5: 100 weight-gradient accumulators, ~200 VGPRs, 2 workgroups per CU)
   int best = 1; double best_cost = 1e30;
   for (int ppt = 1; ppt <= 64 && ppt <= tpi; ++ppt) {
     const long long nwg = (long long)a.B * ((tpi + ppt - 1) / ppt) * nslab;
@@ -1282,6 +1290,10 @@ int launch_bwd_lds(const DwK& a0, hipStream_t st, bool launch) {
   return rows;
 }
 int bwd_dispatch(const DwK& a, int stride, hipStream_t st, bool launch) {
+  if (a.k == 5) {
+    if (slab_chunks(a.nch) == 4) return stride == 1 ? launch_bwd_lds<5, 1, 4>(a, st, launch) : launch_bwd_lds<5, 2, 4>(a, st, launch);
+    return stride == 1 ? launch_bwd_lds<5, 1, 8>(a, st, launch) : launch_bwd_lds<5, 2, 8>(a, st, launch);
+  }
   if (slab_chunks(a.nch) == 4) return stride == 1 ? launch_bwd_lds<3, 1, 4>(a, st, launch) : launch_bwd_lds<3, 2, 4>(a, st, launch);
   return stride == 1 ? launch_bwd_lds<3, 1, 8>(a, st, launch) : launch_bwd_lds<3, 2, 8>(a, st, launch);
 }
@@ -1289,7 +1301,7 @@ int bwd_dispatch(const DwK& a, int stride, hipStream_t st, bool launch) {
 
 extern "C" long long effdet_dwconv_bwd_workspace_bytes(int dtype, int B, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
                                                         int Ho, int Wo) {
-  if (!bwd_fused_ok(dtype, k, H, W)) return 0;             // 0 = not available for this geometry: use the two separate entry points
+  if (!bwd_fused_ok(dtype, k, stride, H, W)) return 0;             // 0 = not available for this geometry: use the two separate entry points
   DwK a{}; dim3 grid;
   if (fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, H * W, grid)) return -1;
   return (long long)bwd_dispatch(a, stride, nullptr, false) * (k * k + 1) * C * (long long)sizeof(float);
@@ -1299,7 +1311,7 @@ extern "C" int effdet_dwconv_bwd(const void* dz, const float* w, const float* sc
                                  void* workspace, long long workspace_bytes, int dtype, int B, int H, int W, int C, int k, int stride,
                                  int pad_t, int pad_l, int Ho, int Wo, effdet_stream_t stream) {
   if (!dz || !w || !zprev || !dx || !g || !workspace) return EFFDET_EINVAL;
-  if (!bwd_fused_ok(dtype, k, H, W)) return EFFDET_EUNSUPPORTED;
+  if (!bwd_fused_ok(dtype, k, stride, H, W)) return EFFDET_EUNSUPPORTED;
   DwK a{}; dim3 grid;
   int rc = fill(a, dtype, B, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, 4, H * W, grid);
   if (rc) return rc;

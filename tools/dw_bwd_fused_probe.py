@@ -24,7 +24,8 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-for (k, s, C, H) in [(3, 1, 32, 256), (3, 2, 96, 256), (3, 1, 144, 128), (3, 2, 240, 64), (3, 1, 480, 32), (3, 1, 1152, 16)]:
+for (k, s, C, H) in [(3, 1, 32, 256), (3, 2, 96, 256), (3, 1, 144, 128), (3, 2, 240, 64), (3, 1, 480, 32), (3, 1, 1152, 16),
+                     (5, 2, 144, 128), (5, 1, 240, 64), (5, 1, 480, 32), (5, 1, 672, 32), (5, 2, 672, 32), (5, 1, 1152, 16)]:
     pad = tf_same_pad(H, k, s)
     Ho = (H + pad[0] + pad[1] - k) // s + 1
     ze = Map.of(torch.randn(B, H, H, C, device='cuda'))
