@@ -61,16 +61,23 @@ __device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const i
     // (45 us for a few KiB).  Spread the slabs over 256/G thread slices and combine the slices through LDS.
     __shared__ f32x4 sred[256];
     const int SL = 256 / G, slice = threadIdx.x / G, grp = threadIdx.x - slice * G;
-    f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+    // (8 slab loads in flight per thread: with 2, the 512-slab rows of the project convs -- 16..40 workgroups for the whole launch, 50-130
+    //  slabs per thread -- were 25-64 dependent L2 round trips, 35-50 us of a block's backward tail)
+    f32x4 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (slice < SL) {
       int sl = slice;
-      for (; sl + SL < nslabs; sl += 2 * SL) {
-        a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac4(sl, grp * 4);
-        a1 += *(const f32x4*)(grow + grp * 4 + (long long)(sl + SL) * slab_stride) * fac4(sl + SL, grp * 4);
+      for (; sl + 7 * SL < nslabs; sl += 8 * SL) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(grow + grp * 4 + (long long)(sl + u * SL) * slab_stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += v[u] * fac4(sl + u * SL, grp * 4);
       }
-      if (sl < nslabs) a0 += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac4(sl, grp * 4);
+      for (; sl < nslabs; sl += SL) a[0] += *(const f32x4*)(grow + grp * 4 + (long long)sl * slab_stride) * fac4(sl, grp * 4);
     }
-    sred[threadIdx.x] = a0 + a1;
+    sred[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
     if ((int)threadIdx.x < G) {
       f32x4 gv = sred[threadIdx.x];
@@ -82,16 +89,20 @@ __device__ __forceinline__ void unpack_row(const effdet_unpack_job_t& j, const i
   // slab loop unrolled x4 so the loads of different slabs are in flight together
   for (int q4 = by * 256 + threadIdx.x; q4 * 4 < np; q4 += gy * 256) {
     const int pidx = q4 * 4;
-    f32x4 a0 = *(const f32x4*)(grow + pidx) * fac4(0, pidx), a1 = f32x4{0.f, 0.f, 0.f, 0.f}, a2 = a1, a3 = a1;
+    f32x4 a[8];
+    a[0] = *(const f32x4*)(grow + pidx) * fac4(0, pidx);
+#pragma unroll
+    for (int u = 1; u < 8; ++u) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     int sl = 1;
-    for (; sl + 3 < nslabs; sl += 4) {
-      a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac4(sl, pidx);
-      a2 += *(const f32x4*)(grow + pidx + (long long)(sl + 1) * slab_stride) * fac4(sl + 1, pidx);
-      a3 += *(const f32x4*)(grow + pidx + (long long)(sl + 2) * slab_stride) * fac4(sl + 2, pidx);
-      a0 += *(const f32x4*)(grow + pidx + (long long)(sl + 3) * slab_stride) * fac4(sl + 3, pidx);
+    for (; sl + 7 < nslabs; sl += 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const f32x4*)(grow + pidx + (long long)(sl + u) * slab_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += v[u] * fac4(sl + u, pidx);
     }
-    for (; sl < nslabs; ++sl) a1 += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac4(sl, pidx);
-    emit(pidx, (a0 + a1) + (a2 + a3));
+    for (; sl < nslabs; ++sl) a[1] += *(const f32x4*)(grow + pidx + (long long)sl * slab_stride) * fac4(sl, pidx);
+    emit(pidx, ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
   }
   }
   if (wsum || dgamma) {
