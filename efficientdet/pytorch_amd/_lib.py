@@ -86,7 +86,7 @@ _lib = None
 SYMBOLS = [
     'effdet_conv2d', 'effdet_conv2d_kernel', 'effdet_tuning_set', 'effdet_conv2d_wgrad', 'effdet_conv2d_wgrad_workspace_bytes', 'effdet_conv2d_wgrad_splits', 'effdet_conv2d_wgrad_seg_slabs', 'effdet_conv2d_wgrad_kernel', 'effdet_pack_conv_weight', 'effdet_scale_pack_weight', 'effdet_unpack_conv_wgrad', 'effdet_unpack_conv_wgrad_bn', 'effdet_unpack_conv_wgrad_batch', 'effdet_backward_tail', 'effdet_dw_unpack_wgrad_bn', 'effdet_prepare_params',
     'effdet_bn_fold', 'effdet_bn_param_grad', 'effdet_dw_pack_weight', 'effdet_dw_unpack_wgrad', 'effdet_bifpn_weight_bwd',
-    'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_mbconv_expand_dw_fwd', 'effdet_mbconv_expand_dw_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes', 'effdet_dwconv_bwd', 'effdet_dwconv_bwd_workspace_bytes', 'effdet_pw_bwd', 'effdet_pw_bwd_slabs',
+    'effdet_dwconv_fwd', 'effdet_dwconv_fwd_pool_groups', 'effdet_mbconv_expand_dw_fwd', 'effdet_mbconv_expand_dw_pool_groups', 'effdet_dwconv_dgrad', 'effdet_dwconv_wgrad', 'effdet_dwconv_wgrad_workspace_bytes', 'effdet_dwconv_bwd', 'effdet_dwconv_bwd_workspace_bytes', 'effdet_pw_bwd', 'effdet_pw_bwd_slabs', 'effdet_pw_dgrad_se', 'effdet_pw_dgrad_se_supported',
     'effdet_se_gate_fwd', 'effdet_se_gate_fwd_split', 'effdet_channel_scale', 'effdet_se_dgate', 'effdet_se_dgate_slabs', 'effdet_se_dgate_from_wgrad', 'effdet_se_gate_bwd', 'effdet_se_gate_bwd_workspace_floats', 'effdet_se_bwd_apply',
     'effdet_act_bwd', 'effdet_add_inplace', 'effdet_colsum', 'effdet_bifpn_fuse_fwd', 'effdet_bifpn_fuse_fwd2', 'effdet_bifpn_fuse_bwd',
     'effdet_anchors', 'effdet_num_anchors', 'effdet_decode_score', 'effdet_nms_workspace_bytes', 'effdet_nms',

@@ -23,6 +23,7 @@ EXPAND_Z_ONLY = os.environ.get('EFFDET_EXPAND_Z_ONLY', '1') == '1'   # training:
 SE_FUSED = os.environ.get('EFFDET_SE_FUSED', '1') == '1'             # squeeze-excite backward fused into the project conv's gradients
 DW_BWD_FUSED = os.environ.get('EFFDET_DW_BWD_FUSED', '1') == '1'       # training, fp32, k = 3: depthwise data + weight gradient in one kernel
 PW_BWD_FUSED = os.environ.get('EFFDET_PW_BWD_FUSED', '1') == '1'       # training, fp32, Cin 16 / 24 / 32: expand conv data + weight gradient in one kernel
+PW_DGRAD_SE = os.environ.get('EFFDET_PW_DGRAD_SE', '1') == '1'         # training, fp32, Co 16 / 24 / 40: project-conv data gradient + SE backward epilogue as a streaming MFMA kernel
 FUSE_EXPAND_DW = os.environ.get('EFFDET_FUSE_EXPAND_DW', '1') == '1'  # inference, fp32 storage: expand conv inside the depthwise kernel
 FUSE_CIN = tuple(int(v) for v in os.environ.get('EFFDET_FUSE_CIN', '16,24,32').split(','))     # block input widths that take it (A/B)
 # f16x3 BiFPN convs from this much work per launch (output pixels x C^2; x 18 = FLOPs): below ~2 GFLOP the launch is a handful of tiles behind a
@@ -210,9 +211,12 @@ def mbconv_bwd(sv, dy):
         dgg = ops.se_dgate_from_wgrad(G2, wp, sv['s2'], rs, B)
         dpool, dw1, db1, dw2, db2 = ops.se_gate_bwd(dgg, sv['gate'], sv['mid'], sv['pool'], w1, P['se_reduce.bias'], w2,
                                                     sv['inv_hw'], times_gate=not giw)
-        dzd = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
-        ops.conv2d(dy, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dzd, Cin=Co, Cout=Ce, KH=1, KW=1, rowscale=rs,
-                   bc_scale=sv['gate'], bc_shift=dpool, res=sv['zd'], res_mode=ops.RES_SWISH_GRAD)
+        # the high-resolution blocks (Co 16 / 24 / 40 over >= 64 k pixels): a streaming kernel of its own (round 6)
+        dzd = ops.pw_dgrad_se(dy, wp, sv['s2'], rs, sv['gate'], dpool, sv['zd']) if PW_DGRAD_SE and dtype == torch.float32 else None
+        if dzd is None:
+            dzd = Map.new(B, dy.H, dy.W, Ce, dtype, dev)
+            ops.conv2d(dy, ops.pack_weight(wp, dtype, mode=1, scale=sv['s2']), dzd, Cin=Co, Cout=Ce, KH=1, KW=1, rowscale=rs,
+                       bc_scale=sv['gate'], bc_shift=dpool, res=sv['zd'], res_mode=ops.RES_SWISH_GRAD)
     else:
         dz2 = ops.act_bwd(dy, None, ACT_NONE, rowscale=rs) if rs is not None else dy
         G2, dsum2 = ops.conv2d_wgrad(sv['xs'], dz2, Cin=Ce, Cout=Co, KH=1, KW=1)

@@ -893,6 +893,22 @@ def pw_bwd(dz, x, w_expand, scale, res=None):
     return dx, slabs, parts
 
 
+def pw_dgrad_se(dy, w_project, scale, rowscale, gate, dpool, zd):
+    """Project-conv data gradient with the squeeze-excite backward + Swish' epilogue (effdet_pw_dgrad_se) -> dz_d Map, or None when the
+    kernel does not serve the geometry (callers use conv2d(..., bc_scale=gate, bc_shift=dpool, res=zd, res_mode=RES_SWISH_GRAD))."""
+    Cout, Cexp = w_project.shape[0], w_project.shape[1]
+    M = dy.B * dy.H * dy.W
+    dense = all(m.ld == m.C and m.off == 0 and m.bstride == m.H * m.W * m.C and m.dtype == torch.float32 for m in (dy, zd))
+    if not dense or dy.C != Cout or zd.C != Cexp or not int(L.lib().effdet_pw_dgrad_se_supported(C.c_longlong(M), Cout, Cexp)):
+        return None
+    dz = Map.new(zd.B, zd.H, zd.W, Cexp, torch.float32, zd.t.device)
+    _timed('conv_pw_dgrad_se_kernel', 2.0 * Cout * Cexp * M, lambda: L.check(L.lib().effdet_pw_dgrad_se(
+        L.ptr(dy.tensor()), L.ptr(w_project.detach()), L.ptr(scale), L.ptr(rowscale), L.ptr(gate), L.ptr(dpool), L.ptr(zd.tensor()), L.ptr(dz.t),
+        C.c_longlong(M), dy.H * dy.W, dy.B, Cout, Cexp, L.stream_ptr()), 'effdet_pw_dgrad_se'), 'Cout%d Cexp%d M%d' % (Cout, Cexp, M),
+        nbytes=4.0 * M * (Cout + 2 * Cexp))
+    return dz
+
+
 # ----------------------------------------------------------------------------- squeeze-excite
 def se_gate_fwd(pool_part, w1, b1, w2, b2, inv_hw, save_mid=False):
     """pool_part: [B][G][C] partial sums of dwconv_fwd (or a plain [B][C] pool) -> (gate, mid, pool [B][C] = the pooled SUM)."""

@@ -341,6 +341,16 @@ int effdet_dwconv_bwd(const void* dz, const float* w_kkc, const float* scale, co
 int effdet_pw_bwd_slabs(long long M, int Cin, int Cexp);
 int effdet_pw_bwd(const float* dz, const float* x, const float* w_expand, const float* scale, const float* res, float* dx,
                   float* slabs, float* dsum_part, long long M, int Cin, int Cexp, effdet_stream_t stream);
+/* Data gradient of the MBConv project conv (1x1, Cexp -> Cout, frozen BN2 folded) with the squeeze-excite backward and the depthwise
+ * conv's Swish' in its epilogue (models/efficientnet.py:89-104 backward) -- replaces effdet_conv2d(rowscale, bc_scale, bc_shift, res,
+ * EFFDET_RES_SWISH_GRAD) for the high-resolution blocks:
+ *   dz[M][Cexp] = (rowscale[b] * (dy[M][Cout] (scale[co] * w_project[co][ce])) * gate[b][ce] + dpool[b][ce]) * swish'(zd[M][Cexp])
+ * fp32 NHWC, dense rows, M = B * HW pixels; w_project is the OIHW 1x1 master weight [Cout][Cexp] as is; rowscale may be null.
+ * effdet_pw_dgrad_se_supported: Cout in {16, 24, 40}, Cexp % 16 == 0, M >= 65536 (else use effdet_conv2d). */
+int effdet_pw_dgrad_se_supported(long long M, int Cout, int Cexp);
+int effdet_pw_dgrad_se(const float* dy, const float* w_project, const float* scale, const float* rowscale, const float* gate,
+                       const float* dpool, const float* zd, float* dz, long long M, int HW, int B, int Cout, int Cexp,
+                       effdet_stream_t stream);
 /* depthwise weight layout: master [C][1][k][k] fp32 -> [k*k][C];  gradient back:
  * dw[c][t] = scale[c]*g[t][c], wsum[c] = sum_t w[c][t]*g[t][c]. */
 int effdet_dw_pack_weight(const float* w_c1kk, float* out_kkc, int C, int k, effdet_stream_t stream);

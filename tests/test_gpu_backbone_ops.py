@@ -177,6 +177,36 @@ def test_expand_conv_fused_data_and_weight_gradient(cfg):
     assert_close_scale(dgam.cpu(), dgam_s.cpu(), 2e-5, 'fused vs separate dgamma'); assert_close_scale(dbeta.cpu(), dbeta_s.cpu(), 2e-6, 'fused vs separate dbeta')
 
 
+@pytest.mark.parametrize('cfg', [(2, 256, 256, 16, 96, True), (8, 128, 128, 24, 96, True), (5, 128, 128, 24, 144, False), (17, 64, 64, 40, 144, True),
+                                 (16, 64, 67, 40, 240, True), (3, 201, 117, 24, 144, True)])
+def test_project_conv_data_gradient_with_se_epilogue(cfg):
+    """effdet_pw_dgrad_se (project-conv data gradient + squeeze-excite backward + Swish' in one streaming MFMA kernel; models/efficientnet.py:89-104
+    backward) vs float64, vs the implicit-GEMM / skinny launch it replaces; two launches bitwise equal."""
+    from efficientdet.pytorch_amd import ops
+    from efficientdet.pytorch_amd.ops import Map
+    B, H, W, Co, Ce, use_rs = cfg
+    g = torch.Generator().manual_seed(13)
+    dev = 'cuda'
+    dy = torch.randn(B, H, W, Co, generator=g).to(dev); zd = torch.randn(B, H, W, Ce, generator=g).to(dev)
+    wp = (torch.randn(Co, Ce, 1, 1, generator=g) / Ce ** 0.5).to(dev); s2 = (0.5 + torch.rand(Co, generator=g)).to(dev)
+    gate = torch.rand(B, Ce, generator=g).to(dev); dpool = (torch.randn(B, Ce, generator=g) * 1e-2).to(dev)
+    rs = (0.5 + torch.rand(B, generator=g)).to(dev) if use_rs else None
+    out = ops.pw_dgrad_se(Map.of(dy), wp, s2, rs, gate, dpool, Map.of(zd))
+    assert out is not None
+    out2 = ops.pw_dgrad_se(Map.of(dy), wp, s2, rs, gate, dpool, Map.of(zd))
+    assert torch.equal(out.tensor(), out2.tensor())
+    ws = (wp.view(Co, Ce) * s2.view(-1, 1)).double()
+    v = (dy.double().view(B, -1, Co) @ ws) * (rs.double().view(B, 1, 1) if use_rs else 1.0)
+    v = v * gate.double().view(B, 1, Ce) + dpool.double().view(B, 1, Ce)
+    z = zd.double().view(B, -1, Ce); sg = torch.sigmoid(z)
+    ref = (v * (sg * (1 + z * (1 - sg)))).float().view(B, H, W, Ce)
+    assert_close(out.tensor().cpu(), ref.cpu(), 2e-4, 'project dgrad + SE epilogue')
+    sep = Map.new(B, H, W, Ce, torch.float32, dev)
+    ops.conv2d(Map.of(dy), ops.pack_weight(wp, torch.float32, mode=1, scale=s2), sep, Cin=Co, Cout=Ce, KH=1, KW=1, rowscale=rs,
+               bc_scale=gate, bc_shift=dpool, res=Map.of(zd), res_mode=ops.RES_SWISH_GRAD)
+    assert_close_scale(out.tensor().cpu(), sep.tensor().cpu(), 5e-6, 'streaming kernel vs the launch it replaces')
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cfg', [(2, 8, 8, 96, 4), (3, 5, 7, 240, 10), (2, 2, 2, 1152, 48), (2, 1, 1, 32, 8), (5, 3, 3, 144, 6), (2, 4, 4, 672, 28)])
 def test_squeeze_excite_fwd_bwd(dtype, cfg):
