@@ -130,7 +130,7 @@ extern "C" int effdet_pw_dgrad_se(const float* dy, const float* w_project, const
   if (!dy || !w_project || !gate || !dpool || !zd || !dz || HW < 1 || B < 1 || (long long)B * HW != M) return EFFDET_EINVAL;
   if (!effdet_pw_dgrad_se_supported(M, Co, Ce)) return EFFDET_EUNSUPPORTED;
   static const int slots_env = getenv("EFFDET_PWD_SLOTS") ? atoi(getenv("EFFDET_PWD_SLOTS")) : 0;
-  const int slots = slots_env > 0 ? slots_env : (Co == 40 ? 768 : 1024);                                  // resident workgroups (3 / 4 per CU)
+  const int slots = slots_env > 0 ? slots_env : 768;       // resident workgroups: 3 per CU (swept 512 / 768 / 1024 / 1536: 768 is best or within 4 % of it on every shape)
   const long long ntiles = (M + 63) / 64;
   PwDgK k{dy, w_project, scale, rowscale, gate, dpool, zd, dz, M, HW, Ce, (int)ntiles,
           (unsigned)(M * Co * 4), (unsigned)(M * Ce * 4), (unsigned)((long long)B * Ce * 4)};
