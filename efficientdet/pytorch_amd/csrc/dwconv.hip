@@ -1285,7 +1285,11 @@ int launch_bwd_lds(const DwK& a0, hipStream_t st, bool launch) {
   DwK a = a0; dim3 grid; size_t lds;
   const int rows = bwd_geometry<K, S, CQ>(a, grid, lds);
   if (!launch) return rows;
-  EFFDET_SET_MAX_LDS((dw_bwd_lds_kernel<K, S, CQ>), lds);
+  {  // (the attribute is set once per device: the largest request of this instantiation, not the first launch's)
+    typedef BwTile<K, S, CQ> TL;
+    const size_t mx = (size_t)2 * TL::npiece(64 / CQ) * 1024 + (size_t)K * K * CQ * 16, red = (size_t)4 * (K * K + 1) * CQ * 16;
+    EFFDET_SET_MAX_LDS((dw_bwd_lds_kernel<K, S, CQ>), (mx > red ? mx : red));
+  }
   hipLaunchKernelGGL((dw_bwd_lds_kernel<K, S, CQ>), grid, dim3(256), lds, st, a);
   return rows;
 }
